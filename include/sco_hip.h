@@ -1,0 +1,214 @@
+/*
+ * sco_hip.h -- C ABI of libsco_hip.so, the MI355X (gfx950) implementation of the
+ * sco_py `sco_osqp` hot path.
+ *
+ * The reference (Algorithmic-Alignment-Lab/sco_py) is pure Python and has no FFI
+ * of its own: its boundary is the Python object API.  This library sits UNDER
+ * that API.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference tree).  Plain C, caller-owned host buffers,
+ * int return codes, no pointer retained past a call except through a handle.
+ * All arithmetic is float64.
+ *
+ * Two layers:
+ *   sco_qp_*   batched QP solve, B problems sharing one sparsity pattern.
+ *              Replaces osqp.OSQP().setup(...) / .solve() as called from
+ *              sco_py/sco_osqp/osqp_utils.py:195-216 (one QP per call there).
+ *   sco_sqp_*  the whole penalty-SQP loop for a batch of trajectory problems,
+ *              device resident.  Replaces, per problem,
+ *              Solver._penalty_sqp / _min_merit_fn (sco_py/sco_osqp/solver.py:62-253)
+ *              together with the Prob methods it drives: find_closest_feasible_point
+ *              (prob.py:369-412), convexify (:522-544), update_obj (:414-426),
+ *              add_trust_region (:514-519), optimize (:146-205), get_value (:547-579),
+ *              get_approx_value (:605-630), get_max_cnt_violation (:592-603),
+ *              save/restore (:639-652).
+ */
+#ifndef SCO_HIP_H
+#define SCO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes ------------------------------------------------------- */
+#define SCO_OK              0
+#define SCO_ERR_ARG        -1   /* bad argument (null pointer, negative size, bad pattern) */
+#define SCO_ERR_DEVICE     -2   /* HIP runtime error (see sco_last_error)                  */
+#define SCO_ERR_NO_GPU     -3   /* no gfx950 device visible                                */
+#define SCO_ERR_STATE      -4   /* call order violated (e.g. solve before load)            */
+#define SCO_ERR_CAPACITY   -5   /* problem too large for the on-chip working set            */
+
+/* ---- per-problem QP status: OSQP's status_val, which the reference tests at
+ *      prob.py:197 (success iff status in {1, 2}) and osqp_utils.py:218 ---------- */
+#define SCO_QP_SOLVED                 1
+#define SCO_QP_SOLVED_INACCURATE      2
+#define SCO_QP_MAX_ITER_REACHED      -2
+#define SCO_QP_PRIMAL_INFEASIBLE     -3
+#define SCO_QP_PRIMAL_INFEASIBLE_INACCURATE 3
+#define SCO_QP_DUAL_INFEASIBLE       -4
+#define SCO_QP_DUAL_INFEASIBLE_INACCURATE   4
+#define SCO_QP_NON_CVX               -7
+#define SCO_QP_UNSOLVED             -10
+
+const char *sco_last_error(void);
+int sco_version(void);
+/* Number of usable gfx950 devices (0 is a valid answer; never initialises a context). */
+int sco_device_count(int *count);
+
+/* ---- QP layer ----------------------------------------------------------- */
+
+/* Settings handed to osqp.OSQP().setup at osqp_utils.py:197-214 plus the OSQP
+ * defaults the reference leaves untouched (alpha, scaling, check_termination,
+ * infeasibility tolerances).  sco_qp_default_settings fills the values the
+ * reference uses: osqp_utils.py:10-15 and OSQP 0.6 defaults. */
+typedef struct sco_qp_settings {
+  double rho;               /* osqp_utils.py:12  DEFAULT_RHO = 0.1       */
+  double sigma;             /* osqp_utils.py:11  DEFAULT_SIGMA = 5e-10   */
+  double alpha;             /* OSQP default 1.6                          */
+  double eps_abs;           /* osqp_utils.py:14  1e-6                    */
+  double eps_rel;           /* osqp_utils.py:15  1e-9                    */
+  double eps_prim_inf;      /* OSQP default 1e-4                         */
+  double eps_dual_inf;      /* OSQP default 1e-4                         */
+  int max_iter;             /* osqp_utils.py:10  100000                  */
+  int check_termination;    /* OSQP default 25                           */
+  int scaling;              /* OSQP default 10 Ruiz passes               */
+  int reserved;
+} sco_qp_settings;
+
+void sco_qp_default_settings(sco_qp_settings *s);
+
+typedef struct sco_qp sco_qp;
+
+/* Create a solver for `batch` QPs
+ *     min 1/2 x'Px + q'x   s.t.  l <= Ax <= u
+ * that share one sparsity pattern: P (n x n) by its UPPER triangle in CSC form
+ * (P_colptr[n+1], P_rowidx[nnzP]; the reference builds an upper-triangular P,
+ * osqp_utils.py:153-163) and A (m x n) in CSC form (A_colptr[n+1],
+ * A_rowidx[nnzA]).  Row indices inside a column must be strictly increasing.
+ * The symbolic analysis (elimination set, dense core, index plans) happens here,
+ * once. */
+int sco_qp_create(int device, int batch, int n, int m,
+                  const int *P_colptr, const int *P_rowidx,
+                  const int *A_colptr, const int *A_rowidx,
+                  sco_qp **out);
+int sco_qp_destroy(sco_qp *qp);
+
+/* Upload values, problem-major: P_val[batch][nnzP], q[batch][n], A_val[batch][nnzA],
+ * l[batch][m], u[batch][m].  Infinite bounds may be +-inf or anything beyond
+ * +-1e30 (OSQP's Python wrapper clamps at 1e30 the same way).
+ * row_weight[batch][m] (may be NULL = all 1) says how many times each row is
+ * present: the reference re-appends its penalty rows on every update_obj call
+ * (prob.py:508-509), which this ABI represents as an integer multiplicity. */
+int sco_qp_load(sco_qp *qp, const double *P_val, const double *q,
+                const double *A_val, const double *l, const double *u,
+                const int *row_weight);
+
+/* Replace only l and u (trust-region retry: variable.py:43-45 changes nothing else). */
+int sco_qp_set_bounds(sco_qp *qp, const double *l, const double *u);
+
+/* Solve all problems of the batch from a cold start (the reference rebuilds the
+ * OSQP object for every QP, osqp_utils.py:195, so x0 = y0 = 0).
+ * Outputs (any may be NULL): x[batch][n], y[batch][m], status[batch] (SCO_QP_*),
+ * iters[batch], resid[batch][2] = {primal, dual} residual at termination. */
+int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings,
+                 double *x, double *y, int *status, int *iters, double *resid);
+
+/* Sizes chosen by the symbolic analysis (for tests and DESIGN.md):
+ * info[0] = size of the eliminated set, info[1] = dense core order,
+ * info[2] = LDS bytes of the ADMM kernel, info[3] = nnz of the coupling block. */
+int sco_qp_info(const sco_qp *qp, int info[4]);
+
+/* Device time of the last sco_qp_solve, split by kernel, in milliseconds,
+ * measured with HIP events on the library's own stream:
+ * ms[0] = setup (scaling + factor), ms[1] = ADMM loop. */
+int sco_qp_last_timing(const sco_qp *qp, double ms[2]);
+
+/* ---- SQP layer ---------------------------------------------------------- */
+
+/* Solver knobs, one-to-one with the attributes of sco_py.sco_osqp.solver.Solver
+ * (solver.py:17-28). */
+typedef struct sco_sqp_params {
+  double improve_ratio_threshold;    /* 0.25  */
+  double min_trust_region_size;      /* 1e-4  */
+  double min_approx_improve;         /* 1e-8  */
+  double trust_shrink_ratio;         /* 0.1   */
+  double trust_expand_ratio;         /* 1.5   */
+  double cnt_tolerance;              /* 1e-4  */
+  double merit_coeff_increase_ratio; /* 10    */
+  double initial_trust_region_size;  /* 1     */
+  double initial_penalty_coeff;      /* 1e3   */
+  int max_merit_coeff_increases;     /* 1     */
+  /* Reference behaviours that look unintended but are load-bearing for result
+   * parity.  1 = reproduce (default), 0 = the "intended" form. */
+  int compound_penalty;     /* Q1: slack cost multiplied in place by penalty_coeff on
+                               every update_obj (prob.py:424-426)                      */
+  int duplicate_rows;       /* Q2: penalty rows appended again on every update_obj
+                               (prob.py:508-509) -> row multiplicity k                 */
+  int max_sqp_iters;        /* safety cap on QP solves per problem; the reference's
+                               loops are unbounded (solver.py:126, 136), 0 = 10000     */
+} sco_sqp_params;
+
+void sco_sqp_default_params(sco_sqp_params *p);
+
+/* Device-evaluable constraint families (the reference differentiates arbitrary
+ * Python callables, expr.py:22-41; a GPU cannot). */
+#define SCO_FAM_ARM_CIRCLES 1  /* planar serial arm, link points vs circular obstacles:
+                                  g[k*O + o](theta) = r_o - || p_k(theta) - c_o ||  <= 0 */
+
+/* Structure of a batch of trajectory problems (shared by all `batch` problems):
+ * variables theta[t][j], t < horizon, j < dof, flattened time-major (n_x = horizon*dof);
+ * objective   sum_t || theta[t+1] - theta[t] ||^2      (a QuadExpr, expr.py:184-213)
+ * linear      theta[0] = start, theta[horizon-1] = goal (EqExpr(AffExpr), prob.py:126-128)
+ * nonlinear   one LEqExpr block of n_points*n_obstacles rows per timestep (family above),
+ *             Jacobians by central finite differences on device. */
+typedef struct sco_trajopt_desc {
+  int batch;
+  int dof;
+  int horizon;
+  int n_points;      /* link points per arm configuration   */
+  int n_obstacles;   /* circular obstacles per problem      */
+  int family;        /* SCO_FAM_*                           */
+  int analytic_jac;  /* 0: finite differences (reference default, expr.py:86-87), 1: analytic */
+  int reserved;
+} sco_trajopt_desc;
+
+typedef struct sco_sqp sco_sqp;
+
+int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out);
+int sco_sqp_destroy(sco_sqp *h);
+
+/* Upload per-problem data (host pointers, problem-major):
+ *   x0[batch][horizon*dof]   initial trajectory
+ *   start[batch][dof], goal[batch][dof]
+ *   link_len[batch][dof]
+ *   point_link[n_points] (shared), point_frac[n_points] (shared): point k sits at
+ *       fraction point_frac[k] along link point_link[k]
+ *   obstacles[batch][n_obstacles][3] = (cx, cy, radius) */
+int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, const double *goal,
+                 const double *link_len, const int *point_link, const double *point_frac,
+                 const double *obstacles);
+
+/* Run Solver.solve(prob, method="penalty_sqp") for every problem of the batch
+ * (solver.py:30-105) starting from the loaded state; blocks until all are done. */
+int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco_qp_settings *qp_settings);
+
+/* Results (any pointer may be NULL): x[batch][n_x] final trajectories,
+ * success[batch] (return value of Solver.solve), sqp_iters[batch] (passes of the
+ * outer loop body solver.py:126-253), qp_solves[batch], admm_iters[batch] (sum),
+ * merit[batch], max_violation[batch] (prob.py:592-603). */
+int sco_sqp_fetch(sco_sqp *h, double *x, int *success, int *sqp_iters, int *qp_solves,
+                  long long *admm_iters, double *merit, double *max_violation);
+
+/* Per-problem decision trace of the last solve, for stage-wise parity checks:
+ * trace[batch][cap][8] = {kind, merit, model_merit, new_merit, trust, penalty,
+ * qp_status, qp_iters}; n_entries[batch].  kind: 0 projection QP, 1 accepted step,
+ * 2 shrink, 3 y-converged, 4 x-converged, 5 bad model, 6 group-converged. */
+int sco_sqp_trace(sco_sqp *h, int cap, double *trace, int *n_entries);
+
+/* Device milliseconds of the last sco_sqp_solve by stage (HIP events):
+ * ms[0] convexify+assemble, ms[1] qp setup, ms[2] admm, ms[3] merit/decision, ms[4] total. */
+int sco_sqp_last_timing(const sco_sqp *h, double ms[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCO_HIP_H */

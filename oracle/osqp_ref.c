@@ -1,0 +1,720 @@
+/*
+ * oracle/osqp_ref.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, single thread, float64) of the QP solve stage S6
+ * of the reference hot path.  The reference calls the third-party OSQP C
+ * library at /root/reference/sco_py/sco_osqp/osqp_utils.py:195-216
+ *     m = osqp.OSQP(); m.setup(P, q, A, rho, sigma, l, u, eps_abs, eps_rel,
+ *                             delta=1e-7, polish=False, adaptive_rho,
+ *                             warm_start=True, verbose=False, max_iter)
+ *     solve_res = m.solve()
+ * OSQP itself (osqp 0.6.2.post5 + qdldl 0.1.5.post2, poetry.lock:101-102,
+ * 231-232) is NOT vendored under /root/reference and is not installed in the
+ * build container, so this file restates its *published* algorithm
+ * (Stellato et al., "OSQP: an operator splitting solver for quadratic
+ * programs", Math. Prog. Comp. 2020, Algorithm 1 + sec. 3-5) with the
+ * library defaults of the 0.6 series for every setting the reference does not
+ * override:
+ *     alpha = 1.6, scaling = 10 Ruiz passes, check_termination = 25,
+ *     eps_prim_inf = eps_dual_inf = 1e-4, scaled_termination = 0,
+ *     rho_eq = 1e3 * rho on rows with u - l < 1e-4, rho_min = 1e-6 on rows
+ *     with both bounds infinite, infinity clamp 1e30, scaling clamp
+ *     [1e-4, 1e4], cold start x = z = y = 0 (the reference
+ *     rebuilds the OSQP object for every QP so warm_start is inert).
+ *
+ * PARITY STATUS: "parity unpinned" at the iterate level -- OSQP's iterate
+ * sequence, iteration counts and sub-tolerance digits cannot be checked here
+ * (library absent).  The SOLUTION is pinned by the reference's own analytic
+ * known-answer tests at this boundary (tests/sco_osqp/test_variable.py:39-96,
+ * test_prob.py:48-430, test_solver.py:91-169), see tests/test_oracle_kat.py.
+ *
+ * Linear system: the quasi-definite KKT matrix
+ *     [ P + sigma I      A'      ]
+ *     [     A       -diag(1/rho) ]
+ * is factored once per QP with a sparse up-looking LDL' (the algorithm of
+ * T. Davis' LDL package, which QDLDL follows) after a minimum-degree
+ * ordering, then solved once per ADMM iteration -- the same structure as
+ * OSQP's default "qdldl" linear-system backend.
+ *
+ * Row multiplicities: `w` (may be NULL) gives an integer weight per row of A.
+ * w[i] = k means "this row is present k times" (the reference
+ * re-appends its penalty rows on every update_obj call, prob.py:508-509).
+ * With expand_dups = 1 the rows are physically replicated before anything
+ * else happens (faithful mode); with expand_dups = 0 the weight is folded
+ * into the algebra (mathematically identical iterates; used to validate the
+ * folded form the HIP kernels use).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#define OSQP_INFTY 1e30
+#define MIN_SCALING 1e-4
+#define MAX_SCALING 1e4
+#define RHO_MIN 1e-6
+#define RHO_TOL 1e-4
+#define RHO_EQ_OVER_RHO_INEQ 1e3
+
+typedef struct {
+  double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  int max_iter, check_termination, scaling;
+  int expand_dups; /* 1: replicate weighted rows physically, 0: fold weights */
+  int linsys;      /* 0: sparse KKT LDL' (OSQP default), 1: dense reduced Cholesky */
+} osqp_ref_settings;
+
+typedef struct {
+  int status;      /* OSQP status_val: 1, 2, -2, -3, 3, -4, 4 */
+  int iters;
+  double obj, pri_res, dua_res;
+} osqp_ref_info;
+
+void osqp_ref_default_settings(osqp_ref_settings *s) {
+  s->rho = 0.1; s->sigma = 5e-10; s->alpha = 1.6;
+  s->eps_abs = 1e-6; s->eps_rel = 1e-9;
+  s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
+  s->max_iter = 100000; s->check_termination = 25; s->scaling = 10;
+  s->expand_dups = 1; s->linsys = 0;
+}
+
+static double dmax(double a, double b) { return a > b ? a : b; }
+static double dmin(double a, double b) { return a < b ? a : b; }
+
+/* ---------------------------------------------------------------- LDL' --- */
+/* Up-looking sparse LDL' of a symmetric matrix given by its UPPER triangle in
+ * CSC form (diagonal included).  Classic elimination-tree formulation. */
+typedef struct {
+  int N;
+  int *Lp, *Li, *Parent, *Lnz, *Flag, *Pattern;
+  double *Lx, *D, *Dinv, *Y;
+  int *perm, *iperm;   /* perm[new] = old */
+  double *work;
+} ldl_t;
+
+static void ldl_free(ldl_t *f) {
+  if (!f) return;
+  free(f->Lp); free(f->Li); free(f->Parent); free(f->Lnz); free(f->Flag);
+  free(f->Pattern); free(f->Lx); free(f->D); free(f->Dinv); free(f->Y);
+  free(f->perm); free(f->iperm); free(f->work); free(f);
+}
+
+static void ldl_symbolic(ldl_t *f, const int *Ap, const int *Ai) {
+  int N = f->N;
+  for (int k = 0; k < N; k++) {
+    f->Parent[k] = -1; f->Flag[k] = k; f->Lnz[k] = 0;
+    for (int p = Ap[k]; p < Ap[k + 1]; p++) {
+      int i = Ai[p];
+      if (i < k) {
+        for (; f->Flag[i] != k; i = f->Parent[i]) {
+          if (f->Parent[i] == -1) f->Parent[i] = k;
+          f->Lnz[i]++; f->Flag[i] = k;
+        }
+      }
+    }
+  }
+  f->Lp[0] = 0;
+  for (int k = 0; k < N; k++) f->Lp[k + 1] = f->Lp[k] + f->Lnz[k];
+}
+
+static int ldl_numeric(ldl_t *f, const int *Ap, const int *Ai, const double *Ax) {
+  int N = f->N;
+  int *Lp = f->Lp, *Li = f->Li, *Parent = f->Parent, *Lnz = f->Lnz;
+  int *Flag = f->Flag, *Pattern = f->Pattern;
+  double *Lx = f->Lx, *D = f->D, *Y = f->Y;
+  for (int k = 0; k < N; k++) {
+    Y[k] = 0.0; int top = N; Flag[k] = k; Lnz[k] = 0;
+    for (int p = Ap[k]; p < Ap[k + 1]; p++) {
+      int i = Ai[p];
+      if (i <= k) {
+        Y[i] += Ax[p];
+        int len = 0;
+        for (; Flag[i] != k; i = Parent[i]) { Pattern[len++] = i; Flag[i] = k; }
+        while (len > 0) Pattern[--top] = Pattern[--len];
+      }
+    }
+    D[k] = Y[k]; Y[k] = 0.0;
+    for (; top < N; top++) {
+      int i = Pattern[top];
+      double yi = Y[i]; Y[i] = 0.0;
+      int p2 = Lp[i] + Lnz[i];
+      for (int p = Lp[i]; p < p2; p++) Y[Li[p]] -= Lx[p] * yi;
+      double lki = yi / D[i];
+      D[k] -= lki * yi;
+      Li[p2] = k; Lx[p2] = lki; Lnz[i]++;
+    }
+    if (D[k] == 0.0) return k;
+    f->Dinv[k] = 1.0 / D[k];
+  }
+  return N;
+}
+
+/* solve K x = b in place (b in ORIGINAL ordering) */
+static void ldl_solve(ldl_t *f, double *b) {
+  int N = f->N; double *x = f->work;
+  for (int k = 0; k < N; k++) x[k] = b[f->perm[k]];
+  for (int j = 0; j < N; j++) {
+    double xj = x[j];
+    for (int p = f->Lp[j]; p < f->Lp[j + 1]; p++) x[f->Li[p]] -= f->Lx[p] * xj;
+  }
+  for (int j = 0; j < N; j++) x[j] *= f->Dinv[j];
+  for (int j = N - 1; j >= 0; j--) {
+    double xj = x[j];
+    for (int p = f->Lp[j]; p < f->Lp[j + 1]; p++) xj -= f->Lx[p] * x[f->Li[p]];
+    x[j] = xj;
+  }
+  for (int k = 0; k < N; k++) b[f->perm[k]] = x[k];
+}
+
+/* ------------------------------------------------ minimum-degree ordering --- */
+/* Plain (exact external degree, no supervariables) minimum-degree ordering on
+ * the symmetric pattern given as full adjacency lists.  N is a few thousand at
+ * most; ordering quality matters more than ordering speed here. */
+typedef struct { int *v; int n, cap; } ivec;
+static void iv_push(ivec *a, int x) {
+  if (a->n == a->cap) { a->cap = a->cap ? 2 * a->cap : 8; a->v = (int *)realloc(a->v, sizeof(int) * a->cap); }
+  a->v[a->n++] = x;
+}
+
+static void min_degree_order(int N, const int *Up, const int *Ui, int *perm) {
+  /* Up/Ui: upper-triangular CSC pattern. Build the symmetric adjacency lists. */
+  ivec *adj = (ivec *)calloc(N, sizeof(ivec));
+  for (int j = 0; j < N; j++)
+    for (int p = Up[j]; p < Up[j + 1]; p++) {
+      int i = Ui[p];
+      if (i != j) { iv_push(&adj[i], j); iv_push(&adj[j], i); }
+    }
+  char *dead = (char *)calloc(N, 1);
+  int *mark = (int *)malloc(sizeof(int) * N);
+  for (int i = 0; i < N; i++) mark[i] = -1;
+  for (int i = 0; i < N; i++) {            /* drop duplicate neighbours */
+    int w = 0;
+    for (int t = 0; t < adj[i].n; t++) {
+      int u = adj[i].v[t];
+      if (mark[u] != i) { mark[u] = i; adj[i].v[w++] = u; }
+    }
+    adj[i].n = w;
+  }
+  for (int i = 0; i < N; i++) mark[i] = -1;
+  for (int k = 0; k < N; k++) {
+    int v = -1, bdeg = 0x7fffffff;
+    for (int i = 0; i < N; i++)            /* first node of minimum degree */
+      if (!dead[i] && adj[i].n < bdeg) { bdeg = adj[i].n; v = i; }
+    perm[k] = v; dead[v] = 1;
+    int nn = adj[v].n; const int *nb = adj[v].v;
+    for (int a = 0; a < nn; a++) {         /* neighbours of v become a clique */
+      int u = nb[a], w = 0;
+      for (int t = 0; t < adj[u].n; t++) {
+        int x = adj[u].v[t];
+        if (x == v) continue;
+        adj[u].v[w++] = x; mark[x] = u;
+      }
+      adj[u].n = w; mark[u] = u;
+      for (int b = 0; b < nn; b++) {
+        int x = nb[b];
+        if (mark[x] != u) { iv_push(&adj[u], x); mark[x] = u; }
+      }
+      for (int t = 0; t < adj[u].n; t++) mark[adj[u].v[t]] = -1;
+      mark[u] = -1;
+    }
+    free(adj[v].v); adj[v].v = NULL; adj[v].n = adj[v].cap = 0;
+  }
+  for (int i = 0; i < N; i++) free(adj[i].v);
+  free(adj); free(dead); free(mark);
+}
+
+/* ------------------------------------------------------------- workspace --- */
+typedef struct {
+  int n, m;
+  /* scaled data */
+  int *Pp, *Pi; double *Px;   /* upper CSC */
+  int *Ap, *Ai; double *Ax;   /* CSC */
+  double *wt;                 /* row weights (all 1 when expanded) */
+  double *q, *l, *u;
+  double *D, *E, *Dinv, *Einv; double c, cinv;
+  double *rho_vec, *rho_inv;
+} qp_t;
+
+static void mat_vec_A(const qp_t *w, const double *x, double *y) { /* y = A x */
+  for (int i = 0; i < w->m; i++) y[i] = 0.0;
+  for (int j = 0; j < w->n; j++)
+    for (int p = w->Ap[j]; p < w->Ap[j + 1]; p++) y[w->Ai[p]] += w->Ax[p] * x[j];
+}
+static void mat_tvec_A(const qp_t *w, const double *y, double *x, int weighted) { /* x = A' (w.*y) */
+  for (int j = 0; j < w->n; j++) {
+    double s = 0.0;
+    for (int p = w->Ap[j]; p < w->Ap[j + 1]; p++)
+      s += w->Ax[p] * y[w->Ai[p]] * (weighted ? w->wt[w->Ai[p]] : 1.0);
+    x[j] = s;
+  }
+}
+static void mat_vec_Psym(const qp_t *w, const double *x, double *y) { /* y = P x, P from triu */
+  for (int j = 0; j < w->n; j++) y[j] = 0.0;
+  for (int j = 0; j < w->n; j++)
+    for (int p = w->Pp[j]; p < w->Pp[j + 1]; p++) {
+      int i = w->Pi[p];
+      y[i] += w->Px[p] * x[j];
+      if (i != j) y[j] += w->Px[p] * x[i];
+    }
+}
+static double norm_inf(const double *v, int n) {
+  double r = 0.0; for (int i = 0; i < n; i++) r = dmax(r, fabs(v[i])); return r;
+}
+static double scaled_norm_inf(const double *s, const double *v, int n) {
+  double r = 0.0; for (int i = 0; i < n; i++) r = dmax(r, fabs(s[i] * v[i])); return r;
+}
+static void limit_scaling(double *D, int n) {
+  for (int i = 0; i < n; i++) {
+    D[i] = D[i] < MIN_SCALING ? 1.0 : D[i];
+    D[i] = D[i] > MAX_SCALING ? MAX_SCALING : D[i];
+  }
+}
+
+/* Ruiz equilibration of [[P, A'],[A, 0]] + cost normalisation, `iters` passes. */
+static void scale_data(qp_t *w, int iters) {
+  int n = w->n, m = w->m;
+  double *Dt = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+  double *DtA = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+  double *Et = (double *)malloc(sizeof(double) * (m > 0 ? m : 1));
+  w->c = 1.0;
+  for (int i = 0; i < n; i++) w->D[i] = 1.0;
+  for (int i = 0; i < m; i++) w->E[i] = 1.0;
+  for (int it = 0; it < iters; it++) {
+    /* inf-norms of the KKT columns */
+    for (int j = 0; j < n; j++) { Dt[j] = 0.0; DtA[j] = 0.0; }
+    for (int i = 0; i < m; i++) Et[i] = 0.0;
+    for (int j = 0; j < n; j++)
+      for (int p = w->Pp[j]; p < w->Pp[j + 1]; p++) {
+        int i = w->Pi[p]; double a = fabs(w->Px[p]);
+        Dt[j] = dmax(Dt[j], a);
+        if (i != j) Dt[i] = dmax(Dt[i], a);
+      }
+    for (int j = 0; j < n; j++)
+      for (int p = w->Ap[j]; p < w->Ap[j + 1]; p++) {
+        double a = fabs(w->Ax[p]);
+        DtA[j] = dmax(DtA[j], a);
+        Et[w->Ai[p]] = dmax(Et[w->Ai[p]], a);
+      }
+    for (int j = 0; j < n; j++) Dt[j] = dmax(Dt[j], DtA[j]);
+    limit_scaling(Dt, n); limit_scaling(Et, m);
+    for (int j = 0; j < n; j++) Dt[j] = 1.0 / sqrt(Dt[j]);
+    for (int i = 0; i < m; i++) Et[i] = 1.0 / sqrt(Et[i]);
+    /* P <- D P D ; A <- E A D ; q <- D q */
+    for (int j = 0; j < n; j++)
+      for (int p = w->Pp[j]; p < w->Pp[j + 1]; p++) {
+        w->Px[p] *= Dt[w->Pi[p]];   /* premult rows   */
+      }
+    for (int j = 0; j < n; j++)
+      for (int p = w->Pp[j]; p < w->Pp[j + 1]; p++) w->Px[p] *= Dt[j]; /* postmult cols */
+    for (int j = 0; j < n; j++)
+      for (int p = w->Ap[j]; p < w->Ap[j + 1]; p++) w->Ax[p] *= Et[w->Ai[p]];
+    for (int j = 0; j < n; j++)
+      for (int p = w->Ap[j]; p < w->Ap[j + 1]; p++) w->Ax[p] *= Dt[j];
+    for (int j = 0; j < n; j++) w->q[j] *= Dt[j];
+    for (int j = 0; j < n; j++) w->D[j] *= Dt[j];
+    for (int i = 0; i < m; i++) w->E[i] *= Et[i];
+    /* cost normalisation */
+    for (int j = 0; j < n; j++) Dt[j] = 0.0;
+    for (int j = 0; j < n; j++)
+      for (int p = w->Pp[j]; p < w->Pp[j + 1]; p++) {
+        int i = w->Pi[p]; double a = fabs(w->Px[p]);
+        Dt[j] = dmax(Dt[j], a);
+        if (i != j) Dt[i] = dmax(Dt[i], a);
+      }
+    double c_temp = 0.0;
+    for (int j = 0; j < n; j++) c_temp += Dt[j];
+    c_temp = n > 0 ? c_temp / n : 0.0;
+    double nq = norm_inf(w->q, n);
+    limit_scaling(&nq, 1);
+    c_temp = dmax(c_temp, nq);
+    limit_scaling(&c_temp, 1);
+    c_temp = 1.0 / c_temp;
+    for (int p = 0; p < w->Pp[n]; p++) w->Px[p] *= c_temp;
+    for (int j = 0; j < n; j++) w->q[j] *= c_temp;
+    w->c *= c_temp;
+  }
+  w->cinv = 1.0 / w->c;
+  for (int j = 0; j < n; j++) w->Dinv[j] = 1.0 / w->D[j];
+  for (int i = 0; i < m; i++) w->Einv[i] = 1.0 / w->E[i];
+  for (int i = 0; i < m; i++) { w->l[i] *= w->E[i]; w->u[i] *= w->E[i]; }
+  free(Dt); free(DtA); free(Et);
+}
+
+static void set_rho_vec(qp_t *w, double rho) {
+  for (int i = 0; i < w->m; i++) {
+    if (w->l[i] < -OSQP_INFTY * MIN_SCALING && w->u[i] > OSQP_INFTY * MIN_SCALING)
+      w->rho_vec[i] = RHO_MIN;
+    else if (w->u[i] - w->l[i] < RHO_TOL)
+      w->rho_vec[i] = RHO_EQ_OVER_RHO_INEQ * rho;
+    else
+      w->rho_vec[i] = rho;
+    w->rho_inv[i] = 1.0 / w->rho_vec[i];
+  }
+}
+
+/* Build the factorisation of the KKT matrix (linsys 0). */
+static ldl_t *kkt_factor(const qp_t *w, double sigma) {
+  int n = w->n, m = w->m, N = n + m;
+  /* CSR of A (== CSC of A') */
+  int *Rp = (int *)calloc(m + 1, sizeof(int));
+  int nnzA = w->Ap[n], nnzP = w->Pp[n];
+  for (int p = 0; p < nnzA; p++) Rp[w->Ai[p] + 1]++;
+  for (int i = 0; i < m; i++) Rp[i + 1] += Rp[i];
+  int *Rj = (int *)malloc(sizeof(int) * (nnzA > 0 ? nnzA : 1));
+  double *Rx = (double *)malloc(sizeof(double) * (nnzA > 0 ? nnzA : 1));
+  int *cur = (int *)malloc(sizeof(int) * (m > 0 ? m : 1));
+  for (int i = 0; i < m; i++) cur[i] = Rp[i];
+  for (int j = 0; j < n; j++)
+    for (int p = w->Ap[j]; p < w->Ap[j + 1]; p++) {
+      int i = w->Ai[p]; Rj[cur[i]] = j; Rx[cur[i]] = w->Ax[p]; cur[i]++;
+    }
+  /* upper-triangular KKT in CSC, original ordering */
+  int cap = nnzP + n + nnzA + m;
+  int *Kp = (int *)malloc(sizeof(int) * (N + 1));
+  int *Ki = (int *)malloc(sizeof(int) * cap);
+  double *Kx = (double *)malloc(sizeof(double) * cap);
+  int nz = 0;
+  for (int j = 0; j < n; j++) {
+    Kp[j] = nz; int has_diag = 0;
+    for (int p = w->Pp[j]; p < w->Pp[j + 1]; p++) {
+      int i = w->Pi[p];
+      Ki[nz] = i; Kx[nz] = w->Px[p];
+      if (i == j) { Kx[nz] += sigma; has_diag = 1; }
+      nz++;
+    }
+    if (!has_diag) { Ki[nz] = j; Kx[nz] = sigma; nz++; }
+  }
+  for (int i = 0; i < m; i++) {
+    Kp[n + i] = nz;
+    for (int p = Rp[i]; p < Rp[i + 1]; p++) { Ki[nz] = Rj[p]; Kx[nz] = Rx[p]; nz++; }
+    /* weight k on a folded row == k copies each with -1/rho: Schur-equivalent
+       single row scaled by sqrt is NOT what we do; instead use -1/(k rho). */
+    Ki[nz] = n + i; Kx[nz] = -w->rho_inv[i] / w->wt[i]; nz++;
+  }
+  Kp[N] = nz;
+  ldl_t *f = (ldl_t *)calloc(1, sizeof(ldl_t));
+  f->N = N;
+  f->perm = (int *)malloc(sizeof(int) * N); f->iperm = (int *)malloc(sizeof(int) * N);
+  min_degree_order(N, Kp, Ki, f->perm);
+  for (int k = 0; k < N; k++) f->iperm[f->perm[k]] = k;
+  /* symmetric permutation -> upper CSC of P K P' */
+  int *Cp = (int *)calloc(N + 1, sizeof(int));
+  for (int j = 0; j < N; j++)
+    for (int p = Kp[j]; p < Kp[j + 1]; p++) {
+      int a = f->iperm[Ki[p]], b = f->iperm[j];
+      int col = a > b ? a : b; Cp[col + 1]++;
+    }
+  for (int j = 0; j < N; j++) Cp[j + 1] += Cp[j];
+  int *Ci = (int *)malloc(sizeof(int) * nz);
+  double *Cx = (double *)malloc(sizeof(double) * nz);
+  int *cc = (int *)malloc(sizeof(int) * N);
+  for (int j = 0; j < N; j++) cc[j] = Cp[j];
+  for (int j = 0; j < N; j++)
+    for (int p = Kp[j]; p < Kp[j + 1]; p++) {
+      int a = f->iperm[Ki[p]], b = f->iperm[j];
+      int col = a > b ? a : b, row = a > b ? b : a;
+      Ci[cc[col]] = row; Cx[cc[col]] = Kx[p]; cc[col]++;
+    }
+  f->Lp = (int *)malloc(sizeof(int) * (N + 1));
+  f->Parent = (int *)malloc(sizeof(int) * N); f->Lnz = (int *)malloc(sizeof(int) * N);
+  f->Flag = (int *)malloc(sizeof(int) * N); f->Pattern = (int *)malloc(sizeof(int) * N);
+  f->D = (double *)malloc(sizeof(double) * N); f->Dinv = (double *)malloc(sizeof(double) * N);
+  f->Y = (double *)malloc(sizeof(double) * N); f->work = (double *)malloc(sizeof(double) * N);
+  ldl_symbolic(f, Cp, Ci);
+  int lnz = f->Lp[N];
+  f->Li = (int *)malloc(sizeof(int) * (lnz > 0 ? lnz : 1));
+  f->Lx = (double *)malloc(sizeof(double) * (lnz > 0 ? lnz : 1));
+  int ok = ldl_numeric(f, Cp, Ci, Cx);
+  free(Rp); free(Rj); free(Rx); free(cur); free(Kp); free(Ki); free(Kx);
+  free(Cp); free(Ci); free(Cx); free(cc);
+  if (ok != N) { ldl_free(f); return NULL; }
+  return f;
+}
+
+/* Dense reduced form (linsys 1): K = P + sigma I + A' diag(w rho) A, Cholesky. */
+typedef struct { int n; double *L; } chol_t;
+static chol_t *reduced_factor(const qp_t *w, double sigma) {
+  int n = w->n;
+  chol_t *c = (chol_t *)calloc(1, sizeof(chol_t)); c->n = n;
+  double *K = (double *)calloc((size_t)n * n, sizeof(double));
+  for (int j = 0; j < n; j++)
+    for (int p = w->Pp[j]; p < w->Pp[j + 1]; p++) {
+      int i = w->Pi[p]; K[(size_t)i * n + j] += w->Px[p]; if (i != j) K[(size_t)j * n + i] += w->Px[p];
+    }
+  for (int j = 0; j < n; j++) K[(size_t)j * n + j] += sigma;
+  /* A' R A via CSR rows */
+  int m = w->m, nnzA = w->Ap[n];
+  int *Rp = (int *)calloc(m + 1, sizeof(int));
+  for (int p = 0; p < nnzA; p++) Rp[w->Ai[p] + 1]++;
+  for (int i = 0; i < m; i++) Rp[i + 1] += Rp[i];
+  int *Rj = (int *)malloc(sizeof(int) * (nnzA > 0 ? nnzA : 1));
+  double *Rx = (double *)malloc(sizeof(double) * (nnzA > 0 ? nnzA : 1));
+  int *cur = (int *)malloc(sizeof(int) * (m > 0 ? m : 1));
+  for (int i = 0; i < m; i++) cur[i] = Rp[i];
+  for (int j = 0; j < n; j++)
+    for (int p = w->Ap[j]; p < w->Ap[j + 1]; p++) { int i = w->Ai[p]; Rj[cur[i]] = j; Rx[cur[i]] = w->Ax[p]; cur[i]++; }
+  for (int i = 0; i < m; i++) {
+    double r = w->rho_vec[i] * w->wt[i];
+    for (int p = Rp[i]; p < Rp[i + 1]; p++)
+      for (int t = Rp[i]; t < Rp[i + 1]; t++)
+        K[(size_t)Rj[p] * n + Rj[t]] += r * Rx[p] * Rx[t];
+  }
+  free(Rp); free(Rj); free(Rx); free(cur);
+  /* in-place lower Cholesky */
+  for (int j = 0; j < n; j++) {
+    double d = K[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= K[(size_t)j * n + k] * K[(size_t)j * n + k];
+    if (d <= 0.0) { free(K); free(c); return NULL; }
+    d = sqrt(d); K[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = K[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) s -= K[(size_t)i * n + k] * K[(size_t)j * n + k];
+      K[(size_t)i * n + j] = s / d;
+    }
+  }
+  c->L = K; return c;
+}
+static void chol_solve(const chol_t *c, double *b) {
+  int n = c->n; const double *L = c->L;
+  for (int i = 0; i < n; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= L[(size_t)i * n + k] * b[k];
+    b[i] = s / L[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = b[i];
+    for (int k = i + 1; k < n; k++) s -= L[(size_t)k * n + i] * b[k];
+    b[i] = s / L[(size_t)i * n + i];
+  }
+}
+
+/* ------------------------------------------------------------------ solve --- */
+typedef struct {
+  qp_t *W; const osqp_ref_settings *st;
+  double *x, *z, *y, *dx, *dy;          /* current iterates / last increments */
+  double *Ax_, *Px_, *Aty, *tn, *tm;    /* work */
+  double pri, dua, obj;
+} admm_t;
+
+/* residuals of the UNSCALED problem (OSQP default scaled_termination = 0) */
+static void update_info(admm_t *a) {
+  qp_t *W = a->W; int n = W->n, m = W->m;
+  mat_vec_A(W, a->x, a->Ax_);
+  double pri = 0.0;
+  for (int i = 0; i < m; i++) pri = dmax(pri, fabs(W->Einv[i] * (a->Ax_[i] - a->z[i])));
+  mat_vec_Psym(W, a->x, a->Px_);
+  mat_tvec_A(W, a->y, a->Aty, 1);
+  double dua = 0.0, obj = 0.0;
+  for (int j = 0; j < n; j++) dua = dmax(dua, fabs(W->Dinv[j] * (W->q[j] + a->Px_[j] + a->Aty[j])));
+  for (int j = 0; j < n; j++) obj += 0.5 * a->x[j] * a->Px_[j] + W->q[j] * a->x[j];
+  a->pri = pri; a->dua = dua * W->cinv; a->obj = obj * W->cinv;
+}
+
+static int is_primal_infeasible(admm_t *a, double eps) {
+  qp_t *W = a->W; int n = W->n, m = W->m; double *dy = a->dy;
+  /* project delta_y onto the polar of the recession cone of [l, u] */
+  for (int i = 0; i < m; i++) {
+    if (W->u[i] > OSQP_INFTY * MIN_SCALING) {
+      if (W->l[i] < -OSQP_INFTY * MIN_SCALING) dy[i] = 0.0; else dy[i] = dmin(dy[i], 0.0);
+    } else if (W->l[i] < -OSQP_INFTY * MIN_SCALING) dy[i] = dmax(dy[i], 0.0);
+  }
+  double ndy = scaled_norm_inf(W->E, dy, m);
+  if (ndy > eps) {
+    double lhs = 0.0;
+    for (int i = 0; i < m; i++) lhs += W->wt[i] * (W->u[i] * dmax(dy[i], 0.0) + W->l[i] * dmin(dy[i], 0.0));
+    if (lhs < -eps * ndy) {
+      mat_tvec_A(W, dy, a->tn, 1);
+      return scaled_norm_inf(W->Dinv, a->tn, n) < eps * ndy;
+    }
+  }
+  return 0;
+}
+
+static int is_dual_infeasible(admm_t *a, double eps) {
+  qp_t *W = a->W; int n = W->n, m = W->m; double *dx = a->dx;
+  double ndx = scaled_norm_inf(W->D, dx, n);
+  if (ndx > eps) {
+    double qdx = 0.0; for (int j = 0; j < n; j++) qdx += W->q[j] * dx[j];
+    if (qdx < -W->c * eps * ndx) {
+      mat_vec_Psym(W, dx, a->tn);
+      if (scaled_norm_inf(W->Dinv, a->tn, n) < W->c * eps * ndx) {
+        mat_vec_A(W, dx, a->tm);
+        for (int i = 0; i < m; i++) {
+          double v = W->Einv[i] * a->tm[i];
+          if ((W->u[i] < OSQP_INFTY * MIN_SCALING && v > eps * ndx) ||
+              (W->l[i] > -OSQP_INFTY * MIN_SCALING && v < -eps * ndx)) return 0;
+        }
+        return 1;
+      }
+    }
+  }
+  return 0;
+}
+
+/* returns the OSQP status_val if a criterion fires, 0 otherwise */
+static int check_termination(admm_t *a, int approximate) {
+  qp_t *W = a->W; const osqp_ref_settings *st = a->st; int n = W->n, m = W->m;
+  double ea = st->eps_abs, er = st->eps_rel, epi = st->eps_prim_inf, edi = st->eps_dual_inf;
+  if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+  int prim_ok = 0, dual_ok = 0, prim_inf = 0, dual_inf = 0;
+  if (a->pri > OSQP_INFTY || a->dua > OSQP_INFTY) return -7;
+  if (m == 0) prim_ok = 1;
+  else {
+    double eps_p = ea + er * dmax(scaled_norm_inf(W->Einv, a->z, m), scaled_norm_inf(W->Einv, a->Ax_, m));
+    if (a->pri < eps_p) prim_ok = 1; else prim_inf = is_primal_infeasible(a, epi);
+  }
+  double mr = scaled_norm_inf(W->Dinv, W->q, n);
+  mr = dmax(mr, scaled_norm_inf(W->Dinv, a->Aty, n));
+  mr = dmax(mr, scaled_norm_inf(W->Dinv, a->Px_, n));
+  double eps_d = ea + er * W->cinv * mr;
+  if (a->dua < eps_d) dual_ok = 1; else dual_inf = is_dual_infeasible(a, edi);
+  if (prim_ok && dual_ok) return approximate ? 2 : 1;
+  if (prim_inf) return approximate ? 3 : -3;
+  if (dual_inf) return approximate ? 4 : -4;
+  return 0;
+}
+
+/* Optional per-check trace: trace[4*k + {0,1,2,3}] = iter, pri_res, dua_res, obj
+ * for the k-th termination check, up to trace_cap entries. */
+int osqp_ref_solve(int n, int m_in,
+                   const int *Pp, const int *Pi, const double *Px,   /* upper-tri CSC */
+                   const double *q,
+                   const int *Ap, const int *Ai, const double *Ax,   /* CSC, m rows */
+                   const double *l, const double *u,
+                   const int *w,                                     /* row weights or NULL */
+                   const osqp_ref_settings *st,
+                   double *x_out, double *y_out, osqp_ref_info *info,
+                   double *trace, int trace_cap, int *trace_len) {
+  qp_t W; memset(&W, 0, sizeof(W));
+  int expand = (w != NULL) && st->expand_dups;
+  /* --- row expansion map ------------------------------------------------ */
+  int m = m_in;
+  int *rowstart = (int *)malloc(sizeof(int) * (m_in + 1));
+  rowstart[0] = 0;
+  for (int i = 0; i < m_in; i++) rowstart[i + 1] = rowstart[i] + (expand ? (w[i] > 0 ? w[i] : 0) : 1);
+  m = rowstart[m_in];
+  W.n = n; W.m = m;
+  int nnzP = Pp[n];
+  W.Pp = (int *)malloc(sizeof(int) * (n + 1)); memcpy(W.Pp, Pp, sizeof(int) * (n + 1));
+  W.Pi = (int *)malloc(sizeof(int) * (nnzP > 0 ? nnzP : 1)); memcpy(W.Pi, Pi, sizeof(int) * nnzP);
+  W.Px = (double *)malloc(sizeof(double) * (nnzP > 0 ? nnzP : 1)); memcpy(W.Px, Px, sizeof(double) * nnzP);
+  int nnzA = 0;
+  for (int p = 0; p < Ap[n]; p++) nnzA += rowstart[Ai[p] + 1] - rowstart[Ai[p]];
+  W.Ap = (int *)malloc(sizeof(int) * (n + 1));
+  W.Ai = (int *)malloc(sizeof(int) * (nnzA > 0 ? nnzA : 1));
+  W.Ax = (double *)malloc(sizeof(double) * (nnzA > 0 ? nnzA : 1));
+  {
+    int nz = 0;
+    for (int j = 0; j < n; j++) {
+      W.Ap[j] = nz;
+      for (int p = Ap[j]; p < Ap[j + 1]; p++)
+        for (int r = rowstart[Ai[p]]; r < rowstart[Ai[p] + 1]; r++) { W.Ai[nz] = r; W.Ax[nz] = Ax[p]; nz++; }
+    }
+    W.Ap[n] = nz;
+  }
+  int mm = m > 0 ? m : 1, nn = n > 0 ? n : 1;
+  W.wt = (double *)malloc(sizeof(double) * mm);
+  W.l = (double *)malloc(sizeof(double) * mm); W.u = (double *)malloc(sizeof(double) * mm);
+  for (int i = 0; i < m_in; i++) {
+    /* OSQP's Python wrapper clamps infinities to +-OSQP_INFTY before setup */
+    double li = dmax(l[i], -OSQP_INFTY), ui = dmin(u[i], OSQP_INFTY);
+    for (int r = rowstart[i]; r < rowstart[i + 1]; r++) {
+      W.l[r] = li; W.u[r] = ui; W.wt[r] = (expand || !w) ? 1.0 : (double)w[i];
+    }
+  }
+  W.q = (double *)malloc(sizeof(double) * nn); memcpy(W.q, q, sizeof(double) * n);
+  W.D = (double *)malloc(sizeof(double) * nn); W.Dinv = (double *)malloc(sizeof(double) * nn);
+  W.E = (double *)malloc(sizeof(double) * mm); W.Einv = (double *)malloc(sizeof(double) * mm);
+  W.rho_vec = (double *)malloc(sizeof(double) * mm); W.rho_inv = (double *)malloc(sizeof(double) * mm);
+
+  /* --- setup: scale, rho, factor ----------------------------------------- */
+  if (st->scaling > 0) scale_data(&W, st->scaling);
+  else {
+    W.c = W.cinv = 1.0;
+    for (int j = 0; j < n; j++) W.D[j] = W.Dinv[j] = 1.0;
+    for (int i = 0; i < m; i++) W.E[i] = W.Einv[i] = 1.0;
+  }
+  set_rho_vec(&W, st->rho);
+  ldl_t *F = NULL; chol_t *C = NULL;
+  if (st->linsys == 0) F = kkt_factor(&W, st->sigma); else C = reduced_factor(&W, st->sigma);
+  int rc = 0;
+  double *x = (double *)calloc(nn, sizeof(double)), *xp = (double *)calloc(nn, sizeof(double));
+  double *z = (double *)calloc(mm, sizeof(double)), *zp = (double *)calloc(mm, sizeof(double));
+  double *y = (double *)calloc(mm, sizeof(double));
+  double *xz = (double *)calloc(nn + mm, sizeof(double));
+  admm_t a; memset(&a, 0, sizeof(a));
+  a.W = &W; a.st = st; a.y = y;
+  a.dx = (double *)calloc(nn, sizeof(double)); a.dy = (double *)calloc(mm, sizeof(double));
+  a.Ax_ = (double *)calloc(mm, sizeof(double)); a.Px_ = (double *)calloc(nn, sizeof(double));
+  a.Aty = (double *)calloc(nn, sizeof(double)); a.tn = (double *)calloc(nn, sizeof(double));
+  a.tm = (double *)calloc(mm, sizeof(double));
+  if (trace_len) *trace_len = 0;
+  info->status = -10; info->iters = 0; info->obj = 0; info->pri_res = 0; info->dua_res = 0;
+  if (!F && !C) { rc = -1; info->status = -7; }
+  else {
+    const double alpha = st->alpha, sigma = st->sigma;
+    int iter, status = 0, checked = 0;
+    for (iter = 1; iter <= st->max_iter; iter++) {
+      { double *t = x; x = xp; xp = t; t = z; z = zp; zp = t; }
+      /* ---- x~, z~ ---- */
+      if (F) {
+        for (int j = 0; j < n; j++) xz[j] = sigma * xp[j] - W.q[j];
+        for (int i = 0; i < m; i++) xz[n + i] = zp[i] - W.rho_inv[i] * y[i];
+        ldl_solve(F, xz);
+        /* folded weight k: KKT block is -1/(k rho), nu is the sum of the k
+           identical multipliers, so z~ = rhs + nu / (k rho) */
+        for (int i = 0; i < m; i++)
+          xz[n + i] = (zp[i] - W.rho_inv[i] * y[i]) + (W.rho_inv[i] / W.wt[i]) * xz[n + i];
+      } else {
+        /* (P + sigma I + A' R A) x~ = sigma x - q + A'(R z - y),  R = w rho */
+        for (int i = 0; i < m; i++) a.tm[i] = W.rho_vec[i] * zp[i] - y[i];
+        mat_tvec_A(&W, a.tm, a.tn, 1);
+        for (int j = 0; j < n; j++) xz[j] = sigma * xp[j] - W.q[j] + a.tn[j];
+        chol_solve(C, xz);
+        mat_vec_A(&W, xz, xz + n);           /* z~ = A x~ */
+      }
+      /* ---- x, z, y ---- */
+      for (int j = 0; j < n; j++) { x[j] = alpha * xz[j] + (1.0 - alpha) * xp[j]; a.dx[j] = x[j] - xp[j]; }
+      for (int i = 0; i < m; i++) {
+        double zr = alpha * xz[n + i] + (1.0 - alpha) * zp[i];
+        double zi = zr + W.rho_inv[i] * y[i];
+        zi = dmin(dmax(zi, W.l[i]), W.u[i]);
+        z[i] = zi;
+        a.dy[i] = W.rho_vec[i] * (zr - zi);
+        y[i] += a.dy[i];
+      }
+      checked = st->check_termination && (iter % st->check_termination == 0);
+      if (!checked) continue;
+      a.x = x; a.z = z;
+      update_info(&a);
+      if (trace && trace_len && *trace_len < trace_cap) {
+        int k = *trace_len; trace[4 * k] = iter; trace[4 * k + 1] = a.pri; trace[4 * k + 2] = a.dua; trace[4 * k + 3] = a.obj; (*trace_len)++;
+      }
+      status = check_termination(&a, 0);
+      if (status) break;
+    }
+    if (!status) {
+      iter = st->max_iter;
+      a.x = x; a.z = z;
+      if (!checked) { update_info(&a); status = check_termination(&a, 0); }
+      if (!status) status = check_termination(&a, 1);
+      if (!status) status = -2;
+    }
+    info->status = status; info->iters = iter;
+    info->pri_res = a.pri; info->dua_res = a.dua; info->obj = a.obj;
+    /* unscale solution */
+    for (int j = 0; j < n; j++) x_out[j] = W.D[j] * x[j];
+    if (y_out)
+      for (int i = 0; i < m_in; i++) {   /* logical row multiplier = sum over its copies */
+        double s = 0.0;
+        for (int r = rowstart[i]; r < rowstart[i + 1]; r++) s += W.cinv * W.E[r] * y[r] * W.wt[r];
+        y_out[i] = s;
+      }
+  }
+  ldl_free(F); if (C) { free(C->L); free(C); }
+  free(x); free(xp); free(z); free(zp); free(y); free(xz);
+  free(a.dx); free(a.dy); free(a.Ax_); free(a.Px_); free(a.Aty); free(a.tn); free(a.tm);
+  free(W.Pp); free(W.Pi); free(W.Px); free(W.Ap); free(W.Ai); free(W.Ax); free(W.wt);
+  free(W.q); free(W.l); free(W.u); free(W.D); free(W.Dinv); free(W.E); free(W.Einv);
+  free(W.rho_vec); free(W.rho_inv); free(rowstart);
+  return rc;
+}

@@ -1,0 +1,69 @@
+// sco_internal.h -- shared between the QP layer (sco_qp.hip) and the SQP layer
+// (sco_sqp.hip).  Not part of the public ABI (that is include/sco_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sco_hip.h"
+#include "qp_plan.h"
+
+#define SCO_INFTY 1e30
+#define SCO_MIN_SCALING 1e-4
+#define SCO_MAX_SCALING 1e4
+#define SCO_RHO_MIN 1e-6
+#define SCO_RHO_TOL 1e-4
+#define SCO_RHO_EQ_OVER_RHO_INEQ 1e3
+
+#define SCO_BLOCK 256   // threads per workgroup (4 wavefronts of 64)
+
+void sco_set_error(const std::string &msg);
+int sco_hip_fail(hipError_t e, const char *what);
+#define SCO_HIP(call)                                                         \
+  do {                                                                        \
+    hipError_t _e = (call);                                                   \
+    if (_e != hipSuccess) return sco_hip_fail(_e, #call);                     \
+  } while (0)
+
+// Device-side view of one batched QP: plans (shared) + per-problem value arrays.
+struct QpDev {
+  int n, m, nnzP, nnzA, n_e, n_c, ncpl, nS, batch;
+  // shared index plans
+  const int *Ap, *Ai, *Rp, *Rj, *Rpos, *Fp, *Fi, *Fpos, *Pdiag;
+  const int *elim_var, *core_var, *elim_of, *core_of;
+  const int *e_ptr, *pair_core, *pair_elim, *cp_ptr, *cp_row, *cp_pa, *cp_pe, *a_ptr, *a_pair;
+  const int *s_a, *s_b, *s_ppos, *sa_ptr, *sa_row, *sa_pa, *sa_pb, *ss_ptr, *ss_k1, *ss_k2, *ss_e;
+  // per-problem inputs (unscaled), problem-major
+  double *Pval, *q, *Aval, *l, *u;
+  int *w;
+  // per-problem scaled data and factor, written by the setup kernel
+  double *Ps, *As, *qs, *ls, *us, *D, *E, *cscale, *rho, *kee_inv, *cpl, *W;
+  // per-problem outputs
+  double *x, *y, *resid;
+  int *status, *iters;
+  // optional per-problem activity mask (NULL = all active); inactive problems
+  // are skipped by both kernels
+  const int *active;
+};
+
+struct sco_qp {
+  int device = 0;
+  QpPlan plan;
+  QpDev d{};
+  const int *Pp_dev = nullptr, *Pi_dev = nullptr;   // device copies of the P triu pattern
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  std::vector<void *> allocs;
+  bool loaded = false;
+  size_t lds_setup = 0, lds_admm = 0;
+  double last_ms[2] = {0, 0};
+};
+
+// Internal (device-pointer) entry points used by the SQP layer.
+int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, const int *Pi,
+                            const int *Ap, const int *Ai, hipStream_t stream, sco_qp **out);
+// Launch setup + ADMM on the handle's stream for the problems whose active flag
+// is non-zero; no host synchronisation.
+int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev);

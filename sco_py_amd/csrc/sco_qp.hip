@@ -1,0 +1,759 @@
+// sco_qp.hip -- batched OSQP-style ADMM for gfx950 (MI355X), QP layer of libsco_hip.
+//
+// Replaces the third-party OSQP solve the reference performs once per QP at
+// /root/reference/sco_py/sco_osqp/osqp_utils.py:195-216.  Algorithm (scaling,
+// rho selection, ADMM recurrences, termination and infeasibility tests) follows
+// the published OSQP method with the 0.6-series defaults; see oracle/osqp_ref.c
+// for the CPU restatement every result here is tested against.
+//
+// Mapping to the hardware
+//   * one workgroup (256 threads = 4 wavefronts) per problem, grid = batch;
+//   * qp_setup_kernel: Ruiz equilibration, rho vector, reduced matrix assembly,
+//     dense Cholesky + inverse of the core Schur complement -- all in LDS;
+//   * qp_admm_kernel: the whole ADMM loop of one problem inside one launch with
+//     every iterate (x, z, y), the scaled A values and the coupling block held
+//     in LDS; HBM is touched once to load the problem, once per iteration for
+//     the dense core inverse W (L2 resident), and once to store the answer;
+//   * residual norms use wavefront shuffles + one LDS hop across the 4 waves;
+//   * no atomics, fixed summation orders: results are run-to-run deterministic.
+#include "sco_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+// --------------------------------------------------------------------------
+// error plumbing
+// --------------------------------------------------------------------------
+static thread_local std::string g_err;
+void sco_set_error(const std::string &msg) { g_err = msg; }
+int sco_hip_fail(hipError_t e, const char *what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return SCO_ERR_DEVICE;
+}
+extern "C" const char *sco_last_error(void) { return g_err.c_str(); }
+extern "C" int sco_version(void) { return 100; }
+
+extern "C" int sco_device_count(int *count) {
+  if (!count) return SCO_ERR_ARG;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return SCO_OK; }
+  *count = n;
+  return SCO_OK;
+}
+
+extern "C" void sco_qp_default_settings(sco_qp_settings *s) {
+  if (!s) return;
+  s->rho = 0.1; s->sigma = 5e-10; s->alpha = 1.6;
+  s->eps_abs = 1e-6; s->eps_rel = 1e-9;
+  s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
+  s->max_iter = 100000; s->check_termination = 25; s->scaling = 10; s->reserved = 0;
+}
+
+// --------------------------------------------------------------------------
+// device helpers
+// --------------------------------------------------------------------------
+#define NWAVE (SCO_BLOCK / 64)
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Reduce NR per-thread values across the workgroup; every thread gets the
+// result.  `red` is NWAVE*NR doubles of LDS.  Fixed tree => deterministic.
+template <int NR, bool IS_MAX>
+__device__ __forceinline__ void block_reduce(double (&v)[NR], double *red) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NR; k++) v[k] = IS_MAX ? wave_max(v[k]) : wave_sum(v[k]);
+  __syncthreads();   // protect `red` against a previous use
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NR; k++) red[wv * NR + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    double r = red[k];
+#pragma unroll
+    for (int w = 1; w < NWAVE; w++) r = IS_MAX ? fmax(r, red[w * NR + k]) : r + red[w * NR + k];
+    v[k] = r;
+  }
+}
+
+__device__ __forceinline__ double limit_scaling(double v) {
+  v = v < SCO_MIN_SCALING ? 1.0 : v;
+  return v > SCO_MAX_SCALING ? SCO_MAX_SCALING : v;
+}
+
+__host__ __device__ __forceinline__ size_t tri_idx(int i, int j) {   // packed lower, j <= i
+  return (size_t)i * (i + 1) / 2 + j;
+}
+
+// --------------------------------------------------------------------------
+// setup kernel: scale, rho, reduced matrix, factor, inverse
+// --------------------------------------------------------------------------
+struct SetupArgs {
+  QpDev d;
+  const int *Pp, *Pi;
+  double rho, sigma;
+  int scaling;
+};
+
+__global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
+  const QpDev &d = a.d;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (d.active && !d.active[b]) return;
+  const int n = d.n, m = d.m, nnzP = d.nnzP, nnzA = d.nnzA, n_e = d.n_e, n_c = d.n_c, ncpl = d.ncpl;
+
+  extern __shared__ double lds[];
+  double *Ps = lds;                 // nnzP
+  double *As = Ps + nnzP;           // nnzA
+  double *qs = As + nnzA;           // n
+  double *D = qs + n;               // n
+  double *E = D + n;                // m
+  double *Dt = E + m;               // n   (later: kinv[n_e])
+  double *Et = Dt + n;              // m   (later: rw[m])
+  double *cpl = Et + m;             // ncpl
+  double *red = cpl + ncpl;         // NWAVE * 2
+  double *Lp = red + NWAVE * 2;     // n_c (n_c + 1) / 2
+
+  const double *Pval = d.Pval + (size_t)b * nnzP;
+  const double *Aval = d.Aval + (size_t)b * nnzA;
+  for (int t = tid; t < nnzP; t += SCO_BLOCK) Ps[t] = Pval[t];
+  for (int t = tid; t < nnzA; t += SCO_BLOCK) As[t] = Aval[t];
+  for (int j = tid; j < n; j += SCO_BLOCK) { qs[j] = d.q[(size_t)b * n + j]; D[j] = 1.0; }
+  for (int i = tid; i < m; i += SCO_BLOCK) E[i] = 1.0;
+  double c = 1.0;
+  __syncthreads();
+
+  for (int it = 0; it < a.scaling; it++) {
+    // inf-norms of the columns of [[P, A'], [A, 0]]
+    for (int j = tid; j < n; j += SCO_BLOCK) {
+      double v = 0.0;
+      for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) v = fmax(v, fabs(Ps[d.Fpos[t]]));
+      for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) v = fmax(v, fabs(As[t]));
+      Dt[j] = 1.0 / sqrt(limit_scaling(v));
+    }
+    for (int i = tid; i < m; i += SCO_BLOCK) {
+      double v = 0.0;
+      for (int t = d.Rp[i]; t < d.Rp[i + 1]; t++) v = fmax(v, fabs(As[d.Rpos[t]]));
+      Et[i] = 1.0 / sqrt(limit_scaling(v));
+    }
+    __syncthreads();
+    // P <- Dt P Dt, A <- Et A Dt, q <- Dt q
+    for (int j = tid; j < n; j += SCO_BLOCK) {
+      const double dj = Dt[j];
+      for (int t = a.Pp[j]; t < a.Pp[j + 1]; t++) Ps[t] = (Ps[t] * Dt[a.Pi[t]]) * dj;
+      for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) As[t] = (As[t] * Et[d.Ai[t]]) * dj;
+      qs[j] *= dj; D[j] *= dj;
+    }
+    for (int i = tid; i < m; i += SCO_BLOCK) E[i] *= Et[i];
+    __syncthreads();
+    // cost normalisation: c = 1 / max(mean col-norm of P, ||q||_inf)
+    double r2[2] = {0.0, 0.0};
+    for (int j = tid; j < n; j += SCO_BLOCK) {
+      double v = 0.0;
+      for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) v = fmax(v, fabs(Ps[d.Fpos[t]]));
+      r2[0] += v;
+    }
+    {
+      double s1[1] = {r2[0]};
+      block_reduce<1, false>(s1, red);
+      r2[0] = s1[0];
+      double mq = 0.0;
+      for (int j = tid; j < n; j += SCO_BLOCK) mq = fmax(mq, fabs(qs[j]));
+      double s2[1] = {mq};
+      block_reduce<1, true>(s2, red);
+      r2[1] = s2[0];
+    }
+    double ct = n > 0 ? r2[0] / (double)n : 0.0;
+    ct = fmax(ct, limit_scaling(r2[1]));
+    ct = 1.0 / limit_scaling(ct);
+    for (int t = tid; t < nnzP; t += SCO_BLOCK) Ps[t] *= ct;
+    for (int j = tid; j < n; j += SCO_BLOCK) qs[j] *= ct;
+    c *= ct;
+    __syncthreads();
+  }
+
+  // scaled bounds, rho vector; Et becomes rw = w * rho
+  {
+    double *ls = d.ls + (size_t)b * m, *us = d.us + (size_t)b * m, *rho = d.rho + (size_t)b * m;
+    const double *l = d.l + (size_t)b * m, *u = d.u + (size_t)b * m;
+    const int *w = d.w + (size_t)b * m;
+    for (int i = tid; i < m; i += SCO_BLOCK) {
+      double li = fmax(l[i], -SCO_INFTY) * E[i], ui = fmin(u[i], SCO_INFTY) * E[i];
+      ls[i] = li; us[i] = ui;
+      double r;
+      if (li < -SCO_INFTY * SCO_MIN_SCALING && ui > SCO_INFTY * SCO_MIN_SCALING) r = SCO_RHO_MIN;
+      else if (ui - li < SCO_RHO_TOL) r = SCO_RHO_EQ_OVER_RHO_INEQ * a.rho;
+      else r = a.rho;
+      rho[i] = r;
+      Et[i] = r * (double)w[i];
+    }
+  }
+  // publish the scaled problem
+  {
+    double *gPs = d.Ps + (size_t)b * nnzP, *gAs = d.As + (size_t)b * nnzA;
+    for (int t = tid; t < nnzP; t += SCO_BLOCK) gPs[t] = Ps[t];
+    for (int t = tid; t < nnzA; t += SCO_BLOCK) gAs[t] = As[t];
+    for (int j = tid; j < n; j += SCO_BLOCK) { d.qs[(size_t)b * n + j] = qs[j]; d.D[(size_t)b * n + j] = D[j]; }
+    for (int i = tid; i < m; i += SCO_BLOCK) d.E[(size_t)b * m + i] = E[i];
+    if (tid == 0) d.cscale[b] = c;
+  }
+  __syncthreads();
+
+  // ---- K_EE^-1 (diagonal) and the coupling block K_CE ----------------------
+  double *kinv = Dt;
+  for (int e = tid; e < n_e; e += SCO_BLOCK) {
+    const int ve = d.elim_var[e];
+    double v = a.sigma;
+    if (d.Pdiag[ve] >= 0) v += Ps[d.Pdiag[ve]];
+    for (int t = d.Ap[ve]; t < d.Ap[ve + 1]; t++) v += Et[d.Ai[t]] * As[t] * As[t];
+    v = 1.0 / v;
+    kinv[e] = v; d.kee_inv[(size_t)b * n_e + e] = v;
+  }
+  for (int k = tid; k < ncpl; k += SCO_BLOCK) {
+    double v = 0.0;
+    for (int t = d.cp_ptr[k]; t < d.cp_ptr[k + 1]; t++) v += Et[d.cp_row[t]] * As[d.cp_pa[t]] * As[d.cp_pe[t]];
+    cpl[k] = v; d.cpl[(size_t)b * ncpl + k] = v;
+  }
+  const size_t ntri = (size_t)n_c * (n_c + 1) / 2;
+  for (size_t t = tid; t < ntri; t += SCO_BLOCK) Lp[t] = 0.0;
+  __syncthreads();
+
+  // ---- S = K_CC - K_CE K_EE^-1 K_EC, structurally non-zero entries ----------
+  for (int id = tid; id < d.nS; id += SCO_BLOCK) {
+    const int sa = d.s_a[id], sb = d.s_b[id];
+    double v = (sa == sb) ? a.sigma : 0.0;
+    if (d.s_ppos[id] >= 0) v += Ps[d.s_ppos[id]];
+    for (int t = d.sa_ptr[id]; t < d.sa_ptr[id + 1]; t++) v += Et[d.sa_row[t]] * As[d.sa_pa[t]] * As[d.sa_pb[t]];
+    for (int t = d.ss_ptr[id]; t < d.ss_ptr[id + 1]; t++) v -= cpl[d.ss_k1[t]] * cpl[d.ss_k2[t]] * kinv[d.ss_e[t]];
+    Lp[tri_idx(sa, sb)] = v;
+  }
+  __syncthreads();
+
+  // ---- dense Cholesky S = L L' (left-looking; every thread recomputes the
+  //      pivot of the current column so one barrier per column suffices) -------
+  for (int j = 0; j < n_c; j++) {
+    double piv = Lp[tri_idx(j, j)];
+    const double *rj = Lp + tri_idx(j, 0);
+    for (int k = 0; k < j; k++) piv -= rj[k] * rj[k];
+    piv = sqrt(piv);
+    for (int i = j + tid; i < n_c; i += SCO_BLOCK) {
+      if (i == j) continue;
+      const double *ri = Lp + tri_idx(i, 0);
+      double s = ri[j];
+      for (int k = 0; k < j; k++) s -= ri[k] * rj[k];
+      Lp[tri_idx(i, j)] = s / piv;
+    }
+    __syncthreads();          // all reads of the old (j, j) entry are done
+    if (tid == 0) Lp[tri_idx(j, j)] = piv;
+    __syncthreads();
+  }
+
+  // ---- M = L^-1 in place, last column first ---------------------------------
+  for (int j = n_c - 1; j >= 0; j--) {
+    const double ljj = Lp[tri_idx(j, j)];
+    double acc[4];   // up to 4 rows per thread (n_c <= 4 * SCO_BLOCK enforced on the host)
+    int cnt = 0;
+    for (int i = j + 1 + tid; i < n_c; i += SCO_BLOCK, cnt++) {
+      const double *ri = Lp + tri_idx(i, 0);
+      double s = 0.0;
+      for (int k = j + 1; k <= i; k++) s += ri[k] * Lp[tri_idx(k, j)];
+      acc[cnt] = s;
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int i = j + 1 + tid; i < n_c; i += SCO_BLOCK, cnt++) Lp[tri_idx(i, j)] = -acc[cnt] / ljj;
+    if (tid == 0) Lp[tri_idx(j, j)] = 1.0 / ljj;
+    __syncthreads();
+  }
+
+  // ---- W = M' M (dense, symmetric) -> global ---------------------------------
+  double *W = d.W + (size_t)b * n_c * n_c;
+  for (size_t p = tid; p < ntri; p += SCO_BLOCK) {
+    int ia = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (tri_idx(ia + 1, 0) <= p) ia++;
+    while (tri_idx(ia, 0) > p) ia--;
+    const int ib = (int)(p - tri_idx(ia, 0));
+    double s = 0.0;
+    for (int k = ia; k < n_c; k++) s += Lp[tri_idx(k, ia)] * Lp[tri_idx(k, ib)];
+    W[(size_t)ia * n_c + ib] = s;
+    W[(size_t)ib * n_c + ia] = s;
+  }
+}
+
+// --------------------------------------------------------------------------
+// ADMM kernel
+// --------------------------------------------------------------------------
+struct AdmmArgs {
+  QpDev d;
+  double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  int max_iter, check;
+};
+
+struct AdmmLds {
+  double *As, *qs, *ls, *us, *rho, *x, *z, *y, *t, *xt, *ge, *r, *xc, *kinv, *cpl, *sdy, *sdx, *red;
+  int *w;
+};
+
+__host__ __device__ inline size_t admm_lds_doubles(int n, int m, int nnzA, int n_e, int n_c, int ncpl) {
+  return (size_t)nnzA + n + 2 * (size_t)m + m + n + 2 * (size_t)m + m + n + n_e + 2 * (size_t)n_c + n_e + ncpl + m + n + NWAVE * 8;
+}
+
+// Termination test of one ADMM iterate (all threads of the workgroup take part
+// and return the same value): 0 = keep iterating, otherwise an SCO_QP_* status.
+__device__ int admm_check(const AdmmArgs &a, const AdmmLds &s, int b, int approximate,
+                          double cscale, double *pri_out, double *dua_out) {
+  const QpDev &d = a.d;
+  const int tid = threadIdx.x, n = d.n, m = d.m;
+  const double *Ps = d.Ps + (size_t)b * d.nnzP;
+  const double *Dg = d.D + (size_t)b * n, *Eg = d.E + (size_t)b * m;
+  const double cinv = 1.0 / cscale;
+  double ea = a.eps_abs, er = a.eps_rel, epi = a.eps_prim_inf, edi = a.eps_dual_inf;
+  if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+
+  // rows: primal residual and its scale
+  double v[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < m; i += SCO_BLOCK) {
+    double ax = 0.0;
+    for (int t = d.Rp[i]; t < d.Rp[i + 1]; t++) ax += s.As[d.Rpos[t]] * s.x[d.Rj[t]];
+    const double ei = 1.0 / Eg[i];
+    v[0] = fmax(v[0], fabs(ei * (ax - s.z[i])));
+    v[1] = fmax(v[1], fabs(ei * s.z[i]));
+    v[2] = fmax(v[2], fabs(ei * ax));
+  }
+  // columns: dual residual and its scale
+  for (int j = tid; j < n; j += SCO_BLOCK) {
+    double px = 0.0, aty = 0.0;
+    for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * s.x[d.Fi[t]];
+    for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) { const int i = d.Ai[t]; aty += s.As[t] * s.y[i] * (double)s.w[i]; }
+    const double dj = 1.0 / Dg[j];
+    v[3] = fmax(v[3], fabs(dj * (s.qs[j] + px + aty)));
+    v[4] = fmax(v[4], fabs(dj * s.qs[j]));
+    v[5] = fmax(v[5], fabs(dj * aty));
+    v[6] = fmax(v[6], fabs(dj * px));
+  }
+  block_reduce<7, true>(v, s.red);
+  const double pri = v[0], dua = cinv * v[3];
+  *pri_out = pri; *dua_out = dua;
+  if (!(pri <= SCO_INFTY) || !(dua <= SCO_INFTY)) return SCO_QP_NON_CVX;
+  const double eps_p = ea + er * fmax(v[1], v[2]);
+  const double eps_d = ea + er * cinv * fmax(v[4], fmax(v[5], v[6]));
+  const bool prim_ok = (m == 0) || (pri < eps_p);
+  const bool dual_ok = dua < eps_d;
+  if (prim_ok && dual_ok) return approximate ? SCO_QP_SOLVED_INACCURATE : SCO_QP_SOLVED;
+
+  // ---- primal infeasibility certificate from delta_y --------------------------
+  if (!prim_ok) {
+    double r2[1] = {0.0};
+    for (int i = tid; i < m; i += SCO_BLOCK) {
+      double dy = s.sdy[i];
+      const double li = s.ls[i], ui = s.us[i];
+      if (ui > SCO_INFTY * SCO_MIN_SCALING) {
+        if (li < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
+      } else if (li < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
+      s.sdy[i] = dy;
+      r2[0] = fmax(r2[0], fabs(Eg[i] * dy));
+    }
+    block_reduce<1, true>(r2, s.red);
+    const double ndy = r2[0];
+    if (ndy > epi) {
+      double lhs[1] = {0.0};
+      for (int i = tid; i < m; i += SCO_BLOCK) {
+        const double dy = s.sdy[i];
+        lhs[0] += (double)s.w[i] * (s.us[i] * fmax(dy, 0.0) + s.ls[i] * fmin(dy, 0.0));
+      }
+      block_reduce<1, false>(lhs, s.red);
+      if (lhs[0] < -epi * ndy) {
+        double nat[1] = {0.0};
+        for (int j = tid; j < n; j += SCO_BLOCK) {
+          double aty = 0.0;
+          for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) { const int i = d.Ai[t]; aty += s.As[t] * s.sdy[i] * (double)s.w[i]; }
+          nat[0] = fmax(nat[0], fabs(aty / Dg[j]));
+        }
+        block_reduce<1, true>(nat, s.red);
+        if (nat[0] < epi * ndy) return approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE;
+      }
+    }
+  }
+  // ---- dual infeasibility certificate from delta_x ------------------------------
+  if (!dual_ok) {
+    double r1[1] = {0.0};
+    for (int j = tid; j < n; j += SCO_BLOCK) r1[0] = fmax(r1[0], fabs(Dg[j] * s.sdx[j]));
+    block_reduce<1, true>(r1, s.red);
+    const double ndx = r1[0];
+    if (ndx > edi) {
+      double qdx[1] = {0.0};
+      for (int j = tid; j < n; j += SCO_BLOCK) qdx[0] += s.qs[j] * s.sdx[j];
+      block_reduce<1, false>(qdx, s.red);
+      if (qdx[0] < -cscale * edi * ndx) {
+        double npx[1] = {0.0};
+        for (int j = tid; j < n; j += SCO_BLOCK) {
+          double px = 0.0;
+          for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * s.sdx[d.Fi[t]];
+          npx[0] = fmax(npx[0], fabs(px / Dg[j]));
+        }
+        block_reduce<1, true>(npx, s.red);
+        if (npx[0] < cscale * edi * ndx) {
+          double bad[1] = {0.0};
+          for (int i = tid; i < m; i += SCO_BLOCK) {
+            double adx = 0.0;
+            for (int t = d.Rp[i]; t < d.Rp[i + 1]; t++) adx += s.As[d.Rpos[t]] * s.sdx[d.Rj[t]];
+            adx /= Eg[i];
+            if ((s.us[i] < SCO_INFTY * SCO_MIN_SCALING && adx > edi * ndx) ||
+                (s.ls[i] > -SCO_INFTY * SCO_MIN_SCALING && adx < -edi * ndx)) bad[0] = 1.0;
+          }
+          block_reduce<1, true>(bad, s.red);
+          if (bad[0] == 0.0) return approximate ? SCO_QP_DUAL_INFEASIBLE_INACCURATE : SCO_QP_DUAL_INFEASIBLE;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
+  const QpDev &d = a.d;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (d.active && !d.active[b]) return;
+  const int n = d.n, m = d.m, nnzA = d.nnzA, n_e = d.n_e, n_c = d.n_c, ncpl = d.ncpl;
+
+  extern __shared__ double lds[];
+  AdmmLds s;
+  s.As = lds;            s.qs = s.As + nnzA;   s.ls = s.qs + n;     s.us = s.ls + m;
+  s.rho = s.us + m;      s.x = s.rho + m;      s.z = s.x + n;       s.y = s.z + m;
+  s.t = s.y + m;         s.xt = s.t + m;       s.ge = s.xt + n;     s.r = s.ge + n_e;
+  s.xc = s.r + n_c;      s.kinv = s.xc + n_c;  s.cpl = s.kinv + n_e; s.sdy = s.cpl + ncpl;
+  s.sdx = s.sdy + m;     s.red = s.sdx + n;
+  s.w = (int *)(s.red + NWAVE * 8);
+
+  {
+    const double *gAs = d.As + (size_t)b * nnzA;
+    for (int t = tid; t < nnzA; t += SCO_BLOCK) s.As[t] = gAs[t];
+    for (int j = tid; j < n; j += SCO_BLOCK) { s.qs[j] = d.qs[(size_t)b * n + j]; s.x[j] = 0.0; s.sdx[j] = 0.0; }
+    for (int i = tid; i < m; i += SCO_BLOCK) {
+      s.ls[i] = d.ls[(size_t)b * m + i]; s.us[i] = d.us[(size_t)b * m + i];
+      s.rho[i] = d.rho[(size_t)b * m + i]; s.w[i] = d.w[(size_t)b * m + i];
+      s.z[i] = 0.0; s.y[i] = 0.0; s.t[i] = 0.0; s.sdy[i] = 0.0;
+    }
+    for (int e = tid; e < n_e; e += SCO_BLOCK) s.kinv[e] = d.kee_inv[(size_t)b * n_e + e];
+    for (int k = tid; k < ncpl; k += SCO_BLOCK) s.cpl[k] = d.cpl[(size_t)b * ncpl + k];
+  }
+  const double *W = d.W + (size_t)b * n_c * n_c;
+  const double cscale = d.cscale[b];
+  const double alpha = a.alpha, sigma = a.sigma;
+  __syncthreads();
+
+  int status = 0, iter = 0;
+  double pri = 0.0, dua = 0.0;
+  for (iter = 1; iter <= a.max_iter; iter++) {
+    const bool chk = (a.check > 0 && iter % a.check == 0) || iter == a.max_iter;
+    // (1) right-hand side  sigma x - q + A' t,  t = w (rho z - y); eliminated part scaled by K_ee^-1
+    for (int j = tid; j < n; j += SCO_BLOCK) {
+      double v = 0.0;
+      for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) v += s.As[t] * s.t[d.Ai[t]];
+      v += sigma * s.x[j] - s.qs[j];
+      s.xt[j] = v;
+      const int e = d.elim_of[j];
+      if (e >= 0) s.ge[e] = v * s.kinv[e];
+    }
+    __syncthreads();
+    // (2) core right-hand side  r = rhs_C - K_CE K_EE^-1 rhs_E
+    for (int c = tid; c < n_c; c += SCO_BLOCK) {
+      double v = s.xt[d.core_var[c]];
+      for (int t = d.a_ptr[c]; t < d.a_ptr[c + 1]; t++) { const int k = d.a_pair[t]; v -= s.cpl[k] * s.ge[d.pair_elim[k]]; }
+      s.r[c] = v;
+    }
+    __syncthreads();
+    // (3) x~_C = W r   (W symmetric: thread c walks column c = row c, coalesced across lanes)
+    for (int c = tid; c < n_c; c += SCO_BLOCK) {
+      double v = 0.0;
+      for (int k = 0; k < n_c; k++) v += W[(size_t)k * n_c + c] * s.r[k];
+      s.xc[c] = v;
+    }
+    __syncthreads();
+    // (4) back-substitute the eliminated variables, scatter x~ into xt
+    for (int j = tid; j < n; j += SCO_BLOCK) {
+      const int e = d.elim_of[j];
+      if (e >= 0) {
+        double v = 0.0;
+        for (int k = d.e_ptr[e]; k < d.e_ptr[e + 1]; k++) v += s.cpl[k] * s.xc[d.pair_core[k]];
+        s.xt[j] = s.ge[e] - s.kinv[e] * v;
+      } else {
+        s.xt[j] = s.xc[d.core_of[j]];
+      }
+    }
+    __syncthreads();
+    // (5) z~ = A x~, then the z / y / x updates and next iteration's t
+    for (int i = tid; i < m; i += SCO_BLOCK) {
+      double zt = 0.0;
+      for (int t = d.Rp[i]; t < d.Rp[i + 1]; t++) zt += s.As[d.Rpos[t]] * s.xt[d.Rj[t]];
+      const double rho = s.rho[i], rinv = 1.0 / rho;
+      const double zr = alpha * zt + (1.0 - alpha) * s.z[i];
+      double zn = zr + rinv * s.y[i];
+      zn = fmin(fmax(zn, s.ls[i]), s.us[i]);
+      const double dy = rho * (zr - zn);
+      const double yn = s.y[i] + dy;
+      s.z[i] = zn; s.y[i] = yn;
+      s.t[i] = (double)s.w[i] * (rho * zn - yn);
+      if (chk) s.sdy[i] = dy;
+    }
+    for (int j = tid; j < n; j += SCO_BLOCK) {
+      const double xo = s.x[j];
+      const double xn = alpha * s.xt[j] + (1.0 - alpha) * xo;
+      if (chk) s.sdx[j] = xn - xo;
+      s.x[j] = xn;
+    }
+    __syncthreads();
+    if (chk) {
+      status = admm_check(a, s, b, 0, cscale, &pri, &dua);
+      if (status) break;
+    }
+  }
+  if (!status) {
+    iter = a.max_iter;
+    status = admm_check(a, s, b, 1, cscale, &pri, &dua);
+    if (!status) status = SCO_QP_MAX_ITER_REACHED;
+  }
+  // ---- unscale and store -----------------------------------------------------
+  {
+    const double *Dg = d.D + (size_t)b * n, *Eg = d.E + (size_t)b * m;
+    const double cinv = 1.0 / cscale;
+    for (int j = tid; j < n; j += SCO_BLOCK) d.x[(size_t)b * n + j] = Dg[j] * s.x[j];
+    for (int i = tid; i < m; i += SCO_BLOCK) d.y[(size_t)b * m + i] = cinv * Eg[i] * s.y[i] * (double)s.w[i];
+    if (tid == 0) {
+      d.status[b] = status; d.iters[b] = iter;
+      d.resid[2 * (size_t)b] = pri; d.resid[2 * (size_t)b + 1] = dua;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+template <typename T>
+static int dev_upload(sco_qp *qp, const std::vector<T> &v, const T **out) {
+  void *p = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  SCO_HIP(hipMalloc(&p, bytes));
+  qp->allocs.push_back(p);
+  if (!v.empty()) SCO_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T *)p;
+  return SCO_OK;
+}
+template <typename T>
+static int dev_alloc(sco_qp *qp, size_t count, T **out) {
+  void *p = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  SCO_HIP(hipMalloc(&p, bytes));
+  SCO_HIP(hipMemset(p, 0, bytes));
+  qp->allocs.push_back(p);
+  *out = (T *)p;
+  return SCO_OK;
+}
+
+static size_t setup_lds_doubles(const QpPlan &pl) {
+  return (size_t)pl.nnzP + pl.nnzA + 2 * (size_t)pl.n + pl.m + pl.n + pl.m + pl.ncpl + NWAVE * 2 +
+         (size_t)pl.n_c * (pl.n_c + 1) / 2;
+}
+
+int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, const int *Pi,
+                            const int *Ap, const int *Ai, hipStream_t stream, sco_qp **out) {
+  if (!out || batch <= 0 || n <= 0 || m < 0 || !Pp || !Ap) { sco_set_error("sco_qp_create: bad argument"); return SCO_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    sco_set_error("sco_qp_create: no HIP device visible (this library has no CPU fallback)");
+    return SCO_ERR_NO_GPU;
+  }
+  if (device < 0 || device >= ndev) { sco_set_error("sco_qp_create: bad device index"); return SCO_ERR_ARG; }
+  SCO_HIP(hipSetDevice(device));
+  sco_qp *qp = new sco_qp();
+  qp->device = device;
+  const char *no_elim = getenv("SCO_QP_NO_ELIM");
+  int rc = qp_plan_build(n, m, Pp, Pi, Ap, Ai, (no_elim && no_elim[0] == '1') ? 0 : 1, qp->plan);
+  if (rc != 0) { delete qp; sco_set_error("sco_qp_create: malformed sparsity pattern"); return SCO_ERR_ARG; }
+  const QpPlan &pl = qp->plan;
+  qp->lds_setup = setup_lds_doubles(pl) * sizeof(double);
+  qp->lds_admm = admm_lds_doubles(n, m, pl.nnzA, pl.n_e, pl.n_c, pl.ncpl) * sizeof(double) + (size_t)m * sizeof(int);
+  const size_t lds_cap = 160 * 1024;
+  if (qp->lds_setup > lds_cap || qp->lds_admm > lds_cap || pl.n_c > 4 * SCO_BLOCK) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "sco_qp_create: working set exceeds 160 KiB LDS (setup %zu B, admm %zu B, core %d)",
+             qp->lds_setup, qp->lds_admm, pl.n_c);
+    delete qp; sco_set_error(buf); return SCO_ERR_CAPACITY;
+  }
+  if (stream) { qp->stream = stream; qp->own_stream = false; }
+  else { SCO_HIP(hipStreamCreate(&qp->stream)); qp->own_stream = true; }
+  for (auto &e : qp->ev) SCO_HIP(hipEventCreate(&e));
+
+  QpDev &d = qp->d;
+  d.n = n; d.m = m; d.nnzP = pl.nnzP; d.nnzA = pl.nnzA; d.n_e = pl.n_e; d.n_c = pl.n_c;
+  d.ncpl = pl.ncpl; d.nS = pl.nS; d.batch = batch; d.active = nullptr;
+#define UP(field, vec) { int r_ = dev_upload<int>(qp, pl.vec, &d.field); if (r_) return r_; }
+  UP(Ap, Ap) UP(Ai, Ai) UP(Rp, Rp) UP(Rj, Rj) UP(Rpos, Rpos) UP(Fp, Fp) UP(Fi, Fi) UP(Fpos, Fpos) UP(Pdiag, Pdiag)
+  UP(elim_var, elim_var) UP(core_var, core_var) UP(elim_of, elim_of) UP(core_of, core_of)
+  UP(e_ptr, e_ptr) UP(pair_core, pair_core) UP(pair_elim, pair_elim) UP(cp_ptr, cp_ptr) UP(cp_row, cp_row)
+  UP(cp_pa, cp_pa) UP(cp_pe, cp_pe) UP(a_ptr, a_ptr) UP(a_pair, a_pair)
+  UP(s_a, s_a) UP(s_b, s_b) UP(s_ppos, s_ppos) UP(sa_ptr, sa_ptr) UP(sa_row, sa_row) UP(sa_pa, sa_pa) UP(sa_pb, sa_pb)
+  UP(ss_ptr, ss_ptr) UP(ss_k1, ss_k1) UP(ss_k2, ss_k2) UP(ss_e, ss_e)
+#undef UP
+  { int r_ = dev_upload<int>(qp, pl.Pp, &qp->Pp_dev); if (r_) return r_; }
+  { int r_ = dev_upload<int>(qp, pl.Pi, &qp->Pi_dev); if (r_) return r_; }
+  const size_t B = (size_t)batch;
+#define AL(field, count) { int r_ = dev_alloc(qp, (count), &d.field); if (r_) return r_; }
+  AL(Pval, B * pl.nnzP) AL(q, B * n) AL(Aval, B * pl.nnzA) AL(l, B * m) AL(u, B * m) AL(w, B * m)
+  AL(Ps, B * pl.nnzP) AL(As, B * pl.nnzA) AL(qs, B * n) AL(ls, B * m) AL(us, B * m) AL(D, B * n) AL(E, B * m)
+  AL(cscale, B) AL(rho, B * m) AL(kee_inv, B * pl.n_e) AL(cpl, B * pl.ncpl) AL(W, B * pl.n_c * pl.n_c)
+  AL(x, B * n) AL(y, B * m) AL(resid, B * 2) AL(status, B) AL(iters, B)
+#undef AL
+  SCO_HIP(hipFuncSetAttribute((const void *)qp_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+  SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+  *out = qp;
+  return SCO_OK;
+}
+
+extern "C" int sco_qp_create(int device, int batch, int n, int m, const int *Pp, const int *Pi,
+                             const int *Ap, const int *Ai, sco_qp **out) {
+  return sco_qp_create_on_stream(device, batch, n, m, Pp, Pi, Ap, Ai, nullptr, out);
+}
+
+extern "C" int sco_qp_destroy(sco_qp *qp) {
+  if (!qp) return SCO_OK;
+  (void)hipSetDevice(qp->device);
+  if (qp->stream) (void)hipStreamSynchronize(qp->stream);
+  for (void *p : qp->allocs) (void)hipFree(p);
+  for (auto &e : qp->ev) if (e) (void)hipEventDestroy(e);
+  if (qp->own_stream && qp->stream) (void)hipStreamDestroy(qp->stream);
+  delete qp;
+  return SCO_OK;
+}
+
+extern "C" int sco_qp_load(sco_qp *qp, const double *P_val, const double *q, const double *A_val,
+                           const double *l, const double *u, const int *row_weight) {
+  if (!qp || !q || (qp->d.nnzP && !P_val) || (qp->d.nnzA && !A_val) || (qp->d.m && (!l || !u))) {
+    sco_set_error("sco_qp_load: null pointer"); return SCO_ERR_ARG;
+  }
+  SCO_HIP(hipSetDevice(qp->device));
+  const QpDev &d = qp->d; const size_t B = d.batch;
+  if (d.nnzP) SCO_HIP(hipMemcpyAsync(d.Pval, P_val, B * d.nnzP * sizeof(double), hipMemcpyHostToDevice, qp->stream));
+  SCO_HIP(hipMemcpyAsync(d.q, q, B * d.n * sizeof(double), hipMemcpyHostToDevice, qp->stream));
+  if (d.nnzA) SCO_HIP(hipMemcpyAsync(d.Aval, A_val, B * d.nnzA * sizeof(double), hipMemcpyHostToDevice, qp->stream));
+  if (d.m) {
+    SCO_HIP(hipMemcpyAsync(d.l, l, B * d.m * sizeof(double), hipMemcpyHostToDevice, qp->stream));
+    SCO_HIP(hipMemcpyAsync(d.u, u, B * d.m * sizeof(double), hipMemcpyHostToDevice, qp->stream));
+    if (row_weight) SCO_HIP(hipMemcpyAsync(d.w, row_weight, B * d.m * sizeof(int), hipMemcpyHostToDevice, qp->stream));
+    else {
+      std::vector<int> ones(B * d.m, 1);
+      SCO_HIP(hipMemcpyAsync(d.w, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice, qp->stream));
+      SCO_HIP(hipStreamSynchronize(qp->stream));
+    }
+  }
+  SCO_HIP(hipStreamSynchronize(qp->stream));
+  qp->loaded = true;
+  return SCO_OK;
+}
+
+extern "C" int sco_qp_set_bounds(sco_qp *qp, const double *l, const double *u) {
+  if (!qp || !l || !u) { sco_set_error("sco_qp_set_bounds: null pointer"); return SCO_ERR_ARG; }
+  if (!qp->loaded) { sco_set_error("sco_qp_set_bounds: call sco_qp_load first"); return SCO_ERR_STATE; }
+  SCO_HIP(hipSetDevice(qp->device));
+  const QpDev &d = qp->d; const size_t B = d.batch;
+  SCO_HIP(hipMemcpyAsync(d.l, l, B * d.m * sizeof(double), hipMemcpyHostToDevice, qp->stream));
+  SCO_HIP(hipMemcpyAsync(d.u, u, B * d.m * sizeof(double), hipMemcpyHostToDevice, qp->stream));
+  SCO_HIP(hipStreamSynchronize(qp->stream));
+  return SCO_OK;
+}
+
+int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev) {
+  QpDev d = qp->d; d.active = active_dev;
+  SetupArgs sa{d, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling};
+  AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
+              st->max_iter, st->check_termination};
+  SCO_HIP(hipEventRecord(qp->ev[0], qp->stream));
+  hipLaunchKernelGGL(qp_setup_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_setup, qp->stream, sa);
+  SCO_HIP(hipGetLastError());
+  SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
+  hipLaunchKernelGGL(qp_admm_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_admm, qp->stream, aa);
+  SCO_HIP(hipGetLastError());
+  SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
+  return SCO_OK;
+}
+
+extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double *x, double *y,
+                            int *status, int *iters, double *resid) {
+  if (!qp || !settings) { sco_set_error("sco_qp_solve: null pointer"); return SCO_ERR_ARG; }
+  if (!qp->loaded) { sco_set_error("sco_qp_solve: call sco_qp_load first"); return SCO_ERR_STATE; }
+  if (settings->max_iter <= 0 || !(settings->rho > 0) || !(settings->sigma > 0) || settings->scaling < 0) {
+    sco_set_error("sco_qp_solve: bad settings"); return SCO_ERR_ARG;
+  }
+  SCO_HIP(hipSetDevice(qp->device));
+  int rc = sco_qp_launch(qp, settings, nullptr);
+  if (rc) return rc;
+  const QpDev &d = qp->d; const size_t B = d.batch;
+  if (x) SCO_HIP(hipMemcpyAsync(x, d.x, B * d.n * sizeof(double), hipMemcpyDeviceToHost, qp->stream));
+  if (y && d.m) SCO_HIP(hipMemcpyAsync(y, d.y, B * d.m * sizeof(double), hipMemcpyDeviceToHost, qp->stream));
+  if (status) SCO_HIP(hipMemcpyAsync(status, d.status, B * sizeof(int), hipMemcpyDeviceToHost, qp->stream));
+  if (iters) SCO_HIP(hipMemcpyAsync(iters, d.iters, B * sizeof(int), hipMemcpyDeviceToHost, qp->stream));
+  if (resid) SCO_HIP(hipMemcpyAsync(resid, d.resid, B * 2 * sizeof(double), hipMemcpyDeviceToHost, qp->stream));
+  SCO_HIP(hipStreamSynchronize(qp->stream));
+  float ms0 = 0, ms1 = 0;
+  SCO_HIP(hipEventElapsedTime(&ms0, qp->ev[0], qp->ev[1]));
+  SCO_HIP(hipEventElapsedTime(&ms1, qp->ev[1], qp->ev[2]));
+  qp->last_ms[0] = ms0; qp->last_ms[1] = ms1;
+  return SCO_OK;
+}
+
+extern "C" int sco_qp_info(const sco_qp *qp, int info[4]) {
+  if (!qp || !info) return SCO_ERR_ARG;
+  info[0] = qp->plan.n_e; info[1] = qp->plan.n_c; info[2] = (int)qp->lds_admm; info[3] = qp->plan.ncpl;
+  return SCO_OK;
+}
+
+extern "C" int sco_qp_last_timing(const sco_qp *qp, double ms[2]) {
+  if (!qp || !ms) return SCO_ERR_ARG;
+  ms[0] = qp->last_ms[0]; ms[1] = qp->last_ms[1];
+  return SCO_OK;
+}
+
+// --------------------------------------------------------------------------
+// Host-only debug view of the symbolic analysis (no HIP call): lets the CPU
+// test-suite check the plans against a NumPy emulation of the kernels.
+// sizes[16]: n_e, n_c, ncpl, nS, len(cp_row), len(sa_row), len(ss_k1), nnzFull
+// --------------------------------------------------------------------------
+static QpPlan g_dbg_plan;
+extern "C" int sco_debug_plan_build(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai,
+                                    int allow_elim, int *sizes) {
+  int rc = qp_plan_build(n, m, Pp, Pi, Ap, Ai, allow_elim, g_dbg_plan);
+  if (rc) return SCO_ERR_ARG;
+  const QpPlan &p = g_dbg_plan;
+  sizes[0] = p.n_e; sizes[1] = p.n_c; sizes[2] = p.ncpl; sizes[3] = p.nS;
+  sizes[4] = (int)p.cp_row.size(); sizes[5] = (int)p.sa_row.size(); sizes[6] = (int)p.ss_k1.size();
+  sizes[7] = (int)p.Fi.size();
+  return SCO_OK;
+}
+extern "C" int sco_debug_plan_get(const char *name, int *out, int cap) {
+  const QpPlan &p = g_dbg_plan;
+  const std::vector<int> *v = nullptr;
+#define F(x) if (!strcmp(name, #x)) v = &p.x;
+  F(Rp) F(Rj) F(Rpos) F(Fp) F(Fi) F(Fpos) F(Pdiag) F(elim_var) F(core_var) F(elim_of) F(core_of)
+  F(e_ptr) F(pair_core) F(pair_elim) F(cp_ptr) F(cp_row) F(cp_pa) F(cp_pe) F(a_ptr) F(a_pair)
+  F(s_a) F(s_b) F(s_ppos) F(sa_ptr) F(sa_row) F(sa_pa) F(sa_pb) F(ss_ptr) F(ss_k1) F(ss_k2) F(ss_e)
+#undef F
+  if (!v) return SCO_ERR_ARG;
+  if ((int)v->size() > cap) return SCO_ERR_CAPACITY;
+  std::copy(v->begin(), v->end(), out);
+  return (int)v->size();
+}

@@ -1,0 +1,226 @@
+"""QP atoms and the assemble-and-solve seam of the SCO front-end.
+
+Mirror of ``sco_py.sco_osqp.osqp_utils``
+(/root/reference/sco_py/sco_osqp/osqp_utils.py).  The model classes keep the
+reference's names and fields; :func:`optimize` keeps its signature and return
+shape ``(solve_res, var_to_index_dict)`` but, instead of building dense matrices
+and calling the third-party OSQP library (osqp_utils.py:146-216), assembles the
+sparse triplets directly and hands them to the MI355X solver through the C ABI
+(``sco_qp_*`` in include/sco_hip.h).  There is no CPU path.
+"""
+from types import SimpleNamespace
+from typing import List
+
+import numpy as np
+import scipy.sparse as sp
+
+from .. import _lib
+from .variable import Variable  # noqa: F401  (type name used by callers, as in the reference)
+
+DEFAULT_MAX_ITER = int(1e05)     # osqp_utils.py:10
+DEFAULT_SIGMA = 5e-10            # osqp_utils.py:11
+DEFAULT_RHO = 1e-01              # osqp_utils.py:12
+DEFAULT_ADAPTIVE_RHO = False     # osqp_utils.py:13
+DEFAULT_EPS_ABS = 1e-06          # osqp_utils.py:14
+DEFAULT_EPS_REL = 1e-09          # osqp_utils.py:15
+
+
+class OSQPVar(object):
+    """One scalar QP variable: name, bounds (the trust region is written here),
+    last solver value (osqp_utils.py:17-51)."""
+
+    def __init__(self, var_name, lb=-np.inf, ub=np.inf, val=None):
+        self.var_name = var_name
+        self._lower_bound = lb
+        self._upper_bound = ub
+        self.val = val
+
+    def __lt__(self, other_osqp_var):
+        # ordering by name only: columns of the QP are the name-sorted variables
+        return self.var_name < other_osqp_var.var_name
+
+    def __repr__(self):
+        return f"OSQPVar with name {self.var_name}"
+
+    def get_lower_bound(self):
+        return self._lower_bound
+
+    def set_lower_bound(self, lb_val):
+        assert isinstance(lb_val, float)      # np.float64 passes, int does not (osqp_utils.py:41)
+        assert not np.isnan(lb_val)
+        self._lower_bound = lb_val
+
+    def get_upper_bound(self):
+        return self._upper_bound
+
+    def set_upper_bound(self, ub_val):
+        assert isinstance(ub_val, float)
+        assert not np.isnan(ub_val)
+        self._upper_bound = ub_val
+
+
+class OSQPLinearObj(object):
+    """coeff * osqp_var (osqp_utils.py:54-68)."""
+
+    def __init__(self, osqp_var, coeff):
+        self.osqp_var = osqp_var
+        self.coeff = coeff
+
+    def __repr__(self):
+        return f"OSQPLinearObj with osqp_var={self.osqp_var}, coeff={self.coeff}"
+
+    def get_all_vars(self):
+        return [self.osqp_var]
+
+
+class OSQPQuadraticObj(object):
+    """0.5 * sum_i coeffs[i] * osqp_vars1[i] * osqp_vars2[i] (osqp_utils.py:71-90)."""
+
+    def __init__(self, osqp_vars1, osqp_vars2, coeffs):
+        assert osqp_vars1.shape == osqp_vars2.shape == coeffs.shape
+        assert len(osqp_vars1.shape) == 1
+        self.osqp_vars1 = osqp_vars1
+        self.osqp_vars2 = osqp_vars2
+        self.coeffs = coeffs
+
+    def __repr__(self):
+        return (f"Quadratic Objective with osqp_vars1={self.osqp_vars1}, "
+                f"osqp_vars2={self.osqp_vars2}, coeffs={self.coeffs}")
+
+    def get_all_vars(self):
+        return self.osqp_vars1.tolist() + self.osqp_vars2.tolist()
+
+
+class OSQPLinearConstraint(object):
+    """lb <= sum_i coeffs[i] * osqp_vars[i] <= ub (osqp_utils.py:93-110)."""
+
+    def __init__(self, osqp_vars, coeffs, lb, ub):
+        assert osqp_vars.shape == coeffs.shape
+        self.osqp_vars = osqp_vars
+        self.coeffs = coeffs
+        self.lb = lb
+        self.ub = ub
+
+    def __repr__(self):
+        return (f"OSQPLinearConstraint with osqp_vars={self.osqp_vars}, coeffs={self.coeffs}, "
+                f"lb = {self.lb}, ub = {self.ub}")
+
+    def get_all_vars(self):
+        return self.osqp_vars.tolist()
+
+
+# --------------------------------------------------------------------------
+# assembly (S5) -- the reference's Python loops over dense matrices
+# (osqp_utils.py:146-193) restated as triplet accumulation
+# --------------------------------------------------------------------------
+def assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs):
+    """Returns (P_triu csc, q, A csc, l, u, var_to_index_dict).
+
+    Column order: variables sorted by name, ties in container order
+    (osqp_utils.py:136-142).  Row order: the constraints in list order, then one
+    bound row per variable in container order (osqp_utils.py:173-189)."""
+    ordered = list(osqp_vars)
+    ordered.sort()
+    index = {v: k for k, v in enumerate(ordered)}
+    n = len(osqp_vars)
+
+    q = np.zeros(n)
+    for term in osqp_lin_objs:
+        q[index[term.osqp_var]] += term.coeff           # += (osqp_utils.py:148)
+
+    # P: off-diagonal pairs put half the coefficient at [min, max], the diagonal
+    # gets the full coefficient; repeated entries add up (osqp_utils.py:153-163)
+    pr, pc, pv = [], [], []
+    for quad in osqp_quad_objs:
+        for k in range(quad.coeffs.shape[0]):
+            a = index[quad.osqp_vars1[k]]
+            b = index[quad.osqp_vars2[k]]
+            pr.append(min(a, b)); pc.append(max(a, b))
+            pv.append(quad.coeffs[k] if a == b else 0.5 * quad.coeffs[k])
+    P = sp.coo_matrix((np.asarray(pv, dtype=np.float64), (pr, pc)), shape=(n, n)).tocsc()
+    P.sum_duplicates()
+    P.sort_indices()
+
+    # A: assignment semantics -- a variable listed twice in one row keeps the LAST
+    # coefficient (osqp_utils.py:179-181)
+    m = n + len(osqp_lin_cnt_exprs)
+    l = np.zeros(m)
+    u = np.zeros(m)
+    cells = {}
+    for row, cnt in enumerate(osqp_lin_cnt_exprs):
+        l[row] = cnt.lb
+        u[row] = cnt.ub
+        for k in range(cnt.coeffs.shape[0]):
+            cells[(row, index[cnt.osqp_vars[k]])] = cnt.coeffs[k]
+    row = len(osqp_lin_cnt_exprs)
+    for v in osqp_vars:
+        cells[(row, index[v])] = 1.0
+        l[row] = v.get_lower_bound()
+        u[row] = v.get_upper_bound()
+        row += 1
+    if cells:
+        rc = np.array(list(cells.keys()), dtype=np.int64)
+        vals = np.array(list(cells.values()), dtype=np.float64)
+        keep = vals != 0.0                     # csc_matrix(dense) drops exact zeros (osqp_utils.py:193)
+        A = sp.coo_matrix((vals[keep], (rc[keep, 0], rc[keep, 1])), shape=(m, n)).tocsc()
+    else:
+        A = sp.csc_matrix((m, n))
+    A.sort_indices()
+    P.eliminate_zeros()
+    return P, q, A, l, u, index
+
+
+def _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma):
+    """One QP on the GPU through the C ABI (batch of 1).  Returns (x, status, iters)."""
+    n, m = A.shape[1], A.shape[0]
+    qp = _lib.BatchedQP(1, n, m, P.indptr, P.indices, A.indptr, A.indices)
+    try:
+        qp.load(P.data[None, :], q[None, :], A.data[None, :], l[None, :], u[None, :])
+        st = _lib.default_qp_settings(rho=rho, sigma=sigma, eps_abs=eps_abs, eps_rel=eps_rel,
+                                      max_iter=int(max_iter))
+        x, _y, status, iters, _res = qp.solve(st)
+    finally:
+        qp.close()
+    return x[0], int(status[0]), int(iters[0])
+
+
+# @profile
+def optimize(
+    osqp_vars: List[OSQPVar],
+    _sco_vars: List[Variable],
+    osqp_quad_objs: List[OSQPQuadraticObj],
+    osqp_lin_objs: List[OSQPLinearObj],
+    osqp_lin_cnt_exprs: List[OSQPLinearConstraint],
+    eps_abs: float = DEFAULT_EPS_ABS,
+    eps_rel: float = DEFAULT_EPS_REL,
+    max_iter: int = DEFAULT_MAX_ITER,
+    rho: float = DEFAULT_RHO,
+    adaptive_rho: bool = DEFAULT_ADAPTIVE_RHO,
+    sigma: float = DEFAULT_SIGMA,
+    verbose: bool = False,
+):
+    """Assemble the current QP and solve it (osqp_utils.py:113-221).
+
+    Returns ``(solve_res, var_to_index_dict)``; callers read ``solve_res.x`` and
+    ``solve_res.info.status_val`` (prob.py:197, 202)."""
+    if adaptive_rho:
+        # the reference default is False (osqp_utils.py:13) and OpenTAMP never enables it
+        raise NotImplementedError("adaptive_rho=True is not supported by the MI355X solver")
+    P, q, A, l, u, index = assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs)
+    x, status, iters = _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma)
+    solve_res = SimpleNamespace(x=x, info=SimpleNamespace(status_val=status, iter=iters))
+    if status == -2 and verbose:
+        print("ERROR! OSQP Solver hit max iteration limit. Either reduce your tolerances "
+              "or increase the max iterations!")
+    return (solve_res, index)
+
+
+def update_osqp_vars(var_to_osqp_indices_dict, solver_values):
+    """Scatter the solution vector into the atoms (osqp_utils.py:224-229)."""
+    for atom, k in var_to_osqp_indices_dict.items():
+        atom.val = solver_values[k]
+
+
+def print_osqp_vars_and_sol(solve_res_x, var_to_index_dict):
+    for atom, k in var_to_index_dict.items():
+        print(f"{atom}, {solve_res_x[k]}")
