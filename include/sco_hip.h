@@ -168,7 +168,9 @@ typedef struct sco_trajopt_desc {
   int n_obstacles;   /* circular obstacles per problem      */
   int family;        /* SCO_FAM_*                           */
   int analytic_jac;  /* 0: finite differences (reference default, expr.py:86-87), 1: analytic */
-  int reserved;
+  int prox_count;    /* how many Variables with a value hold each atom: the projection QP of
+                        find_closest_feasible_point adds one (x_i - x0_i)^2 per Variable
+                        (prob.py:381-404); 0 is read as 1 */
 } sco_trajopt_desc;
 
 typedef struct sco_sqp sco_sqp;

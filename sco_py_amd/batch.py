@@ -1,0 +1,126 @@
+"""Batched, device-resident SCO solves (``sco_sqp_*`` in include/sco_hip.h).
+
+The reference has no batch API: a caller such as OpenTAMP builds one ``Prob`` per
+candidate motion plan and calls ``Solver.solve`` on each in a Python loop
+(/root/reference/sco_py/sco_osqp/solver.py:30).  ``TrajOptBatch`` runs that same
+per-problem algorithm for B structurally identical trajectory problems at once,
+entirely on the GPU, for the constraint families the device can evaluate
+(include/sco_hip.h: SCO_FAM_*).  Arbitrary Python callables stay on the
+per-problem path (``sco_py_amd.sco_osqp``), where only the QP solve is on the GPU.
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib
+
+SCO_FAM_ARM_CIRCLES = 1
+TRACE_W = 8
+
+
+class TrajOptBatch(object):
+    """B planar-arm trajectory problems:
+
+        min  sum_t ||theta[t+1] - theta[t]||^2
+        s.t. theta[0] = start, theta[T-1] = goal,
+             r_o - ||p_k(theta[t]) - c_o|| <= 0   for all t, link points k, obstacles o
+
+    solved per problem exactly like ``Solver().solve(prob, method="penalty_sqp")``.
+    ``prox_count`` says how many Variables hold each atom in the equivalent object-API
+    construction (it scales the projection QP of find_closest_feasible_point,
+    prob.py:381-404); building the problem with one trajectory Variable plus one
+    Variable per timestep, as tests/trajopt_build.py does, gives 2.
+    """
+
+    def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
+                 prox_count=2):
+        self.B, self.d, self.T, self.K, self.O = int(batch), int(dof), int(horizon), int(n_points), int(n_obstacles)
+        self.n_x = self.d * self.T
+        self.device = int(device)
+        self._h = C.c_void_p()
+        desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O, SCO_FAM_ARM_CIRCLES,
+                                1 if analytic_jac else 0, int(prox_count))
+        _lib.check(_lib.load().sco_sqp_create(self.device, C.byref(desc), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.load().sco_sqp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles):
+        """Upload per-problem data (host arrays, copied)."""
+        B, d, K, O = self.B, self.d, self.K, self.O
+
+        def arr(a, shape, dt=np.float64):
+            a = np.ascontiguousarray(a, dtype=dt)
+            if a.shape != shape:
+                raise ValueError("expected shape %r, got %r" % (shape, a.shape))
+            return a
+
+        x0 = arr(x0, (B, self.n_x)); start = arr(start, (B, d)); goal = arr(goal, (B, d))
+        link_len = arr(link_len, (B, d)); obstacles = arr(obstacles, (B, O, 3))
+        point_link = arr(point_link, (K,), np.int32); point_frac = arr(point_frac, (K,))
+        _lib.check(_lib.load().sco_sqp_load(self._h, _lib.dptr(x0), _lib.dptr(start), _lib.dptr(goal),
+                                            _lib.dptr(link_len), _lib.iptr(point_link), _lib.dptr(point_frac),
+                                            _lib.dptr(obstacles)))
+
+    def solve(self, params=None, qp_settings=None):
+        """Run the penalty SQP for every problem; blocks until all are done.
+        May be called repeatedly: every call restarts from the loaded state."""
+        p = params if params is not None else _lib.default_sqp_params()
+        q = qp_settings if qp_settings is not None else _lib.default_qp_settings()
+        _lib.check(_lib.load().sco_sqp_solve(self._h, C.byref(p), C.byref(q)))
+
+    def fetch(self, with_merit=True):
+        B = self.B
+        x = np.zeros((B, self.n_x)); success = np.zeros(B, dtype=np.int32)
+        sqp_iters = np.zeros(B, dtype=np.int32); qp_solves = np.zeros(B, dtype=np.int32)
+        admm = np.zeros(B, dtype=np.int64)
+        merit = np.zeros(B) if with_merit else None
+        viol = np.zeros(B) if with_merit else None
+        _lib.check(_lib.load().sco_sqp_fetch(
+            self._h, _lib.dptr(x), _lib.iptr(success), _lib.iptr(sqp_iters), _lib.iptr(qp_solves),
+            admm.ctypes.data_as(C.POINTER(C.c_longlong)), _lib.dptr(merit), _lib.dptr(viol)))
+        return SimpleNamespace(x=x, success=success.astype(bool), sqp_iters=sqp_iters, qp_solves=qp_solves,
+                               admm_iters=admm, merit=merit, max_violation=viol)
+
+    def trace(self, cap=64):
+        """Per-problem decision trace: list of (n_rows, 8) arrays with columns
+        kind, merit, model_merit, new_merit, trust, penalty, qp_status, qp_iters."""
+        tr = np.zeros((self.B, cap, TRACE_W)); n = np.zeros(self.B, dtype=np.int32)
+        _lib.check(_lib.load().sco_sqp_trace(self._h, cap, _lib.dptr(tr), _lib.iptr(n)))
+        return [tr[b, : min(int(n[b]), cap)].copy() for b in range(self.B)]
+
+    def last_timing(self):
+        ms = np.zeros(5)
+        _lib.check(_lib.load().sco_sqp_last_timing(self._h, _lib.dptr(ms)))
+        return dict(convexify_ms=float(ms[0]), qp_setup_ms=float(ms[1]), admm_ms=float(ms[2]),
+                    decide_ms=float(ms[3]), total_ms=float(ms[4]))
+
+
+def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_jac=False, prox_count=2):
+    """One-shot helper: dict with keys d, T, K, O, B, x0, start, goal, link_len,
+    point_link, point_frac, obstacles (as produced by the synthetic workload
+    generator) -> result namespace of :meth:`TrajOptBatch.fetch`."""
+    a = batch_arrays
+    with TrajOptBatch(a["B"], a["d"], a["T"], a["K"], a["O"], device=device, analytic_jac=analytic_jac,
+                      prox_count=prox_count) as tb:
+        tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"])
+        tb.solve(params, qp_settings)
+        res = tb.fetch()
+        res.trace = tb.trace()
+        res.timing = tb.last_timing()
+    return res

@@ -66,4 +66,5 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
                             const int *Ap, const int *Ai, hipStream_t stream, sco_qp **out);
 // Launch setup + ADMM on the handle's stream for the problems whose active flag
 // is non-zero; no host synchronisation.
-int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev);
+// `mid` (may be null) is recorded between the two kernels so callers can split the time.
+int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, hipEvent_t mid);

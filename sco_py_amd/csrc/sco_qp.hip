@@ -677,7 +677,7 @@ extern "C" int sco_qp_set_bounds(sco_qp *qp, const double *l, const double *u) {
   return SCO_OK;
 }
 
-int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev) {
+int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, hipEvent_t mid) {
   QpDev d = qp->d; d.active = active_dev;
   SetupArgs sa{d, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling};
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
@@ -686,6 +686,7 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev) 
   hipLaunchKernelGGL(qp_setup_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_setup, qp->stream, sa);
   SCO_HIP(hipGetLastError());
   SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
+  if (mid) SCO_HIP(hipEventRecord(mid, qp->stream));
   hipLaunchKernelGGL(qp_admm_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_admm, qp->stream, aa);
   SCO_HIP(hipGetLastError());
   SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
@@ -700,7 +701,7 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
     sco_set_error("sco_qp_solve: bad settings"); return SCO_ERR_ARG;
   }
   SCO_HIP(hipSetDevice(qp->device));
-  int rc = sco_qp_launch(qp, settings, nullptr);
+  int rc = sco_qp_launch(qp, settings, nullptr, nullptr);
   if (rc) return rc;
   const QpDev &d = qp->d; const size_t B = d.batch;
   if (x) SCO_HIP(hipMemcpyAsync(x, d.x, B * d.n * sizeof(double), hipMemcpyDeviceToHost, qp->stream));

@@ -1,0 +1,727 @@
+// sco_sqp.hip -- device-resident penalty-SQP loop for a batch of trajectory
+// problems (SQP layer of libsco_hip).
+//
+// Per problem this is Solver.solve(prob, method="penalty_sqp") of the reference
+// (/root/reference/sco_py/sco_osqp/solver.py:30-253) together with the Prob methods
+// it drives (prob.py:369-652), restated as a per-problem state machine so that a
+// whole batch advances in lock-step "rounds", one QP solve per active problem per
+// round:
+//
+//   round 0   projection QP           find_closest_feasible_point (prob.py:369-412)
+//   round r   sqp_pre_kernel          convexify (prob.py:522-544, expr.py:130-142,
+//                                     353-371) with finite-difference Jacobians
+//                                     (expr.py:61-69), update_obj (prob.py:414-512,
+//                                     incl. quirks Q1/Q2), get_value (prob.py:571-579),
+//                                     save (prob.py:639-645), add_trust_region
+//                                     (variable.py:37-45), all written straight into the
+//                                     QP value arrays (no dense P/A as in
+//                                     osqp_utils.py:146-193)
+//             qp setup + ADMM         sco_qp.hip
+//             sqp_post_kernel         get_approx_value / get_value (prob.py:605-630,
+//                                     571-579), the accept / shrink / converge decisions
+//                                     (solver.py:151-251), penalty escalation
+//                                     (solver.py:84-105)
+//
+// One workgroup of 256 threads per problem; problems are independent, so there is
+// no inter-workgroup communication.  The host only reads one "active problems"
+// counter per round.
+#include "sco_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#define NWAVE (SCO_BLOCK / 64)
+#define FD_LEVELS 4
+#define FD_BASE (1.0 / 64.0)
+
+enum { ST_PROJECT = 0, ST_CONVEXIFY = 1, ST_TRIAL = 2, ST_DONE = 3 };
+enum { STEP_PROJECT = 0, STEP_ACCEPT = 1, STEP_SHRINK = 2, STEP_YCONV = 3, STEP_XCONV = 4, STEP_BAD = 5, STEP_GROUP = 6 };
+
+#define TRACE_W 8
+
+struct SqpScalars {
+  double penalty, trust, slack_cost, merit, merit_viol;
+  long long admm_iters;
+  int state, k, sqp_iters, qp_solves, success, escalations, n_trace, spawned;
+};
+
+struct SqpDev {
+  int batch, d, T, K, O, R, n_x, n_slack, n, m_lin, m_nl, m, prox_count, analytic_jac, trace_cap;
+  // problem data
+  double *x0, *start, *goal, *link_len, *obstacles;   // [B][...]
+  const int *point_link; const double *point_frac;    // [K]
+  // SQP state
+  double *x, *x_saved, *gsave, *J, *bmod, *trace;
+  unsigned char *mask;
+  SqpScalars *sc;
+  int *active, *n_active;
+  const int *jpos;   // [T*d] CSC position of J[t][0][j] in qp1's A values
+  const int *bpos;   // CSC positions are not needed for bounds: rows are contiguous
+};
+
+struct sco_sqp {
+  int device = 0;
+  sco_trajopt_desc desc{};
+  sco_qp *qp0 = nullptr, *qp1 = nullptr;
+  SqpDev d{};
+  hipStream_t stream = nullptr;
+  std::vector<void *> allocs;
+  std::vector<hipEvent_t> events;
+  bool loaded = false, solved = false;
+  double last_ms[5] = {0, 0, 0, 0, 0};
+  int rounds = 0;
+};
+
+// --------------------------------------------------------------------------
+// device helpers
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+// sums v[0..NS) and maxes v[NS..NS+NM) over the workgroup; result in every thread
+template <int NS, int NM>
+__device__ __forceinline__ void block_reduce_sm(double (&v)[NS + NM], double *red) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; k++) v[k] = wsum(v[k]);
+#pragma unroll
+  for (int k = NS; k < NS + NM; k++) v[k] = wmax(v[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NS + NM; k++) red[wv * (NS + NM) + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NS + NM; k++) {
+    double r = red[k];
+#pragma unroll
+    for (int w = 1; w < NWAVE; w++) {
+      const double o = red[w * (NS + NM) + k];
+      r = (k < NS) ? r + o : fmax(r, o);
+    }
+    v[k] = r;
+  }
+}
+
+// SCO_FAM_ARM_CIRCLES: row (k, o) of one timestep block,
+//   g = r_o - || p_k(theta) - c_o ||,  p_k = planar forward kinematics.
+// `pert` >= 0 adds `h` to joint `pert` (finite differences).
+__device__ __forceinline__ double arm_row(const double *th, const double *len, int lk, double frac,
+                                          double cx, double cy, double rad, int pert, double h) {
+  double phi = 0.0, px = 0.0, py = 0.0;
+  for (int i = 0; i <= lk; i++) {
+    double a = th[i];
+    if (i == pert) a += h;
+    phi += a;
+    double s, c;
+    sincos(phi, &s, &c);
+    const double L = (i == lk) ? frac * len[i] : len[i];
+    px += L * c; py += L * s;
+  }
+  const double dx = px - cx, dy = py - cy;
+  return rad - sqrt(dx * dx + dy * dy);
+}
+
+// analytic d g / d theta_j of the same row
+__device__ __forceinline__ double arm_row_grad(const double *th, const double *len, int lk, double frac,
+                                               double cx, double cy, int j) {
+  if (j > lk) return 0.0;
+  double phi = 0.0, px = 0.0, py = 0.0, sx = 0.0, sy = 0.0;
+  for (int i = 0; i <= lk; i++) {
+    phi += th[i];
+    double s, c;
+    sincos(phi, &s, &c);
+    const double L = (i == lk) ? frac * len[i] : len[i];
+    px += L * c; py += L * s;
+    if (i >= j) { sx += -L * s; sy += L * c; }
+  }
+  const double dx = px - cx, dy = py - cy;
+  return -(dx * sx + dy * sy) / sqrt(dx * dx + dy * dy);
+}
+
+__device__ __forceinline__ double traj_obj_partial(const double *x, int d, int T, int tid) {
+  double s = 0.0;
+  for (int e = tid; e < (T - 1) * d; e += SCO_BLOCK) {
+    const double df = x[e + d] - x[e];
+    s += df * df;
+  }
+  return s;
+}
+
+// --------------------------------------------------------------------------
+// round 0: projection QP values  (prob.py:369-412)
+//   P_ii = 2 c, q_i = -2 c x0_i  (c = number of Variables holding atom i),
+//   rows = [pins ; bound rows (-inf, inf)]
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, QpDev q0) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n_x = s.n_x, d = s.d, m0 = q0.m;
+  const double c = (double)s.prox_count;
+  const double *x0 = s.x0 + (size_t)b * n_x;
+  for (int i = tid; i < n_x; i += SCO_BLOCK) {
+    q0.Pval[(size_t)b * q0.nnzP + i] = 2.0 * c;
+    q0.q[(size_t)b * n_x + i] = (-2.0 * x0[i]) * c;
+    s.x[(size_t)b * n_x + i] = x0[i];
+  }
+  for (int t = tid; t < q0.nnzA; t += SCO_BLOCK) q0.Aval[(size_t)b * q0.nnzA + t] = 1.0;
+  for (int i = tid; i < m0; i += SCO_BLOCK) {
+    double lo, hi;
+    if (i < d) lo = hi = s.start[(size_t)b * d + i];
+    else if (i < 2 * d) lo = hi = s.goal[(size_t)b * d + (i - d)];
+    else { lo = -INFINITY; hi = INFINITY; }
+    q0.l[(size_t)b * m0 + i] = lo; q0.u[(size_t)b * m0 + i] = hi;
+    q0.w[(size_t)b * m0 + i] = 1;
+  }
+  if (tid == 0) {
+    SqpScalars &sc = s.sc[b];
+    sc.state = ST_PROJECT; sc.k = 0; sc.sqp_iters = 0; sc.qp_solves = 0; sc.success = 0;
+    sc.escalations = 0; sc.n_trace = 0; sc.spawned = 0; sc.admm_iters = 0;
+    sc.slack_cost = 1.0; sc.merit = 0.0; sc.merit_viol = 0.0;
+    s.active[b] = 1;
+  }
+}
+
+struct SqpParamsDev {
+  double improve_ratio_threshold, min_trust_region_size, min_approx_improve, trust_shrink_ratio,
+      trust_expand_ratio, cnt_tolerance, merit_coeff_increase_ratio, initial_trust_region_size,
+      initial_penalty_coeff;
+  int max_merit_coeff_increases, compound_penalty, duplicate_rows, max_qp_solves;
+};
+
+__device__ __forceinline__ void trace_row(const SqpDev &s, int b, SqpScalars &sc, int kind, double merit,
+                                          double model, double newm, double trust, double pen, int status,
+                                          int iters) {
+  if (sc.n_trace < s.trace_cap) {
+    double *r = s.trace + ((size_t)b * s.trace_cap + sc.n_trace) * TRACE_W;
+    r[0] = kind; r[1] = merit; r[2] = model; r[3] = newm; r[4] = trust; r[5] = pen; r[6] = status; r[7] = iters;
+  }
+  sc.n_trace++;
+}
+
+__global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDev q0, QpDev q1, SqpParamsDev p) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n_x = s.n_x, n = s.n, m = s.m, d = s.d;
+  const int status = q0.status[b];
+  const bool ok = (status == 1 || status == 2);
+  if (ok) for (int i = tid; i < n_x; i += SCO_BLOCK) s.x[(size_t)b * n_x + i] = q0.x[(size_t)b * n_x + i];
+  // constant parts of the penalty QP (prob.py:251-278, 348-367; osqp_utils.py:185-189)
+  {
+    double *Pv = q1.Pval + (size_t)b * q1.nnzP;
+    // pattern built on the host: column (t, j) holds [super-diagonal (-2) if t > 0, diagonal]
+    int pos = 0;
+    for (int col = 0; col < n_x; col++) {   // cheap: n_x entries, one thread
+      if (tid == 0) {
+        const int t = col / d;
+        if (t > 0) Pv[pos++] = -2.0;
+        Pv[pos++] = (t == 0 || t == s.T - 1) ? 2.0 : 4.0;
+      }
+    }
+    double *qv = q1.q + (size_t)b * n;
+    for (int i = tid; i < n; i += SCO_BLOCK) qv[i] = 0.0;
+    double *Av = q1.Aval + (size_t)b * q1.nnzA;
+    // x columns: [pin 1.0]? [R hinge entries (written by convexify)] [bound 1.0]
+    for (int col = tid; col < n_x; col += SCO_BLOCK) {
+      const int t = col / d;
+      int pz = q1.Ap[col];
+      if (t == 0 || t == s.T - 1) Av[pz++] = 1.0;
+      for (int r = 0; r < s.R; r++) Av[pz++] = 0.0;
+      Av[pz] = 1.0;
+    }
+    for (int sidx = tid; sidx < s.n_slack; sidx += SCO_BLOCK) {
+      const int pz = q1.Ap[n_x + sidx];
+      Av[pz] = -1.0; Av[pz + 1] = 1.0;
+    }
+    double *l = q1.l + (size_t)b * m, *u = q1.u + (size_t)b * m;
+    int *w = q1.w + (size_t)b * m;
+    for (int i = tid; i < m; i += SCO_BLOCK) {
+      double lo, hi;
+      if (i < d) lo = hi = s.start[(size_t)b * d + i];
+      else if (i < 2 * d) lo = hi = s.goal[(size_t)b * d + (i - d)];
+      else if (i < s.m_lin + s.m_nl) { lo = -INFINITY; hi = 0.0; }
+      else if (i < s.m_lin + s.m_nl + n_x) { lo = -INFINITY; hi = INFINITY; }
+      else { lo = 0.0; hi = INFINITY; }
+      l[i] = lo; u[i] = hi; w[i] = 1;
+    }
+  }
+  if (tid == 0) {
+    SqpScalars &sc = s.sc[b];
+    sc.qp_solves = 1; sc.admm_iters = q0.iters[b];
+    sc.penalty = p.initial_penalty_coeff; sc.trust = p.initial_trust_region_size;
+    trace_row(s, b, sc, STEP_PROJECT, 0.0, 0.0, 0.0, sc.trust, sc.penalty, status, q0.iters[b]);
+    if (ok) { sc.state = ST_CONVEXIFY; atomicAdd(s.n_active, 1); }
+    else { sc.state = ST_DONE; sc.success = 0; s.active[b] = 0; }   // solver.py:81-82
+  }
+}
+
+// --------------------------------------------------------------------------
+// sqp_pre: convexify + update_obj + merit + save (for problems that start a new
+// SQP iteration), then the trust-region bounds (for every active problem)
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, SqpParamsDev p) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  SqpScalars &sc = s.sc[b];
+  const int state = sc.state;
+  if (state == ST_DONE) return;
+  __shared__ double red[NWAVE * 4];
+  const int n_x = s.n_x, d = s.d, T = s.T, R = s.R, O = s.O, n = s.n, m = s.m;
+  double *x = s.x + (size_t)b * n_x, *xs = s.x_saved + (size_t)b * n_x;
+  const double *len = s.link_len + (size_t)b * d;
+  const double *obs = s.obstacles + (size_t)b * O * 3;
+  double *gs = s.gsave + (size_t)b * s.m_nl, *J = s.J + (size_t)b * s.m_nl * d, *bm = s.bmod + (size_t)b * s.m_nl;
+  unsigned char *mask = s.mask + (size_t)b * s.m_nl * d;
+  const double penalty = sc.penalty, trust = sc.trust;
+  const int spawned = sc.spawned;
+  int k_rows = sc.k;
+  double slack_cost = sc.slack_cost;
+
+  if (state == ST_CONVEXIFY) {
+    // S1: f(x) per row (expr.py:34-41)
+    for (int e = tid; e < T * R; e += SCO_BLOCK) {
+      const int t = e / R, r = e % R, kp = r / O, o = r % O;
+      gs[e] = arm_row(x + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
+    }
+    // S1: Jacobian entry per thread (expr.py:61-69 numeric / :88 analytic)
+    for (int e = tid; e < T * R * d; e += SCO_BLOCK) {
+      const int j = e % d, r = (e / d) % R, t = e / (d * R), kp = r / O, o = r % O;
+      const double *th = x + t * d;
+      const int lk = s.point_link[kp];
+      const double fr = s.point_frac[kp], cx = obs[3 * o], cy = obs[3 * o + 1], rad = obs[3 * o + 2];
+      double val;
+      if (s.analytic_jac) {
+        val = arm_row_grad(th, len, lk, fr, cx, cy, j);
+      } else {
+        // central differences on a halving ladder + Richardson extrapolation
+        const double h0 = FD_BASE * fmax(1.0, fabs(th[j]));
+        double tab[FD_LEVELS];
+#pragma unroll
+        for (int lv = 0; lv < FD_LEVELS; lv++) {
+          const double h = h0 / (double)(1 << lv);
+          const double fp = arm_row(th, len, lk, fr, cx, cy, rad, j, h);
+          const double fm = arm_row(th, len, lk, fr, cx, cy, rad, j, -h);
+          tab[lv] = (fp - fm) / (2.0 * h);
+        }
+        double p4 = 4.0;
+#pragma unroll
+        for (int i = 1; i < FD_LEVELS; i++) {
+          const double fac = 1.0 / (p4 - 1.0);
+#pragma unroll
+          for (int lv = FD_LEVELS - 1; lv >= i; lv--) tab[lv] = tab[lv] + (tab[lv] - tab[lv - 1]) * fac;
+          p4 *= 4.0;
+        }
+        val = tab[FD_LEVELS - 1];
+      }
+      J[e] = val;
+      if (!spawned) mask[e] = (val != 0.0) ? 1 : 0;   // creation-time pattern (prob.py:264, 440)
+    }
+    __syncthreads();
+    // S2: affine model b = f - J x - val (expr.py:141, 367), val = 0;  S3: rows
+    if (p.duplicate_rows) k_rows += 1; else k_rows = 1;
+    slack_cost = p.compound_penalty ? slack_cost * penalty : penalty;
+    double *Av = q1.Aval + (size_t)b * q1.nnzA;
+    double *u = q1.u + (size_t)b * m;
+    int *w = q1.w + (size_t)b * m;
+    for (int e = tid; e < T * R; e += SCO_BLOCK) {
+      const int t = e / R;
+      double acc = 0.0;
+      for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * x[t * d + j];
+      const double bb = gs[e] - acc;
+      bm[e] = bb;
+      u[s.m_lin + e] = -bb;            // -inf <= a x - t <= -b  (prob.py:265-275, 486)
+      w[s.m_lin + e] = k_rows;         // row present k times (prob.py:508-509)
+    }
+    for (int e = tid; e < T * R * d; e += SCO_BLOCK) {
+      const int j = e % d, r = (e / d) % R, t = e / (d * R);
+      Av[s.jpos[t * d + j] + r] = mask[e] ? J[e] : 0.0;   // prob.py:493-504
+    }
+    double *qv = q1.q + (size_t)b * n;
+    for (int i = tid; i < s.n_slack; i += SCO_BLOCK) qv[n_x + i] = slack_cost;   // prob.py:424-426
+    // S7: merit at the convexification point (prob.py:571-579), S4 prerequisite: save
+    double v[2] = {traj_obj_partial(x, d, T, tid), 0.0};
+    for (int e = tid; e < T * R; e += SCO_BLOCK) v[1] += fmax(gs[e], 0.0);
+    block_reduce_sm<2, 0>(v, red);
+    for (int i = tid; i < n_x; i += SCO_BLOCK) xs[i] = x[i];
+    if (tid == 0) {
+      sc.merit_viol = v[1];
+      sc.merit = v[0] + penalty * v[1];
+      sc.k = k_rows; sc.slack_cost = slack_cost; sc.spawned = 1;
+      sc.sqp_iters += 1;
+      sc.state = ST_TRIAL;
+    }
+    __syncthreads();
+  }
+  // S4: trust box around the saved point (variable.py:43-45)
+  {
+    double *l = q1.l + (size_t)b * m, *u = q1.u + (size_t)b * m;
+    const int base = s.m_lin + s.m_nl;
+    for (int i = tid; i < n_x; i += SCO_BLOCK) { l[base + i] = xs[i] - trust; u[base + i] = xs[i] + trust; }
+  }
+}
+
+// --------------------------------------------------------------------------
+// sqp_post: model merit, new merit, decision
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1, SqpParamsDev p) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  SqpScalars &sc = s.sc[b];
+  if (sc.state != ST_TRIAL) return;
+  __shared__ double red[NWAVE * 4];
+  const int n_x = s.n_x, d = s.d, T = s.T, R = s.R, O = s.O, n = s.n;
+  double *x = s.x + (size_t)b * n_x, *xs = s.x_saved + (size_t)b * n_x;
+  const double *len = s.link_len + (size_t)b * d;
+  const double *obs = s.obstacles + (size_t)b * O * 3;
+  const double *gs = s.gsave + (size_t)b * s.m_nl, *J = s.J + (size_t)b * s.m_nl * d, *bm = s.bmod + (size_t)b * s.m_nl;
+  const int status = q1.status[b], iters = q1.iters[b];
+  // every scalar is read BEFORE the reduction's barriers; thread 0 rewrites them afterwards
+  const double pen = sc.penalty, trust = sc.trust, merit = sc.merit, merit_viol0 = sc.merit_viol;
+  const int qp_solves0 = sc.qp_solves;
+  const bool ok = (status == 1 || status == 2);                 // prob.py:197
+  const double *xq = ok ? (q1.x + (size_t)b * n) : xs;          // failed QP leaves the variables alone
+  // model violation uses the FULL Jacobian (prob.py:627-628), new violation fresh f (prob.py:575-577)
+  double v[4] = {traj_obj_partial(xq, d, T, tid), 0.0, 0.0, 0.0};
+  for (int e = tid; e < T * R; e += SCO_BLOCK) {
+    const int t = e / R, r = e % R, kp = r / O, o = r % O;
+    double acc = 0.0;
+    for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * xq[t * d + j];
+    v[1] += fmax(acc + bm[e], 0.0);
+    const double g = arm_row(xq + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
+    v[2] += fmax(g, 0.0);
+    v[3] = fmax(v[3], fmax(gs[e], 0.0));                        // max violation at the SAVED point
+  }
+  block_reduce_sm<3, 1>(v, red);
+  const double model_merit = v[0] + pen * v[1], new_merit = v[0] + pen * v[2];
+  double approx = merit - model_merit;
+  if (approx == 0.0) approx += 1e-12;                           // solver.py:152-153
+  const double exact = merit - new_merit;
+  const double ratio = exact / approx;
+  const double approx_vec = merit_viol0 - v[1];               // single group "all" (prob.py:135-136)
+  const bool violated = merit_viol0 > p.cnt_tolerance;
+  int kind, ret = -1;   // ret: -1 continue, 0/1 = _min_merit_fn returned False/True
+  double new_trust = trust;
+  if (approx < -1e-5) { kind = STEP_BAD; ret = 0; }                               // solver.py:185-198
+  else if (approx < p.min_approx_improve) { kind = STEP_YCONV; ret = 1; }         // solver.py:200-204
+  else if (violated && approx_vec < p.min_approx_improve) { kind = STEP_GROUP; ret = 1; }   // solver.py:209-235
+  else if (exact < 0.0 || ratio < p.improve_ratio_threshold) {                   // solver.py:237-241
+    kind = STEP_SHRINK; new_trust = trust * p.trust_shrink_ratio;
+    if (new_trust < p.min_trust_region_size) { kind = STEP_XCONV; ret = 1; }      // solver.py:248-251
+  } else { kind = STEP_ACCEPT; new_trust = trust * p.trust_expand_ratio; }        // solver.py:242-246
+  const int qp_solves = qp_solves0 + 1;
+  const bool capped = (ret < 0) && (qp_solves >= p.max_qp_solves);
+  if (kind == STEP_ACCEPT) for (int i = tid; i < n_x; i += SCO_BLOCK) x[i] = xq[i];
+  // every other outcome restores the saved point (solver.py:197, 203, 229, 238); x == xs already
+  if (tid == 0) {
+    sc.qp_solves = qp_solves; sc.admm_iters += iters;
+    trace_row(s, b, sc, kind, merit, model_merit, new_merit, trust, pen, status, iters);
+    sc.trust = new_trust;
+    if (ret < 0 && !capped) {
+      sc.state = (kind == STEP_ACCEPT) ? ST_CONVEXIFY : ST_TRIAL;
+      atomicAdd(s.n_active, 1);
+    } else {
+      // _min_merit_fn returned: outer loop of _penalty_sqp (solver.py:84-105)
+      const double max_viol = v[3];
+      sc.escalations += 1;
+      if (!capped && max_viol > p.cnt_tolerance && sc.escalations < p.max_merit_coeff_increases) {
+        sc.penalty = pen * p.merit_coeff_increase_ratio;
+        sc.trust = p.initial_trust_region_size;
+        sc.state = ST_CONVEXIFY;
+        atomicAdd(s.n_active, 1);
+      } else {
+        sc.success = (!capped && max_viol <= p.cnt_tolerance) ? ret : 0;
+        sc.state = ST_DONE; s.active[b] = 0;
+      }
+    }
+  }
+}
+
+// final merit / max violation at the returned point (prob.py:571-603)
+__global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *merit_out, double *viol_out) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ double red[NWAVE * 4];
+  const int n_x = s.n_x, d = s.d, T = s.T, R = s.R, O = s.O;
+  const double *x = s.x + (size_t)b * n_x;
+  const double *len = s.link_len + (size_t)b * d;
+  const double *obs = s.obstacles + (size_t)b * O * 3;
+  double v[3] = {traj_obj_partial(x, d, T, tid), 0.0, 0.0};
+  for (int e = tid; e < T * R; e += SCO_BLOCK) {
+    const int t = e / R, r = e % R, kp = r / O, o = r % O;
+    const double g = arm_row(x + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
+    v[1] += fmax(g, 0.0); v[2] = fmax(v[2], fmax(g, 0.0));
+  }
+  block_reduce_sm<2, 1>(v, red);
+  if (tid == 0) { merit_out[b] = v[0] + s.sc[b].penalty * v[1]; viol_out[b] = v[2]; }
+}
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+extern "C" void sco_sqp_default_params(sco_sqp_params *p) {
+  if (!p) return;
+  p->improve_ratio_threshold = 0.25; p->min_trust_region_size = 1e-4; p->min_approx_improve = 1e-8;
+  p->trust_shrink_ratio = 0.1; p->trust_expand_ratio = 1.5; p->cnt_tolerance = 1e-4;
+  p->merit_coeff_increase_ratio = 10.0; p->initial_trust_region_size = 1.0; p->initial_penalty_coeff = 1e3;
+  p->max_merit_coeff_increases = 1; p->compound_penalty = 1; p->duplicate_rows = 1; p->max_sqp_iters = 0;
+}
+
+template <typename T>
+static int sq_alloc(sco_sqp *h, size_t count, T **out) {
+  void *p = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  SCO_HIP(hipMalloc(&p, bytes));
+  SCO_HIP(hipMemset(p, 0, bytes));
+  h->allocs.push_back(p);
+  *out = (T *)p;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
+  if (!desc || !out) { sco_set_error("sco_sqp_create: null pointer"); return SCO_ERR_ARG; }
+  if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
+      desc->family != SCO_FAM_ARM_CIRCLES) {
+    sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    sco_set_error("sco_sqp_create: no HIP device visible (this library has no CPU fallback)");
+    return SCO_ERR_NO_GPU;
+  }
+  if (device < 0 || device >= ndev) { sco_set_error("sco_sqp_create: bad device index"); return SCO_ERR_ARG; }
+  SCO_HIP(hipSetDevice(device));
+  sco_sqp *h = new sco_sqp();
+  h->device = device; h->desc = *desc;
+  SCO_HIP(hipStreamCreate(&h->stream));
+  const int B = desc->batch, d = desc->dof, T = desc->horizon, K = desc->n_points, O = desc->n_obstacles;
+  const int R = K * O, n_x = d * T, n_slack = T * R, n = n_x + n_slack, m_lin = 2 * d, m_nl = T * R, m = m_lin + m_nl + n;
+  // ---- projection QP pattern: P = diag, A = [pins ; I]
+  {
+    std::vector<int> Pp(n_x + 1), Pi(n_x), Ap(n_x + 1), Ai;
+    for (int i = 0; i < n_x; i++) { Pp[i] = i; Pi[i] = i; }
+    Pp[n_x] = n_x;
+    for (int col = 0; col < n_x; col++) {
+      Ap[col] = (int)Ai.size();
+      const int t = col / d, j = col % d;
+      if (t == 0) Ai.push_back(j);
+      if (t == T - 1) Ai.push_back(d + j);
+      Ai.push_back(m_lin + col);
+    }
+    Ap[n_x] = (int)Ai.size();
+    int rc = sco_qp_create_on_stream(device, B, n_x, m_lin + n_x, Pp.data(), Pi.data(), Ap.data(), Ai.data(), h->stream, &h->qp0);
+    if (rc) { delete h; return rc; }
+  }
+  // ---- penalty QP pattern (prob.py:251-278 rows, osqp_utils.py:185-189 bound rows)
+  std::vector<int> jpos(n_x);
+  {
+    std::vector<int> Pp(n + 1), Pi, Ap(n + 1), Ai;
+    for (int col = 0; col < n; col++) {
+      Pp[col] = (int)Pi.size();
+      if (col < n_x) {
+        if (col / d > 0) Pi.push_back(col - d);
+        Pi.push_back(col);
+      }
+    }
+    Pp[n] = (int)Pi.size();
+    for (int col = 0; col < n; col++) {
+      Ap[col] = (int)Ai.size();
+      if (col < n_x) {
+        const int t = col / d, j = col % d;
+        if (t == 0) Ai.push_back(j);
+        if (t == T - 1) Ai.push_back(d + j);
+        jpos[col] = (int)Ai.size();
+        for (int r = 0; r < R; r++) Ai.push_back(m_lin + t * R + r);
+        Ai.push_back(m_lin + m_nl + col);
+      } else {
+        const int sidx = col - n_x;
+        Ai.push_back(m_lin + sidx);
+        Ai.push_back(m_lin + m_nl + col);
+      }
+    }
+    Ap[n] = (int)Ai.size();
+    int rc = sco_qp_create_on_stream(device, B, n, m, Pp.data(), Pi.data(), Ap.data(), Ai.data(), h->stream, &h->qp1);
+    if (rc) { sco_qp_destroy(h->qp0); delete h; return rc; }
+  }
+  SqpDev &s = h->d;
+  s.batch = B; s.d = d; s.T = T; s.K = K; s.O = O; s.R = R; s.n_x = n_x; s.n_slack = n_slack; s.n = n;
+  s.m_lin = m_lin; s.m_nl = m_nl; s.m = m; s.prox_count = desc->prox_count > 0 ? desc->prox_count : 1;
+  s.analytic_jac = desc->analytic_jac; s.trace_cap = 64;
+  int rc = 0;
+#define AL(f, cnt) if ((rc = sq_alloc(h, (cnt), &s.f))) return rc;
+  AL(x0, (size_t)B * n_x) AL(start, (size_t)B * d) AL(goal, (size_t)B * d) AL(link_len, (size_t)B * d)
+  AL(obstacles, (size_t)B * O * 3)
+  AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
+  AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
+  AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, 1)
+#undef AL
+  { int *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_link = p; }
+  { double *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_frac = p; }
+  { int *p; if ((rc = sq_alloc(h, (size_t)n_x, &p))) return rc; s.jpos = p;
+    SCO_HIP(hipMemcpy(p, jpos.data(), n_x * sizeof(int), hipMemcpyHostToDevice)); }
+  s.bpos = nullptr;
+  *out = h;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_destroy(sco_sqp *h) {
+  if (!h) return SCO_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->qp0) sco_qp_destroy(h->qp0);
+  if (h->qp1) sco_qp_destroy(h->qp1);
+  for (void *p : h->allocs) (void)hipFree(p);
+  for (auto e : h->events) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, const double *goal,
+                            const double *link_len, const int *point_link, const double *point_frac,
+                            const double *obstacles) {
+  if (!h || !x0 || !start || !goal || !link_len || !point_link || !point_frac || !obstacles) {
+    sco_set_error("sco_sqp_load: null pointer"); return SCO_ERR_ARG;
+  }
+  const SqpDev &s = h->d;
+  for (int k = 0; k < s.K; k++)
+    if (point_link[k] < 0 || point_link[k] >= s.d) { sco_set_error("sco_sqp_load: point_link out of range"); return SCO_ERR_ARG; }
+  SCO_HIP(hipSetDevice(h->device));
+  const size_t B = s.batch;
+  SCO_HIP(hipMemcpyAsync(s.x0, x0, B * s.n_x * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync(s.start, start, B * s.d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync(s.goal, goal, B * s.d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync(s.link_len, link_len, B * s.d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync(s.obstacles, obstacles, B * s.O * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync((void *)s.point_link, point_link, s.K * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync((void *)s.point_frac, point_frac, s.K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipStreamSynchronize(h->stream));
+  h->loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
+static hipEvent_t next_event(sco_sqp *h, size_t &cursor) {
+  if (cursor == h->events.size()) {
+    hipEvent_t e; (void)hipEventCreate(&e); h->events.push_back(e);
+  }
+  return h->events[cursor++];
+}
+
+extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco_qp_settings *qs) {
+  if (!h || !params || !qs) { sco_set_error("sco_sqp_solve: null pointer"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_solve: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  SCO_HIP(hipSetDevice(h->device));
+  SqpDev &s = h->d;
+  SqpParamsDev p{params->improve_ratio_threshold, params->min_trust_region_size, params->min_approx_improve,
+                 params->trust_shrink_ratio, params->trust_expand_ratio, params->cnt_tolerance,
+                 params->merit_coeff_increase_ratio, params->initial_trust_region_size, params->initial_penalty_coeff,
+                 params->max_merit_coeff_increases, params->compound_penalty, params->duplicate_rows,
+                 params->max_sqp_iters > 0 ? params->max_sqp_iters : 10000};
+  const dim3 grid(s.batch), block(SCO_BLOCK);
+  size_t ec = 0;
+  std::vector<int> stage;   // stage id of the interval that ENDS at event i
+  auto mark = [&](int st) { hipEvent_t e = next_event(h, ec); (void)hipEventRecord(e, h->stream); stage.push_back(st); };
+  mark(-1);
+  // ---- round 0: projection onto the linear constraints, DEFAULT QP settings (Q7)
+  SCO_HIP(hipMemsetAsync(s.n_active, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(sqp_proj_assemble_kernel, grid, block, 0, h->stream, s, h->qp0->d);
+  SCO_HIP(hipGetLastError());
+  mark(0);
+  sco_qp_settings q0s; sco_qp_default_settings(&q0s);
+  hipEvent_t mid = next_event(h, ec); stage.push_back(1);
+  int rc = sco_qp_launch(h->qp0, &q0s, nullptr, mid);
+  if (rc) return rc;
+  mark(2);
+  hipLaunchKernelGGL(sqp_proj_post_kernel, grid, block, 0, h->stream, s, h->qp0->d, h->qp1->d, p);
+  SCO_HIP(hipGetLastError());
+  mark(3);
+  int n_active = 0;
+  SCO_HIP(hipMemcpyAsync(&n_active, s.n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  SCO_HIP(hipStreamSynchronize(h->stream));
+  h->rounds = 1;
+  // ---- rounds: one QP solve per active problem
+  const int round_cap = p.max_qp_solves + 8;
+  while (n_active > 0 && h->rounds < round_cap) {
+    SCO_HIP(hipMemsetAsync(s.n_active, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(sqp_pre_kernel, grid, block, 0, h->stream, s, h->qp1->d, p);
+    SCO_HIP(hipGetLastError());
+    mark(0);
+    mid = next_event(h, ec); stage.push_back(1);
+    rc = sco_qp_launch(h->qp1, qs, s.active, mid);
+    if (rc) return rc;
+    mark(2);
+    hipLaunchKernelGGL(sqp_post_kernel, grid, block, 0, h->stream, s, h->qp1->d, p);
+    SCO_HIP(hipGetLastError());
+    mark(3);
+    SCO_HIP(hipMemcpyAsync(&n_active, s.n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SCO_HIP(hipStreamSynchronize(h->stream));
+    h->rounds++;
+  }
+  // ---- timing: sum the event intervals by stage
+  double ms[5] = {0, 0, 0, 0, 0};
+  for (size_t i = 1; i < ec; i++) {
+    float t = 0; (void)hipEventElapsedTime(&t, h->events[i - 1], h->events[i]);
+    if (stage[i] >= 0) ms[stage[i]] += t;
+    ms[4] += t;
+  }
+  memcpy(h->last_ms, ms, sizeof ms);
+  h->solved = true;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_fetch(sco_sqp *h, double *x, int *success, int *sqp_iters, int *qp_solves,
+                             long long *admm_iters, double *merit, double *max_violation) {
+  if (!h) return SCO_ERR_ARG;
+  if (!h->solved) { sco_set_error("sco_sqp_fetch: call sco_sqp_solve first"); return SCO_ERR_STATE; }
+  SCO_HIP(hipSetDevice(h->device));
+  const SqpDev &s = h->d; const size_t B = s.batch;
+  if (x) SCO_HIP(hipMemcpy(x, s.x, B * s.n_x * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<SqpScalars> sc(B);
+  SCO_HIP(hipMemcpy(sc.data(), s.sc, B * sizeof(SqpScalars), hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < B; b++) {
+    if (success) success[b] = sc[b].success;
+    if (sqp_iters) sqp_iters[b] = sc[b].sqp_iters;
+    if (qp_solves) qp_solves[b] = sc[b].qp_solves;
+    if (admm_iters) admm_iters[b] = sc[b].admm_iters;
+  }
+  if (merit || max_violation) {
+    double *dm = nullptr, *dv = nullptr;
+    SCO_HIP(hipMalloc((void **)&dm, B * sizeof(double)));
+    SCO_HIP(hipMalloc((void **)&dv, B * sizeof(double)));
+    hipLaunchKernelGGL(sqp_final_kernel, dim3(s.batch), dim3(SCO_BLOCK), 0, h->stream, s, dm, dv);
+    SCO_HIP(hipGetLastError());
+    SCO_HIP(hipStreamSynchronize(h->stream));
+    if (merit) SCO_HIP(hipMemcpy(merit, dm, B * sizeof(double), hipMemcpyDeviceToHost));
+    if (max_violation) SCO_HIP(hipMemcpy(max_violation, dv, B * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dm); (void)hipFree(dv);
+  }
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_trace(sco_sqp *h, int cap, double *trace, int *n_entries) {
+  if (!h || !trace || !n_entries || cap <= 0) return SCO_ERR_ARG;
+  if (!h->solved) { sco_set_error("sco_sqp_trace: call sco_sqp_solve first"); return SCO_ERR_STATE; }
+  SCO_HIP(hipSetDevice(h->device));
+  const SqpDev &s = h->d; const size_t B = s.batch;
+  std::vector<double> tr(B * s.trace_cap * TRACE_W);
+  std::vector<SqpScalars> sc(B);
+  SCO_HIP(hipMemcpy(tr.data(), s.trace, tr.size() * sizeof(double), hipMemcpyDeviceToHost));
+  SCO_HIP(hipMemcpy(sc.data(), s.sc, B * sizeof(SqpScalars), hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < B; b++) {
+    n_entries[b] = sc[b].n_trace;
+    const int rows = std::min(std::min(sc[b].n_trace, s.trace_cap), cap);
+    for (int r = 0; r < rows; r++)
+      memcpy(trace + (b * cap + r) * TRACE_W, tr.data() + (b * s.trace_cap + r) * TRACE_W, TRACE_W * sizeof(double));
+  }
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_last_timing(const sco_sqp *h, double ms[5]) {
+  if (!h || !ms) return SCO_ERR_ARG;
+  memcpy(ms, h->last_ms, 5 * sizeof(double));
+  return SCO_OK;
+}

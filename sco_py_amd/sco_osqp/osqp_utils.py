@@ -113,6 +113,11 @@ class OSQPLinearConstraint(object):
 # assembly (S5) -- the reference's Python loops over dense matrices
 # (osqp_utils.py:146-193) restated as triplet accumulation
 # --------------------------------------------------------------------------
+def _scalar(v):
+    """Row bounds arrive as floats or as 1-element arrays (b[i] of an (r, 1) offset)."""
+    return v if isinstance(v, float) else np.asarray(v, dtype=np.float64).reshape(-1)[0]
+
+
 def assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs):
     """Returns (P_triu csc, q, A csc, l, u, var_to_index_dict).
 
@@ -148,8 +153,8 @@ def assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs):
     u = np.zeros(m)
     cells = {}
     for row, cnt in enumerate(osqp_lin_cnt_exprs):
-        l[row] = cnt.lb
-        u[row] = cnt.ub
+        l[row] = _scalar(cnt.lb)
+        u[row] = _scalar(cnt.ub)
         for k in range(cnt.coeffs.shape[0]):
             cells[(row, index[cnt.osqp_vars[k]])] = cnt.coeffs[k]
     row = len(osqp_lin_cnt_exprs)

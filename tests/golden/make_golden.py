@@ -1,0 +1,209 @@
+"""Generate golden vectors by running the REFERENCE's own modules in this container.
+
+Run once, here, as   python tests/golden/make_golden.py   (the GPU box has no
+/root/reference; only the .npz/.json files this script writes travel).
+
+The reference (/root/reference/sco_py) imports two third-party packages that are
+neither vendored nor installed: ``osqp`` (osqp_utils.py:4) and ``numdifftools``
+(expr.py:1).  Nothing was denied by the environment; the imports simply fail.  To
+let every line of the reference's OWN arithmetic run (S2 convexify algebra, S3
+penalty lowering, S4 trust region, S5 assembly, S7 merits, S8 control flow) this
+script registers two stand-in modules for those third-party names:
+  * ``osqp.OSQP``     -> records the exact arguments of setup(...) and answers
+                         solve() with oracle/osqp_ref.c (our restatement of OSQP);
+  * ``numdifftools``  -> Jacobian/Hessian by the Richardson central differences
+                         of sco_py_amd/numdiff.py.
+Everything the stand-ins return is OURS and is labelled so below; everything else
+in the recorded vectors is computed by unmodified reference code.  No reference
+source text is copied: the fixtures hold numbers only.
+
+Outputs (tests/golden/):
+  kat_results.json     pass/fail of the reference's tests/sco_osqp suite under this harness
+  trajopt_small.npz    4 problems d=3 T=6 K=2 O=2: full QP sequence, merit-call log, result
+  trajopt_7x20.npz     problem 0 at d=7 T=20 K=5 O=2: QP sequence (sparse), merit log, result
+  quirks.npz           Q1/Q2/Q14 demonstrations (q and A shapes over three update_obj calls)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import arm_family as af          # noqa: E402
+from oracle import osqp_ref                  # noqa: E402
+from sco_py_amd import numdiff               # noqa: E402
+
+QP_LOG = []
+
+
+def install_standins():
+    nd = types.ModuleType("numdifftools")
+
+    class Jacobian(object):
+        def __init__(self, f, **kw):
+            self.f = f
+
+        def __call__(self, x):
+            x = np.asarray(x, dtype=np.float64)
+            return numdiff.jacobian(lambda v: np.ravel(self.f(v.reshape(x.shape))), x.ravel())
+
+    class Hessian(object):
+        def __init__(self, f, **kw):
+            self.f = f
+
+        def __call__(self, x):
+            x = np.asarray(x, dtype=np.float64)
+            return numdiff.hessian(lambda v: np.ravel(self.f(v.reshape(x.shape))), x.ravel())
+
+    nd.Jacobian, nd.Hessian = Jacobian, Hessian
+    sys.modules["numdifftools"] = nd
+
+    osqp = types.ModuleType("osqp")
+
+    class OSQP(object):
+        def setup(self, P=None, q=None, A=None, l=None, u=None, **kw):
+            self.args = dict(P=P, q=q, A=A, l=l, u=u, kw=kw)
+
+        def solve(self):
+            a = self.args
+            kw = a["kw"]
+            res = osqp_ref.solve(a["P"], a["q"], a["A"], a["l"], a["u"], rho=kw["rho"], sigma=kw["sigma"],
+                                 eps_abs=kw["eps_abs"], eps_rel=kw["eps_rel"], max_iter=int(kw["max_iter"]))
+            QP_LOG.append(dict(P=sp.csc_matrix(a["P"]).toarray(), q=np.array(a["q"]),
+                               A=sp.csc_matrix(a["A"]).toarray(), l=np.array(a["l"]), u=np.array(a["u"]),
+                               x=res.x.copy(), status=res.info.status_val, iters=res.info.iter,
+                               settings={k: (float(v) if not isinstance(v, bool) else v) for k, v in kw.items()}))
+            return res
+
+    osqp.OSQP = OSQP
+    sys.modules["osqp"] = osqp
+
+
+def import_reference():
+    sys.path.insert(0, "/root/reference")
+    import sco_py.expr as rexpr
+    import sco_py.sco_osqp.osqp_utils as rutils
+    import sco_py.sco_osqp.prob as rprob
+    import sco_py.sco_osqp.solver as rsolver
+    import sco_py.sco_osqp.variable as rvar
+    assert rexpr.__file__.startswith("/root/reference"), rexpr.__file__
+    mods = types.SimpleNamespace(
+        Expr=rexpr.Expr, AffExpr=rexpr.AffExpr, QuadExpr=rexpr.QuadExpr, EqExpr=rexpr.EqExpr,
+        LEqExpr=rexpr.LEqExpr, BoundExpr=rexpr.BoundExpr, AbsExpr=rexpr.AbsExpr, HingeExpr=rexpr.HingeExpr,
+        Variable=rvar.Variable, OSQPVar=rutils.OSQPVar, Prob=rprob.Prob, Solver=rsolver.Solver,
+        OSQPLinearConstraint=rutils.OSQPLinearConstraint)
+    return mods
+
+
+def run_reference_tests():
+    import pytest
+    rc = pytest.main(["-q", "--rootdir=/tmp", "-p", "no:cacheprovider", "/root/reference/tests/sco_osqp"])
+    return int(rc)
+
+
+def run_trajopt(mods, pr, analytic_jac=False):
+    import trajopt_build as tb
+    del QP_LOG[:]
+    prob, traj, step_vars, atoms = tb.build_prob(mods, pr, analytic_jac=analytic_jac)
+    merit_log = []
+    gv, gav = prob.get_value, prob.get_approx_value
+
+    def get_value(pc, vectorize=False):
+        v = gv(pc, vectorize)
+        merit_log.append((0.0, float(vectorize), float(pc), float(np.sum(v))))
+        return v
+
+    def get_approx_value(pc, vectorize=False):
+        v = gav(pc, vectorize)
+        merit_log.append((1.0, float(vectorize), float(pc), float(np.sum(v))))
+        return v
+
+    prob.get_value, prob.get_approx_value = get_value, get_approx_value
+    solver = mods.Solver()
+    ok = solver.solve(prob, method="penalty_sqp")
+    n_x = pr["d"] * pr["T"]
+    qps = []
+    for rec in QP_LOG:
+        if rec["q"].shape[0] == n_x:     # projection QP: no slack columns yet
+            P2, q2, A2, l2, u2, perm = tb.canonical_qp(rec["P"], rec["q"], rec["A"], rec["l"], rec["u"], n_x)
+        else:
+            P2, q2, A2, l2, u2, perm = tb.canonical_qp(rec["P"], rec["q"], rec["A"], rec["l"], rec["u"], n_x)
+        qps.append(dict(P=P2, q=q2, A=A2, l=l2, u=u2, x=rec["x"][perm], status=rec["status"], iters=rec["iters"]))
+    return dict(success=bool(ok), x=traj.get_value().ravel(), qps=qps, merit_log=np.array(merit_log),
+                max_violation=float(prob.get_max_cnt_violation()))
+
+
+def pack(prefix, res, out, sparse=False):
+    out[prefix + "success"] = np.array(res["success"])
+    out[prefix + "x"] = res["x"]
+    out[prefix + "merit_log"] = res["merit_log"]
+    out[prefix + "max_violation"] = np.array(res["max_violation"])
+    out[prefix + "n_qp"] = np.array(len(res["qps"]))
+    for k, qp in enumerate(res["qps"]):
+        base = "%sqp%d_" % (prefix, k)
+        for name in ("q", "l", "u", "x"):
+            out[base + name] = qp[name]
+        out[base + "status"] = np.array(qp["status"]); out[base + "iters"] = np.array(qp["iters"])
+        for name in ("P", "A"):
+            if sparse:
+                c = sp.coo_matrix(qp[name])
+                out[base + name + "_shape"] = np.array(c.shape)
+                out[base + name + "_row"] = c.row.astype(np.int32)
+                out[base + name + "_col"] = c.col.astype(np.int32)
+                out[base + name + "_val"] = c.data
+            else:
+                out[base + name] = qp[name]
+
+
+def quirk_vectors(mods):
+    """Q1/Q2/Q14 in numbers: min x^2 - 2x + pen*|x - 4| style problem, three update_obj calls."""
+    f = lambda x: np.array([[x[0, 0] ** 2]])
+    prob = mods.Prob()
+    v = mods.OSQPVar("x"); prob.add_osqp_var(v)
+    var = mods.Variable(np.array([[v]]), np.array([[1.0]])); prob.add_var(var)
+    prob.add_obj_expr(mods.BoundExpr(mods.QuadExpr(2 * np.eye(1), -2 * np.ones((1, 1)), np.zeros((1, 1))), var))
+    prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(mods.Expr(f), np.array([[4.0]])), var))
+    qs, shapes = [], []
+    for _ in range(3):
+        del QP_LOG[:]
+        prob.convexify(); prob.update_obj(10.0); prob.optimize()
+        rec = QP_LOG[-1]
+        order = np.argsort(rec["q"], kind="stable")
+        qs.append(np.sort(rec["q"])); shapes.append(rec["A"].shape)
+    return dict(q=np.array(qs), A_shapes=np.array(shapes))
+
+
+def main():
+    install_standins()
+    mods = import_reference()
+    rc = run_reference_tests()
+    with open(os.path.join(HERE, "kat_results.json"), "w") as fh:
+        json.dump({"suite": "reference tests/sco_osqp run on reference modules with stand-in osqp "
+                            "(oracle/osqp_ref.c) and numdifftools (sco_py_amd/numdiff.py)",
+                   "pytest_exit_code": rc}, fh, indent=1)
+    out = {}
+    for i in range(4):
+        pr = af.make_problem(i, d=3, T=6, K=2, O=2)
+        pack("p%d_" % i, run_trajopt(mods, pr), out)
+    pr = af.make_problem(1, d=3, T=6, K=2, O=2)
+    pack("p1a_", run_trajopt(mods, pr, analytic_jac=True), out)
+    np.savez_compressed(os.path.join(HERE, "trajopt_small.npz"), **out)
+    out = {}
+    pack("p0_", run_trajopt(mods, af.make_problem(0)), out, sparse=True)
+    np.savez_compressed(os.path.join(HERE, "trajopt_7x20.npz"), **out)
+    qv = quirk_vectors(mods)
+    np.savez_compressed(os.path.join(HERE, "quirks.npz"), **qv)
+    print("reference test-suite exit code under the harness:", rc)
+    for f in ("trajopt_small.npz", "trajopt_7x20.npz", "quirks.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""Build the SURVEY 8(d) planar-arm trajectory problem through the sco_py object API.
+
+Test infrastructure shared by tests/golden/make_golden.py (which passes the
+REFERENCE's modules) and the parity tests (which pass sco_py_amd's mirror): the
+construction code is identical, only the module namespace differs.
+"""
+import numpy as np
+
+from oracle import arm_family as af
+
+
+def build_prob(mods, pr, analytic_jac=False):
+    """mods: namespace with Expr, AffExpr, QuadExpr, EqExpr, LEqExpr, BoundExpr,
+    Variable, OSQPVar, Prob.  pr: dict from oracle.arm_family.make_problem."""
+    d, T = pr["d"], pr["T"]
+    n_x = d * T
+    prob = mods.Prob()
+    atoms = np.empty((n_x, 1), dtype=object)
+    for t in range(T):
+        for j in range(d):
+            v = mods.OSQPVar("q%03d_%02d" % (t, j))     # lexicographic == creation order
+            prob.add_osqp_var(v)
+            atoms[t * d + j, 0] = v
+    traj = mods.Variable(atoms, pr["x0"].reshape(n_x, 1).copy())
+    prob.add_var(traj)
+
+    Q = np.zeros((n_x, n_x))
+    for t in range(T - 1):
+        for j in range(d):
+            a, b = t * d + j, (t + 1) * d + j
+            Q[a, a] += 2.0; Q[b, b] += 2.0; Q[a, b] -= 2.0; Q[b, a] -= 2.0
+    prob.add_obj_expr(mods.BoundExpr(mods.QuadExpr(Q, np.zeros((1, n_x)), np.zeros((1, 1))), traj))
+
+    pins = np.zeros((2 * d, n_x))
+    for j in range(d):
+        pins[j, j] = 1.0
+        pins[d + j, (T - 1) * d + j] = 1.0
+    rhs = np.concatenate([pr["start"], pr["goal"]]).reshape(-1, 1)
+    prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(mods.AffExpr(pins, np.zeros((2 * d, 1))), rhs), traj))
+
+    R = pr["K"] * pr["O"]
+    step_vars = []
+    for t in range(T):
+        sv = mods.Variable(atoms[t * d:(t + 1) * d, :], pr["x0"][t * d:(t + 1) * d].reshape(d, 1).copy())
+        step_vars.append(sv)
+
+        def f(x, pr=pr):
+            return af.arm_dist(x.ravel(), pr["link_len"], pr["point_link"], pr["point_frac"],
+                               pr["obstacles"]).reshape(-1, 1)
+
+        grad = None
+        if analytic_jac:
+            def grad(x, pr=pr):
+                return af.arm_dist_jac(x.ravel(), pr["link_len"], pr["point_link"], pr["point_frac"],
+                                       pr["obstacles"])
+        e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
+        prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(e, np.zeros((R, 1))), sv))
+    return prob, traj, step_vars, atoms
+
+
+def canonical_qp(P, q, A, l, u, n_x):
+    """Bring a QP assembled in the reference's (partly arbitrary) order
+    into the canonical order used by the oracle and the device path:
+      columns  x in name order (already so), then slack columns ordered by the
+               first row they appear in (ties: the -1 column before the +1 column);
+      rows     constraint rows as given, then the n bound rows in column order.
+    P, A dense arrays.  Returns (P, q, A, l, u, column permutation)."""
+    n = q.shape[0]
+    m_c = A.shape[0] - n
+    slack = list(range(n_x, n))
+
+    def key(c):
+        rows = np.nonzero(A[:m_c, c])[0]
+        first = rows[0] if rows.size else 1 << 30
+        sign = A[first, c] if rows.size else 0.0
+        return (first, 0 if sign < 0 else 1)
+
+    slack.sort(key=key)
+    perm = np.array(list(range(n_x)) + slack, dtype=np.int64)
+    A2 = A[:, perm]
+    P2 = P[np.ix_(perm, perm)]
+    P2 = np.triu(P2) + np.triu(P2.T, 1)       # keep it upper triangular after the permutation
+    q2 = q[perm]
+    brow = A2[m_c:, :]
+    order = np.argsort(np.argmax(brow != 0, axis=1), kind="stable")
+    rows = np.concatenate([np.arange(m_c), m_c + order])
+    return P2, q2, A2[rows, :], l[rows], u[rows], perm
