@@ -1,0 +1,61 @@
+"""Multi-GPU sharding of a batch of independent SCO problems.
+
+Each ``Prob`` of the reference is self-contained (all state hangs off ``self``,
+/root/reference/sco_py/sco_osqp/prob.py:48-86) and a caller solves them one after
+another, so a batch shards embarrassingly: one process per GPU, a contiguous
+slice of the batch per rank, NO data-path collective.  The only exchange is the
+final gather of per-problem results -- (merit f64, max_violation f64, success i32,
+sqp_iters i32) = 24 bytes per problem -- done with one all-gather (RCCL over xGMI
+when the backend is "nccl", gloo on CPU for tests).
+"""
+import numpy as np
+
+RESULT_DTYPE = np.dtype([("merit", "<f8"), ("max_violation", "<f8"), ("success", "<i4"), ("sqp_iters", "<i4")])
+
+
+def shard_range(total, rank, world):
+    """Contiguous slice [lo, hi) of `total` problems owned by `rank`; the first
+    `total % world` ranks take one extra problem."""
+    if world <= 0 or not (0 <= rank < world) or total < 0:
+        raise ValueError("bad shard request")
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def pack_results(merit, max_violation, success, sqp_iters):
+    rec = np.zeros(len(merit), dtype=RESULT_DTYPE)
+    rec["merit"] = merit; rec["max_violation"] = max_violation
+    rec["success"] = np.asarray(success, dtype=np.int32); rec["sqp_iters"] = sqp_iters
+    return rec
+
+
+def gather_results(local, total, device=None):
+    """All-gather the per-problem result records of every rank.
+
+    local: structured array (RESULT_DTYPE) of this rank's shard; total: batch size
+    over all ranks.  Returns the (total,) structured array on every rank.  With no
+    initialised process group (single process) it returns `local` unchanged."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        assert len(local) == total
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(total, rank, world)
+    assert len(local) == hi - lo, (len(local), lo, hi)
+    cap = -(-total // world)                       # shards padded to equal length
+    item = RESULT_DTYPE.itemsize
+    buf = np.zeros(cap * item, dtype=np.uint8)
+    buf[: len(local) * item] = np.frombuffer(local.tobytes(), dtype=np.uint8)
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    send = torch.from_numpy(buf).to(dev)
+    recv = torch.empty(world * cap * item, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    raw = recv.cpu().numpy()
+    out = np.zeros(total, dtype=RESULT_DTYPE)
+    for r in range(world):
+        rlo, rhi = shard_range(total, r, world)
+        chunk = raw[r * cap * item: r * cap * item + (rhi - rlo) * item]
+        out[rlo:rhi] = np.frombuffer(chunk.tobytes(), dtype=RESULT_DTYPE)
+    return out

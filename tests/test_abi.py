@@ -1,0 +1,83 @@
+"""The C-ABI shared library loads and exports every symbol include/sco_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sco_py_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "sco_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sco_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared_functions()
+    for must in ("sco_qp_create", "sco_qp_load", "sco_qp_set_bounds", "sco_qp_solve", "sco_sqp_create",
+                 "sco_sqp_load", "sco_sqp_solve", "sco_sqp_fetch", "sco_sqp_trace"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.lib_path())
+    for name in _declared_functions():
+        assert hasattr(lib, name), name
+
+
+def test_python_binding_table_matches_the_header():
+    assert sorted(_lib.ABI.keys()) == _declared_functions()
+    _lib.load()      # binds restype/argtypes for all of them
+
+
+def test_default_settings_are_the_reference_values():
+    s = _lib.default_qp_settings()
+    # osqp_utils.py:10-15 of the reference + OSQP 0.6 defaults
+    assert (s.rho, s.sigma, s.eps_abs, s.eps_rel, s.max_iter) == (0.1, 5e-10, 1e-6, 1e-9, 100000)
+    assert (s.alpha, s.check_termination, s.scaling) == (1.6, 25, 10)
+    p = _lib.default_sqp_params()
+    # solver.py:17-28
+    assert (p.improve_ratio_threshold, p.min_trust_region_size, p.min_approx_improve) == (0.25, 1e-4, 1e-8)
+    assert (p.trust_shrink_ratio, p.trust_expand_ratio, p.cnt_tolerance) == (0.1, 1.5, 1e-4)
+    assert (p.max_merit_coeff_increases, p.merit_coeff_increase_ratio) == (1, 10.0)
+    assert (p.initial_trust_region_size, p.initial_penalty_coeff) == (1.0, 1e3)
+    assert (p.compound_penalty, p.duplicate_rows) == (1, 1)
+
+
+def test_struct_layouts_match_the_c_side():
+    # sizes the C compiler gives the same declarations
+    assert ctypes.sizeof(_lib.QpSettings) == 7 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.SqpParams) == 9 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.TrajoptDesc) == 8 * 4
+
+
+def test_no_gpu_means_a_loud_failure_not_a_fallback():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    Pp = np.array([0, 1], dtype=np.int32); Pi = np.array([0], dtype=np.int32)
+    with pytest.raises(_lib.ScoHipError) as e:
+        _lib.BatchedQP(1, 1, 1, Pp, Pi, Pp, Pi)
+    assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+    from sco_py_amd.sco_osqp import osqp_utils
+    v = osqp_utils.OSQPVar("x")
+    with pytest.raises(_lib.ScoHipError):
+        osqp_utils.optimize([v], [], [osqp_utils.OSQPQuadraticObj(np.array([v]), np.array([v]), np.array([2.0]))],
+                            [osqp_utils.OSQPLinearObj(v, -4.0)], [])
+    from sco_py_amd import batch
+    with pytest.raises(_lib.ScoHipError):
+        batch.TrajOptBatch(2, 3, 4, 1, 1)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sco_py_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "osqp_ref" not in src.replace("oracle/osqp_ref.c", ""), f

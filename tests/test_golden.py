@@ -1,0 +1,127 @@
+"""Oracle and mirror API against vectors recorded from the REFERENCE's own code.
+
+tests/golden/*.npz were produced by tests/golden/make_golden.py, which ran the
+unmodified reference modules (sco_py.expr, sco_py.sco_osqp.*) in the build
+container with the oracle ADMM at the third-party ``osqp`` seam.  They hold, per
+problem, every QP the reference assembled (P, q, A, l, u in canonical order), its
+solution, the merit-function call log and the final answer.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import conftest as ct
+import trajopt_build as tb
+from oracle import arm_family as af
+from oracle import sco_ref as sr
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _compare_sequence(gold_qps, oracle_qps, tag):
+    assert len(gold_qps) == len(oracle_qps), (tag, len(gold_qps), len(oracle_qps))
+    for k, (a, b) in enumerate(zip(gold_qps, oracle_qps)):
+        P, q, A, l, u = ct.expand_weighted_qp(b)
+        ct.assert_qp_close(a, P, q, A, l, u, (tag, k))
+        assert a["status"] == b["status"] and a["iters"] == b["iters"], (tag, k)
+        assert np.abs(a["x"] - b["x"]).max() < 1e-9, (tag, k)
+
+
+def test_reference_suite_passed_under_the_harness():
+    import json
+    with open(os.path.join(GOLD, "kat_results.json")) as fh:
+        assert json.load(fh)["pytest_exit_code"] == 0
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_flat_oracle_reproduces_reference_qp_sequence_small(i):
+    g = np.load(os.path.join(GOLD, "trajopt_small.npz"))
+    pr = af.make_problem(i, d=3, T=6, K=2, O=2)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr), record_qps=True)
+    _compare_sequence(ct.load_golden_qps(g, "p%d_" % i), out.qps, "p%d" % i)
+    assert out.success == bool(g["p%d_success" % i])
+    assert np.abs(out.x - g["p%d_x" % i]).max() < 1e-9
+    assert abs(out.max_violation - float(g["p%d_max_violation" % i])) < 1e-9
+
+
+def test_flat_oracle_reproduces_reference_with_analytic_jacobian():
+    g = np.load(os.path.join(GOLD, "trajopt_small.npz"))
+    pr = af.make_problem(1, d=3, T=6, K=2, O=2)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr, analytic_jac=True), record_qps=True)
+    _compare_sequence(ct.load_golden_qps(g, "p1a_"), out.qps, "p1a")
+    assert np.abs(out.x - g["p1a_x"]).max() < 1e-9
+
+
+def test_flat_oracle_reproduces_reference_qp_sequence_7x20():
+    g = np.load(os.path.join(GOLD, "trajopt_7x20.npz"))
+    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(0)), record_qps=True)
+    gq = ct.load_golden_qps(g, "p0_", sparse=True)
+    # sizes of SURVEY.md 8: n = 340; m = 14 + k*200 + 340 for the k-th penalty QP (Q2)
+    assert [q["A"].shape for q in gq] == [(154, 140), (554, 340), (754, 340)]
+    _compare_sequence(gq, out.qps, "7x20")
+    assert out.success == bool(g["p0_success"]) and np.abs(out.x - g["p0_x"]).max() < 1e-9
+
+
+def test_merit_log_of_the_reference_matches_oracle_trace():
+    g = np.load(os.path.join(GOLD, "trajopt_small.npz"))
+    pr = af.make_problem(1, d=3, T=6, K=2, O=2)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr))
+    log = g["p1_merit_log"]          # rows: (is_approx, vectorize, penalty, value)
+    scalar_exact = log[(log[:, 0] == 0) & (log[:, 1] == 0)][:, 3]
+    scalar_model = log[(log[:, 0] == 1) & (log[:, 1] == 0)][:, 3]
+    tr = out.trace[1:]               # skip the projection row
+    # reference call order (solver.py:130-149): per SQP iteration one get_value (merit),
+    # then per trust-region trial one get_approx_value (model) and one get_value (new)
+    assert np.allclose(scalar_model, tr[:, 2], rtol=0, atol=1e-9)
+    expected, new_iter = [], True
+    for row in tr:
+        if new_iter:
+            expected.append(row[1])
+        expected.append(row[3])
+        new_iter = row[0] == sr.STEP_ACCEPT
+    assert np.allclose(scalar_exact, expected, rtol=0, atol=1e-9)
+
+
+def test_quirk_vectors_q1_q2():
+    g = np.load(os.path.join(GOLD, "quirks.npz"))
+    # Q1: slack costs 10, 100, 1000 over three update_obj(10.0) calls; Q2: one more row each time
+    assert np.allclose(g["q"], [[-2, 10, 10], [-2, 100, 100], [-2, 1000, 1000]])
+    assert g["A_shapes"].tolist() == [[4, 3], [5, 3], [6, 3]]
+
+
+@pytest.mark.parametrize("i", range(2))
+def test_mirror_api_reproduces_reference_qp_sequence(i, oracle_qp_backend):
+    """The product's host logic (expr/prob/solver mirror) builds the same QPs."""
+    g = np.load(os.path.join(GOLD, "trajopt_small.npz"))
+    pr = af.make_problem(i, d=3, T=6, K=2, O=2)
+    mods = ct.mirror_mods()
+    prob, traj, _, _ = tb.build_prob(mods, pr)
+    ok = mods.Solver().solve(prob, method="penalty_sqp")
+    gold = ct.load_golden_qps(g, "p%d_" % i)
+    assert len(gold) == len(oracle_qp_backend)
+    n_x = pr["d"] * pr["T"]
+    for k, (a, rec) in enumerate(zip(gold, oracle_qp_backend)):
+        P2, q2, A2, l2, u2, perm = tb.canonical_qp(rec["P"], rec["q"], rec["A"], rec["l"], rec["u"], n_x)
+        ct.assert_qp_close(a, P2, q2, A2, l2, u2, ("mirror", i, k))
+        assert a["status"] == rec["status"] and a["iters"] == rec["iters"]
+        assert np.abs(a["x"] - rec["x"][perm]).max() < 1e-9
+    assert ok == bool(g["p%d_success" % i])
+    assert np.abs(traj.get_value().ravel() - g["p%d_x" % i]).max() < 1e-9
+
+
+def test_mirror_quirks_match_reference(oracle_qp_backend):
+    g = np.load(os.path.join(GOLD, "quirks.npz"))
+    mods = ct.mirror_mods()
+    f = lambda x: np.array([[x[0, 0] ** 2]])
+    prob = mods.Prob()
+    v = mods.OSQPVar("x"); prob.add_osqp_var(v)
+    var = mods.Variable(np.array([[v]]), np.array([[1.0]])); prob.add_var(var)
+    prob.add_obj_expr(mods.BoundExpr(mods.QuadExpr(2 * np.eye(1), -2 * np.ones((1, 1)), np.zeros((1, 1))), var))
+    prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(mods.Expr(f), np.array([[4.0]])), var))
+    qs, shapes = [], []
+    for _ in range(3):
+        prob.convexify(); prob.update_obj(10.0); prob.optimize()
+        rec = oracle_qp_backend[-1]
+        qs.append(np.sort(rec["q"])); shapes.append(list(rec["A"].shape))
+    assert np.allclose(qs, g["q"]) and shapes == g["A_shapes"].tolist()

@@ -1,0 +1,311 @@
+"""Known-answer tests of the mirror API (sco_py_amd.expr / sco_py_amd.sco_osqp.*).
+
+Modelled on the reference's own suite (tests/sco_osqp/test_{expr,variable,prob,solver}.py):
+analytic optima checked with np.allclose.  Every test that solves a QP runs twice:
+``backend="oracle"`` (CPU, host logic only, oracle ADMM patched in at the seam) and
+``backend="hip"`` (marked gpu: the real path through the C ABI).
+"""
+import numpy as np
+import pytest
+
+import conftest as ct
+
+BACKENDS = ["oracle", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+    if request.param == "oracle":
+        request.getfixturevalue("oracle_qp_backend")
+    else:
+        request.getfixturevalue("gpu")
+    return request.param
+
+
+M = ct.mirror_mods()
+
+
+def _one_var_prob(value=None, **var_kw):
+    prob = M.Prob()
+    atom = M.OSQPVar("x", **var_kw)
+    prob.add_osqp_var(atom)
+    var = M.Variable(np.array([[atom]]), None if value is None else np.array([[value]]))
+    prob.add_var(var)
+    return prob, var, atom
+
+
+def _two_var_prob(x0):
+    prob = M.Prob()
+    a1, a2 = M.OSQPVar("x1"), M.OSQPVar("x2")
+    prob.add_osqp_var(a1); prob.add_osqp_var(a2)
+    var = M.Variable(np.array([[a1], [a2]]), x0)
+    prob.add_var(var)
+    return prob, var
+
+
+# ------------------------------------------------------------------ expr (host only)
+def test_numeric_and_analytic_derivatives_agree():
+    cases = [(lambda x: x, lambda x: np.array([[1.0]])),
+             (lambda x: x ** 2, lambda x: 2 * x),
+             (lambda x: x ** 3, lambda x: 3 * x ** 2)]
+    for f, df in cases:
+        for x0 in (1.0, 2.0, -1.0, 0.0):
+            x = np.array([[x0]])
+            assert np.allclose(M.Expr(f).grad(x), df(x))
+            assert np.allclose(M.Expr(f, df).grad(x, num_check=True), df(x))
+    with pytest.raises(Exception) as e:
+        M.Expr(cases[0][0]).grad(np.zeros((1, 1, 1)))
+    assert "Input shape not supported" in str(e.value)
+
+
+def test_convexify_degree_one_and_two():
+    f = lambda x: x ** 3
+    x = np.array([[2.0]])
+    aff = M.Expr(f).convexify(x, degree=1)
+    assert isinstance(aff, M.AffExpr)
+    assert np.allclose(aff.A, 12.0) and np.allclose(aff.b, 8.0 - 24.0) and np.allclose(aff.eval(x), 8.0)
+    quad = M.Expr(f).convexify(x, degree=2)
+    assert isinstance(quad, M.QuadExpr) and np.allclose(quad.Q, 12.0) and np.allclose(quad.eval(x), 8.0)
+    # negative curvature is shifted to zero (expr.py:145-148)
+    assert np.allclose(M.Expr(lambda x: -(x ** 2)).convexify(np.zeros((1, 1)), degree=2).Q, 0.0)
+
+
+def test_eval_is_memoised_on_the_rounded_point():
+    calls = []
+
+    def f(x):
+        calls.append(1)
+        return x * 2.0
+
+    e = M.Expr(f)
+    x = np.array([[1.0]])
+    first = e.eval(x); second = e.eval(x + 1e-8)       # rounds to the same 6-decimal key (Q3)
+    assert len(calls) == 1 and np.allclose(first, second)
+    assert e.eval(x + 1e-5) is not None and len(calls) == 2
+
+
+def test_comparison_expressions():
+    aff = M.AffExpr(np.eye(2), np.zeros((2, 1)))
+    x = np.array([[1.0], [2.0]])
+    assert M.EqExpr(aff, x.copy()).eval(x, tol=0.0)
+    assert not M.EqExpr(aff, x + 0.1).eval(x, tol=0.01)
+    assert M.LEqExpr(aff, x + 0.1).eval(x) and not M.LEqExpr(aff, x - 0.1).eval(x, tol=0.01)
+    val = np.array([[1.0]])
+    comp = M.CompExpr(M.Expr(lambda x: x), val)
+    val[0, 0] = 5.0
+    assert comp.val[0, 0] == 1.0                         # val is copied (expr.py:273)
+    for bad in (lambda: comp.eval(0), lambda: comp.convexify(0)):
+        with pytest.raises(NotImplementedError):
+            bad()
+    with pytest.raises(Exception):
+        comp.grad(0)
+    hinge = M.LEqExpr(M.Expr(lambda x: x ** 2), np.array([[1.0]])).convexify(np.array([[2.0]]))
+    assert isinstance(hinge, M.HingeExpr) and np.allclose(hinge.expr.A, 4.0) and np.allclose(hinge.expr.b, -5.0)
+    absx = M.EqExpr(M.Expr(lambda x: x ** 2), np.array([[1.0]])).convexify(np.array([[2.0]]))
+    assert isinstance(absx, M.AbsExpr) and np.allclose(absx.eval(np.array([[0.0]])), 5.0)
+
+
+def test_variable_copy_semantics_and_errors():
+    atom = M.OSQPVar("x")
+    atoms = np.array([[atom]])
+    val = np.array([[2.0]])
+    var = M.Variable(atoms, val)
+    val[0, 0] = 7.0
+    assert var.get_value()[0, 0] == 2.0
+    got = var.get_value(); got[0, 0] = 9.0
+    assert var.get_value()[0, 0] == 2.0
+    with pytest.raises(ValueError):
+        var.update()                                     # atom has no solver value yet
+    var.save(); var._value = np.array([[3.0]]); var.restore()
+    assert var.get_value()[0, 0] == 2.0
+    var.add_trust_region(0.5)
+    assert atom.get_lower_bound() == 1.5 and atom.get_upper_bound() == 2.5
+    with pytest.raises(AssertionError):
+        atom.set_lower_bound(1)                          # ints are rejected (Q19)
+
+
+def test_error_messages_of_the_lowering():
+    prob = M.Prob()
+    with pytest.raises(Exception) as e:
+        prob._add_osqp_objs_and_cnts_from_expr(M.BoundExpr(M.CompExpr(M.AffExpr(np.ones((1, 1)), np.zeros((1, 1))),
+                                                                     np.zeros((1, 1))), None))
+    assert "Comparison" in str(e.value)
+    with pytest.raises(Exception) as e:
+        prob._add_osqp_objs_and_cnts_from_expr(M.BoundExpr(lambda x: x, None))
+    assert "Expression cannot be converted" in str(e.value)
+    with pytest.raises(Exception) as e:
+        M.Solver().solve(prob, method="nope")
+    assert "not supported" in str(e.value)
+
+
+# ------------------------------------------------------------------ QP seam
+def test_optimize_seam_scalar_minimum(backend):
+    atom = M.OSQPVar("x")
+    var = M.Variable(np.array([[atom]]))
+    res, index = M.osqp_utils.optimize(
+        [atom], [var], [M.OSQPQuadraticObj(np.array([atom]), np.array([atom]), np.array([2.0]))],
+        [M.OSQPLinearObj(atom, -4.0)], [])
+    assert res.info.status_val in (1, 2)
+    M.osqp_utils.update_osqp_vars(index, res.x); var.update()
+    assert np.allclose(var.get_value(), 2.0)
+
+
+def test_optimize_seam_respects_trust_box(backend):
+    atom = M.OSQPVar("x")
+    var = M.Variable(np.array([[atom]]))
+    var._saved_value = np.array([[4.0]]); var.add_trust_region(1.0)
+    res, index = M.osqp_utils.optimize(
+        [atom], [var], [M.OSQPQuadraticObj(np.array([atom]), np.array([atom]), np.array([2.0]))],
+        [M.OSQPLinearObj(atom, -4.0)], [])
+    M.osqp_utils.update_osqp_vars(index, res.x); var.update()
+    assert np.allclose(var.get_value(), 3.0)
+
+
+def test_affine_objective_is_scaled_by_the_penalty_coefficient(backend):
+    # Q14: min x^2 - 2x (+ an affine -2x that update_obj(0) wipes out) -> 1.0
+    prob, var, _ = _one_var_prob()
+    prob.add_obj_expr(M.BoundExpr(M.QuadExpr(2 * np.eye(1), -2 * np.ones((1, 1)), np.zeros((1, 1))), var))
+    prob.add_obj_expr(M.BoundExpr(M.AffExpr(-2 * np.ones((1, 1)), np.zeros((1, 1))), var))
+    prob.update_obj(penalty_coeff=0)
+    assert prob.optimize()
+    assert np.allclose(var.get_value(), 1.0)
+
+
+def test_closest_feasible_point(backend):
+    for cnt_val, want in (([1.0, 1.0], [0.0, 0.0]), ([-1.0, 1.0], [-1.0, 0.0]), ([-1.0, -1.0], [-1.0, -1.0])):
+        prob, var = _two_var_prob(np.zeros((2, 1)))
+        cnt = M.LEqExpr(M.AffExpr(np.eye(2), np.zeros((2, 1))), np.array(cnt_val).reshape(2, 1))
+        prob.add_cnt_expr(M.BoundExpr(cnt, var))
+        assert prob.find_closest_feasible_point()
+        assert np.allclose(var.get_value().ravel(), want)
+    prob, var = _two_var_prob(np.zeros((2, 1)))
+    target = np.array([[5.0], [-10.0]])
+    prob.add_cnt_expr(M.BoundExpr(M.EqExpr(M.AffExpr(np.eye(2), np.zeros((2, 1))), target), var))
+    prob.find_closest_feasible_point()
+    assert np.allclose(var.get_value(), target)
+
+
+def test_hinge_and_abs_lowering(backend):
+    # min max(0, x + 1) s.t. x == -4 and s.t. x == 1
+    for pin in (-4.0, 1.0):
+        prob, var, _ = _one_var_prob()
+        prob._add_to_lin_objs_and_cnts_from_hinge_expr(M.HingeExpr(M.AffExpr(np.ones((1, 1)), np.ones((1, 1)))), var)
+        prob.add_cnt_expr(M.BoundExpr(M.EqExpr(M.AffExpr(np.ones((1, 1)), np.zeros((1, 1))), np.array([[pin]])), var))
+        prob.optimize(); var.update()
+        assert np.allclose(var.get_value(), pin)
+    # min |x + 1| with x <= -4 through the variable's own bound
+    prob, var, _ = _one_var_prob(ub=-4.0)
+    prob._add_to_lin_objs_and_cnts_from_abs_expr(M.AbsExpr(M.AffExpr(np.ones((1, 1)), np.ones((1, 1)))), var)
+    prob.optimize(add_convexified_terms=True); var.update()
+    assert np.allclose(var.get_value(), -4.0)
+
+
+def test_merit_values_of_an_l1_penalised_equality(backend):
+    # min x^2 s.t. x == 4: penalty 1 -> x = 0.5, merit 3.75; penalty 2 (compounded: Q1) -> x = 1, merit 7
+    prob, var, _ = _one_var_prob()
+    prob.add_obj_expr(M.BoundExpr(M.QuadExpr(2 * np.eye(1), np.zeros((1, 1)), np.zeros((1, 1))), var))
+    prob.add_cnt_expr(M.BoundExpr(M.EqExpr(M.Expr(lambda x: np.array([[x]]).reshape(1, 1)), np.array([[4.0]])), var))
+    prob.optimize()
+    prob.convexify(); prob.update_obj(penalty_coeff=1.0); prob.optimize()
+    assert np.allclose(var.get_value(), 0.5)
+    assert np.allclose(prob.get_value(1.0), 3.75) and np.allclose(prob.get_approx_value(1.0), 3.75)
+    prob.update_obj(penalty_coeff=2.0); prob.optimize()
+    assert np.allclose(var.get_value(), 1.0)
+    assert np.allclose(prob.get_value(2.0), 7.0) and np.allclose(prob.get_approx_value(2.0), 7.0)
+
+
+def test_model_and_true_merit_differ_for_a_nonlinear_constraint(backend):
+    # min x^2 - 2x + 1 s.t. x^2 == 4, convexified at x = 1, penalty 0.5 -> x = 1.5
+    prob, var, _ = _one_var_prob(1.0)
+    prob.add_obj_expr(M.BoundExpr(M.QuadExpr(2 * np.eye(1), -2 * np.ones((1, 1)), np.ones((1, 1))), var))
+    prob.add_cnt_expr(M.BoundExpr(M.EqExpr(M.QuadExpr(2 * np.eye(1), np.zeros((1, 1)), np.zeros((1, 1))),
+                                           np.array([[4.0]])), var))
+    prob.convexify(); prob.update_obj(penalty_coeff=0.5); prob.optimize()
+    assert np.allclose(var.get_value(), 1.5)
+    assert np.allclose(prob.get_approx_value(0.5), 1.25) and np.allclose(prob.get_value(0.5), 1.125)
+
+
+def test_max_constraint_violation():
+    prob = M.Prob()
+    dummy = M.Variable(np.zeros((1, 1)), np.zeros((1, 1)))
+    prob.add_cnt_expr(M.BoundExpr(M.LEqExpr(M.Expr(lambda x: np.array([[1.0, 3.0]])), np.array([[1.0, 1.0]])), dummy))
+    prob.add_cnt_expr(M.BoundExpr(M.EqExpr(M.Expr(lambda x: np.array([[0.0, 0.0]])), np.array([[1.0, 1.0]])), dummy))
+    assert np.allclose(prob.get_max_cnt_violation(), 2.0)
+
+
+# ------------------------------------------------------------------ end to end
+def _nlp(x0, x_true, f=None, g=None, h=None, Q=None, q=None, A_ineq=None, b_ineq=None):
+    """The reference's test_solver harness in our own words: quadratic + black-box
+    objective, one linear and one non-linear inequality, one non-linear equality."""
+    zero = lambda x: np.array([[0.0]])
+    f = f or zero; h = h or zero
+    g = g or (lambda x: np.array([[-1e5]]))
+    Q = np.zeros((2, 2)) if Q is None else Q
+    q = np.zeros((1, 2)) if q is None else q
+    A_ineq = np.zeros((1, 2)) if A_ineq is None else A_ineq
+    b_ineq = np.zeros((1, 1)) if b_ineq is None else b_ineq
+    prob, var = _two_var_prob(x0)
+    prob.add_obj_expr(M.BoundExpr(M.QuadExpr(Q, q, np.zeros((1, 1))), var))
+    prob.add_obj_expr(M.BoundExpr(M.Expr(f), var))
+    prob.add_cnt_expr(M.BoundExpr(M.LEqExpr(M.AffExpr(A_ineq, -b_ineq), np.zeros(b_ineq.shape)), var))
+    shape = g(np.zeros((2, 1))).shape
+    prob.add_cnt_expr(M.BoundExpr(M.LEqExpr(M.Expr(g), np.zeros(shape)), var))
+    prob.add_cnt_expr(M.BoundExpr(M.EqExpr(M.Expr(h), np.zeros(shape)), var))
+    solv = M.Solver()
+    solv.min_trust_region_size = 1e-5
+    solv.max_merit_coeff_increases = 5
+    solv.initial_penalty_coeff = 1.0
+    solv.solve(prob, method="penalty_sqp")
+    assert np.allclose(var.get_value(), x_true, atol=5e-4), (var.get_value().ravel(), np.ravel(x_true))
+    return solv
+
+
+def test_sqp_quadratic_objective_linear_inequality(backend):
+    _nlp(np.array([[1.0], [1.0]]), np.array([[1.5], [1.5]]),
+         f=lambda x: np.array([[x[0, 0] ** 2 + x[1, 0] ** 2]]), g=lambda x: np.array([[3 - x[0, 0] - x[1, 0]]]))
+
+
+def test_sqp_rosenbrock_like(backend):
+    _nlp(np.array([[-2.0], [1.0]]), np.array([[1.0], [1.0]]),
+         f=lambda x: np.array([[(x[1, 0] - x[0, 0] ** 2) ** 2 + (1 - x[0, 0]) ** 2]]),
+         g=lambda x: np.array([[-1.5 - x[1, 0]]]))
+
+
+def test_sqp_nonlinear_equality(backend):
+    _nlp(np.array([[10.0], [1.0]]), np.array([[1.0], [1.0]]),
+         f=lambda x: np.array([[(1 - x[0, 0]) ** 2]]), h=lambda x: np.array([[10 * (x[1, 0] - x[0, 0] ** 2)]]))
+
+
+def test_sqp_log_objective_quartic_equality(backend):
+    _nlp(np.array([[2.0], [2.0]]), np.array([[0.0], [np.sqrt(3)]]),
+         f=lambda x: np.array([[np.log(1 + x[0, 0] ** 2) - x[1, 0]]]),
+         h=lambda x: np.array([[(1 + x[0, 0] ** 2) ** 2 + x[1, 0] ** 2 - 4]]))
+
+
+def test_sqp_hexagon_lp(backend):
+    ang = (np.arange(1, 7) * 2 * np.pi / 6).reshape(6, 1)
+    A = np.hstack((np.cos(ang), np.sin(ang)))
+    q = -np.array([[np.cos(np.pi / 6), np.sin(np.pi / 6)]])
+    _nlp(np.zeros((2, 1)), np.array([[1.0], [np.tan(np.pi / 6)]]), q=q, A_ineq=A, b_ineq=np.ones((6, 1)))
+    _nlp(np.zeros((2, 1)), np.array([[1.0], [np.tan(np.pi / 6)]]), Q=0.1 * np.eye(2), q=q,
+         g=lambda x: 0.01 * (A.dot(x) - np.ones((6, 1))))
+
+
+def test_sqp_mixed_constraints_and_nonconvex_set(backend):
+    _nlp(np.zeros((2, 1)), np.array([[2.0], [1.0]]),
+         f=lambda x: np.array([[x[0, 0] ** 4 + x[1, 0] ** 4]]),
+         g=lambda x: np.array([[3 - x[0, 0] - x[1, 0]]]), h=lambda x: np.array([[x[0, 0] - 2 * x[1, 0]]]))
+    g = lambda x: np.vstack((x[0, 0] ** 2 + x[1, 0] ** 2 - 4,
+                             -((x[0, 0] - 1) ** 2 + (x[1, 0] - 1) ** 2 - 0.25),
+                             -((x[0, 0] + 1) ** 2 + (x[1, 0] - 1) ** 2 - 0.25),
+                             -((x[0, 0]) ** 2 + 7 * (x[1, 0] + 1 - x[0, 0] ** 2 / 2) ** 2 - 0.8)))
+    _nlp(np.array([[5.0], [5.0]]), np.zeros((2, 1)), g=g, Q=np.eye(2))
+
+
+def test_tol_argument_overwrites_thresholds(backend):
+    prob, var, _ = _one_var_prob(0.0)
+    prob.add_obj_expr(M.BoundExpr(M.QuadExpr(2 * np.eye(1), -2 * np.ones((1, 1)), np.zeros((1, 1))), var))
+    s = M.Solver()
+    assert s.solve(prob, method="penalty_sqp", tol=1e-3) in (True, False)
+    assert (s.min_trust_region_size, s.min_approx_improve, s.cnt_tolerance) == (1e-3, 1e-3, 1e-3)   # Q8
+    assert np.allclose(var.get_value(), 1.0, atol=1e-3)

@@ -1,0 +1,157 @@
+"""HIP QP kernels (through the C ABI) against the oracle ADMM: x within 1e-6 (the
+north_star tolerance; in practice ~1e-13), identical status and iteration counts."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import osqp_ref as o
+from sco_py_amd import _lib
+from test_qp_plan import penalty_qp
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6          # abs tolerance stated by BASELINE.json north_star
+
+
+def _stack(probs):
+    P0, q0, A0, l0, u0 = probs[0]
+    n, m = len(q0), len(l0)
+    Pu = sp.triu(sp.csc_matrix(P0), format="csc"); Pu.sort_indices()
+    Ac = sp.csc_matrix((A0 != 0).astype(float)); Ac.sort_indices()
+    pr, pc = Pu.indices, np.repeat(np.arange(n), np.diff(Pu.indptr))
+    ar, ac = Ac.indices, np.repeat(np.arange(n), np.diff(Ac.indptr))
+    Pval = np.stack([p[0][pr, pc] for p in probs]); Aval = np.stack([p[2][ar, ac] for p in probs])
+    q = np.stack([p[1] for p in probs]); l = np.stack([p[3] for p in probs]); u = np.stack([p[4] for p in probs])
+    return n, m, Pu.indptr, Pu.indices, Ac.indptr, Ac.indices, Pval, q, Aval, l, u
+
+
+def _check(probs, w=None, settings=None, check=None, **okw):
+    n, m, Pp, Pi, Ap, Ai, Pval, q, Aval, l, u = _stack(probs)
+    qp = _lib.BatchedQP(len(probs), n, m, Pp, Pi, Ap, Ai)
+    try:
+        qp.load(Pval, q, Aval, l, u, w)
+        x, y, st, it, res = qp.solve(settings)
+        info = qp.info()
+    finally:
+        qp.close()
+    for b in (range(len(probs)) if check is None else check):
+        ref = o.solve(*probs[b], w=None if w is None else w[b], **okw)
+        assert st[b] == ref.info.status_val, (b, st[b], ref.info.status_val)
+        assert it[b] == ref.info.iter, (b, it[b], ref.info.iter)
+        if ref.info.status_val in (1, 2, -2):
+            assert np.abs(x[b] - ref.x).max() < TOL, (b, np.abs(x[b] - ref.x).max())
+            assert np.abs(y[b] - ref.y).max() < 1e-5 * (1 + np.abs(ref.y).max())
+            assert abs(res[b, 0] - ref.info.pri_res) < 1e-9 and abs(res[b, 1] - ref.info.dua_res) < 1e-9
+    return info, x, st, it
+
+
+def test_scalar_known_answers(gpu):
+    P = np.array([[2.0]]); A = np.array([[1.0]])
+    probs = [(P, np.array([-4.0]), A, np.array([-np.inf]), np.array([np.inf])),
+             (P, np.array([-4.0]), A, np.array([3.0]), np.array([5.0]))]
+    info, x, st, it = _check(probs)
+    assert np.allclose(x[:, 0], [2.0, 3.0], atol=1e-5) and info["n_core"] == 0    # the only variable is eliminated
+
+
+@pytest.mark.parametrize("shape,B", [((3, 1, 1), 3), ((5, 3, 4), 8), ((6, 2, 3), 5)])
+def test_penalty_qps_match_oracle(gpu, shape, B):
+    rng = np.random.default_rng(100 + B)
+    probs = [penalty_qp(rng, *shape) for _ in range(B)]
+    info, *_ = _check(probs)
+    T, d, r = shape
+    assert info["n_elim"] == T * r and info["n_core"] == T * d
+
+
+def test_row_multiplicities_match_physically_duplicated_rows(gpu):
+    rng = np.random.default_rng(5)
+    T, d, r = 5, 3, 4
+    probs = [penalty_qp(rng, T, d, r) for _ in range(6)]
+    m = len(probs[0][3])
+    w = np.ones((6, m), dtype=np.int32)
+    w[:, d:d + T * r] = rng.integers(1, 6, size=(6, 1))
+    _check(probs, w=w)            # oracle runs with expand_dups=1: rows physically repeated
+
+
+def test_7x20_shape_batch(gpu):
+    rng = np.random.default_rng(9)
+    probs = [penalty_qp(rng, 20, 7, 10) for _ in range(32)]
+    m = len(probs[0][3])
+    w = np.ones((32, m), dtype=np.int32); w[:, 7:7 + 200] = 2
+    info, *_ = _check(probs, w=w, check=range(6))
+    assert (info["n_elim"], info["n_core"]) == (200, 140)      # reduced SPD system of order n_x
+    assert info["lds_admm"] < 80 * 1024                         # two workgroups per CU
+
+
+def test_elimination_can_be_disabled_and_agrees(gpu, monkeypatch):
+    rng = np.random.default_rng(11)
+    probs = [penalty_qp(rng, 4, 2, 3) for _ in range(4)]
+    monkeypatch.setenv("SCO_QP_NO_ELIM", "1")
+    info, x0, *_ = _check(probs)
+    assert info["n_elim"] == 0
+    monkeypatch.delenv("SCO_QP_NO_ELIM")
+    info, x1, *_ = _check(probs)
+    assert info["n_elim"] > 0 and np.abs(x0 - x1).max() < 1e-9
+
+
+def test_infeasible_and_unbounded_statuses(gpu):
+    A = np.array([[1.0], [1.0]])
+    prim = (np.array([[1.0]]), np.array([0.0]), A, np.array([1.0, -np.inf]), np.array([np.inf, 0.0]))
+    _, _, st, _ = _check([prim])
+    assert st[0] == -3
+    dual = (np.array([[0.0]]), np.array([1.0]), np.array([[1.0]]), np.array([-np.inf]), np.array([0.0]))
+    _, _, st, _ = _check([dual])
+    assert st[0] == -4
+
+
+def test_max_iter_and_settings_are_honoured(gpu):
+    rng = np.random.default_rng(3)
+    probs = [penalty_qp(rng, 5, 3, 4) for _ in range(3)]
+    s = _lib.default_qp_settings(max_iter=40)
+    _, _, st, it = _check(probs, settings=s, max_iter=40)
+    assert np.all(st == -2) and np.all(it == 40)
+    s = _lib.default_qp_settings(rho=0.5, sigma=1e-6, eps_abs=1e-5, eps_rel=1e-5, alpha=1.2, check_termination=10)
+    _check(probs, settings=s, rho=0.5, sigma=1e-6, eps_abs=1e-5, eps_rel=1e-5, alpha=1.2, check_termination=10)
+
+
+def test_set_bounds_changes_only_the_box(gpu):
+    rng = np.random.default_rng(21)
+    probs = [penalty_qp(rng, 5, 3, 4) for _ in range(2)]
+    n, m, Pp, Pi, Ap, Ai, Pval, q, Aval, l, u = _stack(probs)
+    qp = _lib.BatchedQP(2, n, m, Pp, Pi, Ap, Ai)
+    qp.load(Pval, q, Aval, l, u)
+    qp.solve()
+    l2, u2 = l.copy(), u.copy()
+    box = slice(m - n, m - n + 15)
+    mid = 0.5 * (l[:, box] + u[:, box]); l2[:, box] = mid - 0.1; u2[:, box] = mid + 0.1     # shrunk trust region
+    qp.set_bounds(l2, u2)
+    x, y, st, it, _ = qp.solve()
+    qp.close()
+    for b in range(2):
+        ref = o.solve(probs[b][0], probs[b][1], probs[b][2], l2[b], u2[b])
+        assert (st[b], it[b]) == (ref.info.status_val, ref.info.iter) and np.abs(x[b] - ref.x).max() < TOL
+
+
+def test_api_misuse_is_reported(gpu):
+    Pp = np.array([0, 1], dtype=np.int32); Pi = np.array([0], dtype=np.int32)
+    qp = _lib.BatchedQP(1, 1, 1, Pp, Pi, Pp, Pi)
+    with pytest.raises(_lib.ScoHipError) as e:
+        qp.solve()                                   # solve before load
+    assert e.value.code == -4
+    qp.close()
+    bad = np.array([0, 2], dtype=np.int32)
+    with pytest.raises(_lib.ScoHipError) as e:
+        _lib.BatchedQP(1, 1, 1, Pp, Pi, bad, np.array([0, 0], dtype=np.int32))   # repeated row index
+    assert e.value.code == -1
+
+
+def test_results_are_run_to_run_deterministic(gpu):
+    rng = np.random.default_rng(33)
+    probs = [penalty_qp(rng, 6, 3, 4) for _ in range(16)]
+    n, m, Pp, Pi, Ap, Ai, Pval, q, Aval, l, u = _stack(probs)
+    outs = []
+    for _ in range(2):
+        qp = _lib.BatchedQP(16, n, m, Pp, Pi, Ap, Ai)
+        qp.load(Pval, q, Aval, l, u)
+        outs.append(qp.solve()); qp.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][3], outs[1][3])

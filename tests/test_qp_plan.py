@@ -1,0 +1,108 @@
+"""Host-side symbolic analysis (csrc/qp_plan.cpp) checked without a GPU: the real
+C++ plans drive a NumPy rendition of the device phases (tests/qp_emulator.py) and
+the result must equal the oracle's."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import qp_emulator as E
+from oracle import osqp_ref as o
+from sco_py_amd import _lib
+
+
+def penalty_qp(rng, T, d, r, feasible_pins=True):
+    nx = T * d; ns = T * r; n = nx + ns
+    Q = np.zeros((n, n))
+    for t in range(T - 1):
+        for j in range(d):
+            a, b = t * d + j, (t + 1) * d + j
+            Q[a, a] += 2; Q[b, b] += 2; Q[a, b] -= 2; Q[b, a] -= 2
+    x0 = rng.standard_normal(nx) * 0.3
+    rows, lo, hi = [], [], []
+    for j in range(d):
+        e = np.zeros(n); e[j] = 1; rows.append(e)
+        v = x0[j] + 0.1 * rng.standard_normal(); lo.append(v); hi.append(v)
+    for t in range(T):
+        for k in range(r):
+            e = np.zeros(n); e[t * d:(t + 1) * d] = rng.standard_normal(d); e[nx + t * r + k] = -1
+            rows.append(e); lo.append(-np.inf); hi.append(rng.standard_normal())
+    for j in range(n):
+        e = np.zeros(n); e[j] = 1; rows.append(e)
+        if j < nx:
+            lo.append(x0[j] - 1); hi.append(x0[j] + 1)
+        else:
+            lo.append(0.0); hi.append(np.inf)
+    q = np.zeros(n); q[nx:] = 10.0
+    return Q, q, np.array(rows), np.array(lo), np.array(hi)
+
+
+def _patterns(P, A):
+    Pu = sp.triu(sp.csc_matrix(P), format="csc"); Pu.sort_indices()
+    Ac = sp.csc_matrix(A); Ac.sort_indices()
+    return (Pu.indptr.astype(np.int32), Pu.indices.astype(np.int32), Pu.data,
+            Ac.indptr.astype(np.int32), Ac.indices.astype(np.int32), Ac.data)
+
+
+@pytest.mark.parametrize("shape", [(5, 3, 4), (4, 2, 3), (3, 1, 1)])
+@pytest.mark.parametrize("elim", [1, 0])
+def test_plans_reproduce_the_oracle(shape, elim):
+    lib = _lib.load()
+    rng = np.random.default_rng(sum(shape))
+    T, d, r = shape
+    P, q, A, l, u = penalty_qp(rng, T, d, r)
+    n, m = len(q), len(l)
+    Pp, Pi, Pv, Ap, Ai, Av = _patterns(P, A)
+    w = np.ones(m, dtype=np.int32); w[d:d + T * r] = 3
+    ref = o.solve(P, q, A, l, u, w=w)
+    plan = E.get_plan(lib, n, m, Pp, Pi, Ap, Ai, elim)
+    if elim:
+        assert plan["n_e"] == T * r and plan["n_c"] == T * d      # slacks eliminated, x in the core
+        assert plan["ncpl"] == T * r * d
+    else:
+        assert plan["n_e"] == 0 and plan["n_c"] == n
+    x, y, st, it = E.emulate(plan, Pv, q, Av, l, u, w=w)
+    assert (st, it) == (ref.info.status_val, ref.info.iter)
+    assert np.abs(x - ref.x).max() < 1e-11 and np.abs(y - ref.y).max() < 1e-9
+
+
+def test_eliminated_set_is_independent_and_core_is_complete():
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    # abs-penalty shaped rows: p and n slacks share a row, so only one of each pair may be eliminated
+    n_x, r = 4, 3
+    n = n_x + 2 * r
+    rows = []
+    for i in range(r):
+        e = np.zeros(n); e[:n_x] = rng.standard_normal(n_x); e[n_x + i] = -1; e[n_x + r + i] = 1
+        rows.append(e)
+    A = np.vstack([np.array(rows), np.eye(n)])
+    P = np.zeros((n, n)); P[:n_x, :n_x] = np.eye(n_x) + 0.1
+    Pp, Pi, Pv, Ap, Ai, Av = _patterns(P, A)
+    plan = E.get_plan(lib, n, A.shape[0], Pp, Pi, Ap, Ai, 1)
+    assert plan["n_e"] == r and plan["n_c"] == n - r
+    elim = set(plan["elim_var"].tolist())
+    for i in range(r):
+        assert len(elim & {n_x + i, n_x + r + i}) == 1
+    # solving with this plan still matches the oracle
+    q = np.concatenate([rng.standard_normal(n_x), np.full(2 * r, 5.0)])
+    l = np.concatenate([np.ones(r), np.full(n_x, -2.0), np.zeros(2 * r)])
+    u = np.concatenate([np.ones(r), np.full(n_x, 2.0), np.full(2 * r, np.inf)])
+    ref = o.solve(P, q, A, l, u)
+    x, y, st, it = E.emulate(plan, Pv, q, Av, l, u)
+    assert (st, it) == (ref.info.status_val, ref.info.iter) and np.abs(x - ref.x).max() < 1e-10
+
+
+def test_malformed_patterns_are_rejected():
+    lib = _lib.load()
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    sizes = np.zeros(16, dtype=np.int32)
+    Pp = np.array([0, 1, 2], dtype=np.int32); Pi = np.array([0, 1], dtype=np.int32)
+    Ap = np.array([0, 2, 3], dtype=np.int32)
+    bad_rows = np.array([1, 0, 0], dtype=np.int32)           # not increasing inside column 0
+    assert lib.sco_debug_plan_build(2, 2, ip(Pp), ip(Pi), ip(Ap), ip(bad_rows), 1, ip(sizes)) != 0
+    lower = np.array([1, 1], dtype=np.int32)                  # P entry below the diagonal
+    ok_rows = np.array([0, 1, 0], dtype=np.int32)
+    assert lib.sco_debug_plan_build(2, 2, ip(Pp), ip(lower), ip(Ap), ip(ok_rows), 1, ip(sizes)) != 0
+    assert lib.sco_debug_plan_build(2, 2, ip(Pp), ip(Pi), ip(Ap), ip(ok_rows), 1, ip(sizes)) == 0

@@ -1,0 +1,127 @@
+"""Device-resident penalty-SQP loop (sco_sqp_* through the C ABI) against the flat
+oracle and against the golden vectors recorded from the reference's own code."""
+import os
+
+import numpy as np
+import pytest
+
+import conftest as ct
+from oracle import arm_family as af
+from oracle import sco_ref as sr
+from sco_py_amd import _lib, batch as sb
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-6          # abs, BASELINE.json north_star
+SMALL = dict(d=3, T=6, K=2, O=2)
+
+
+def _compare(res, probs, which, oracle_params=None, analytic=False):
+    for b in which:
+        ref = sr.penalty_sqp(sr.trajopt_flat(probs[b], analytic_jac=analytic), oracle_params, emulate_memo=False)
+        tr = res.trace[b]
+        assert tr.shape == ref.trace.shape, (b, tr.shape, ref.trace.shape)
+        assert np.array_equal(tr[:, 0], ref.trace[:, 0]), (b, tr[:, 0], ref.trace[:, 0])      # same decisions
+        assert np.array_equal(tr[:, 6:8], ref.trace[:, 6:8]), b                                # QP status + iterations
+        assert np.abs(tr[:, 1:4] - ref.trace[:, 1:4]).max() < 1e-7 * (1 + np.abs(ref.trace[:, 1:4]).max()), b
+        assert np.array_equal(tr[:, 4:6], ref.trace[:, 4:6]), b                                # trust, penalty
+        assert np.abs(res.x[b] - ref.x).max() < TOL, (b, np.abs(res.x[b] - ref.x).max())
+        assert bool(res.success[b]) == ref.success
+        assert (res.sqp_iters[b], res.qp_solves[b], res.admm_iters[b]) == (ref.sqp_iters, ref.qp_solves, ref.admm_iters)
+        assert abs(res.max_violation[b] - ref.max_violation) < 1e-7
+
+
+def test_small_batch_parity_mode(gpu):
+    arrays, probs = af.make_batch(8, **SMALL)
+    _compare(sb.solve_batch(arrays), probs, range(8))
+
+
+def test_small_batch_intended_mode(gpu):
+    arrays, probs = af.make_batch(6, **SMALL)
+    p = _lib.default_sqp_params(compound_penalty=0, duplicate_rows=0)
+    _compare(sb.solve_batch(arrays, params=p), probs, range(6),
+             sr.SolverParams(compound_penalty=False, duplicate_rows=False))
+
+
+def test_penalty_escalation_and_custom_knobs(gpu):
+    arrays, probs = af.make_batch(6, first=8, **SMALL)
+    kw = dict(initial_penalty_coeff=10.0, max_merit_coeff_increases=3, initial_trust_region_size=0.5,
+              min_trust_region_size=1e-3, improve_ratio_threshold=0.2)
+    p = _lib.default_sqp_params(**kw)
+    _compare(sb.solve_batch(arrays, params=p), probs, range(6), sr.SolverParams(**kw))
+
+
+def test_analytic_jacobian_path(gpu):
+    arrays, probs = af.make_batch(4, **SMALL)
+    _compare(sb.solve_batch(arrays, analytic_jac=True), probs, range(4), analytic=True)
+
+
+def test_matches_reference_golden_run_small(gpu):
+    """x, success and the per-QP status/iterations recorded from the REFERENCE's own
+    modules (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(GOLD, "trajopt_small.npz"))
+    arrays, _ = af.make_batch(4, **SMALL)
+    res = sb.solve_batch(arrays)
+    for i in range(4):
+        gq = ct.load_golden_qps(g, "p%d_" % i)
+        assert np.abs(res.x[i] - g["p%d_x" % i]).max() < TOL
+        assert bool(res.success[i]) == bool(g["p%d_success" % i])
+        assert [int(v) for v in res.trace[i][:, 6]] == [q["status"] for q in gq]
+        assert [int(v) for v in res.trace[i][:, 7]] == [q["iters"] for q in gq]
+
+
+def test_matches_reference_golden_run_7x20(gpu):
+    g = np.load(os.path.join(GOLD, "trajopt_7x20.npz"))
+    arrays, _ = af.make_batch(2)
+    res = sb.solve_batch(arrays)
+    gq = ct.load_golden_qps(g, "p0_", sparse=True)
+    assert np.abs(res.x[0] - g["p0_x"]).max() < TOL
+    assert bool(res.success[0]) == bool(g["p0_success"])
+    assert [int(v) for v in res.trace[0][:, 7]] == [q["iters"] for q in gq]
+    assert abs(res.max_violation[0] - float(g["p0_max_violation"])) < 1e-7
+
+
+def test_7x20_batch_against_oracle(gpu):
+    arrays, probs = af.make_batch(16)
+    _compare(sb.solve_batch(arrays), probs, range(3))
+
+
+def test_repeated_solves_restart_from_the_loaded_state_and_are_deterministic(gpu):
+    arrays, _ = af.make_batch(8, **SMALL)
+    with sb.TrajOptBatch(8, 3, 6, 2, 2) as tb:
+        tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                arrays["point_frac"], arrays["obstacles"])
+        tb.solve(); a = tb.fetch()
+        tb.solve(); b = tb.fetch()
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.admm_iters, b.admm_iters)
+
+
+def test_full_size_batch_properties(gpu):
+    """BASELINE configs[2] size (1024 problems): size-independent properties."""
+    B = 1024
+    arrays, _ = af.make_batch(B)
+    res = sb.solve_batch(arrays)
+    d, T = 7, 20
+    x = res.x.reshape(B, T, d)
+    # linear constraints hold to QP accuracy at every returned point
+    assert np.abs(x[:, 0, :] - arrays["start"]).max() < 1e-4 and np.abs(x[:, -1, :] - arrays["goal"]).max() < 1e-4
+    # success implies the non-linear constraints are within tolerance (solver.py:94-101)
+    assert np.all(res.max_violation[res.success] <= 1e-4)
+    # the reported violation is the violation of the reported trajectory
+    for b in range(0, B, 97):
+        v = max(np.max(af.arm_dist(x[b, t], arrays["link_len"][b], arrays["point_link"], arrays["point_frac"],
+                                   arrays["obstacles"][b])) for t in range(T))
+        assert abs(max(v, 0.0) - res.max_violation[b]) < 1e-9
+    # every problem did at least the projection and one SQP iteration; counters are consistent
+    assert np.all(res.qp_solves >= 2) and np.all(res.sqp_iters >= 1) and np.all(res.qp_solves > res.sqp_iters - 1)
+    assert np.all(np.isfinite(res.x))
+
+
+def test_descriptor_validation(gpu):
+    with pytest.raises(_lib.ScoHipError) as e:
+        sb.TrajOptBatch(0, 3, 6, 2, 2)
+    assert e.value.code == -1
+    with sb.TrajOptBatch(2, 3, 6, 2, 2) as tb:
+        with pytest.raises(_lib.ScoHipError) as e:
+            tb.solve()                     # solve before load
+        assert e.value.code == -4
