@@ -47,9 +47,35 @@ struct QpDev {
   const int *active;
 };
 
+// ---- fast ADMM path (sco_admm_fast.hip) ------------------------------------
+// Sliced-ELL image of a sparse operator: slices of 64 items, entry k of item
+// (slice s, lane l) at base[s] + 64 k + l; idx = 16-bit index of the gathered
+// vector element, src = position of the value in the flat per-problem array.
+struct SellHost {
+  int nitems = 0, total = 0;
+  std::vector<int> base, width, src;
+  std::vector<unsigned short> idx;
+};
+struct SellDev { const int *base, *width, *src; const unsigned short *idx; int total; };
+struct FastHost { SellHost Ac, Ar, Ca, Ce; int TR = 1; size_t lds_doubles = 0, lds_bytes = 0; };
+struct FastDev { SellDev Ac, Ar, Ca, Ce; };
+
+struct AdmmArgs {
+  QpDev d;
+  double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  int max_iter, check;
+};
+
+bool fast_plan_build(const QpPlan &pl, FastHost &fh);
+int fast_upload(const FastHost &fh, std::vector<void *> &allocs, FastDev &fd);
+int fast_launch(const AdmmArgs &a, const FastHost &fh, const FastDev &fd, hipStream_t st);
+
 struct sco_qp {
   int device = 0;
   QpPlan plan;
+  FastHost fast;
+  FastDev fastd{};
+  bool use_fast = false;
   QpDev d{};
   const int *Pp_dev = nullptr, *Pi_dev = nullptr;   // device copies of the P triu pattern
   hipStream_t stream = nullptr;

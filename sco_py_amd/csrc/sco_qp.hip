@@ -297,12 +297,6 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
 // --------------------------------------------------------------------------
 // ADMM kernel
 // --------------------------------------------------------------------------
-struct AdmmArgs {
-  QpDev d;
-  double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
-  int max_iter, check;
-};
-
 struct AdmmLds {
   double *As, *qs, *ls, *us, *rho, *x, *z, *y, *t, *xt, *ge, *r, *xc, *kinv, *cpl, *sdy, *sdx, *red;
   int *w;
@@ -621,6 +615,14 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
 #undef AL
   SCO_HIP(hipFuncSetAttribute((const void *)qp_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+  {
+    const char *no_fast = getenv("SCO_QP_NO_FAST");
+    if (!(no_fast && no_fast[0] == '1') && fast_plan_build(pl, qp->fast)) {
+      int r_ = fast_upload(qp->fast, qp->allocs, qp->fastd);
+      if (r_) return r_;
+      qp->use_fast = true;
+    }
+  }
   *out = qp;
   return SCO_OK;
 }
@@ -687,8 +689,13 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
   SCO_HIP(hipGetLastError());
   SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
   if (mid) SCO_HIP(hipEventRecord(mid, qp->stream));
-  hipLaunchKernelGGL(qp_admm_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_admm, qp->stream, aa);
-  SCO_HIP(hipGetLastError());
+  if (qp->use_fast) {
+    int r_ = fast_launch(aa, qp->fast, qp->fastd, qp->stream);
+    if (r_) return r_;
+  } else {
+    hipLaunchKernelGGL(qp_admm_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_admm, qp->stream, aa);
+    SCO_HIP(hipGetLastError());
+  }
   SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
   return SCO_OK;
 }
@@ -719,7 +726,8 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
 
 extern "C" int sco_qp_info(const sco_qp *qp, int info[4]) {
   if (!qp || !info) return SCO_ERR_ARG;
-  info[0] = qp->plan.n_e; info[1] = qp->plan.n_c; info[2] = (int)qp->lds_admm; info[3] = qp->plan.ncpl;
+  info[0] = qp->plan.n_e; info[1] = qp->plan.n_c;
+  info[2] = (int)(qp->use_fast ? qp->fast.lds_bytes : qp->lds_admm); info[3] = qp->plan.ncpl;
   return SCO_OK;
 }
 
