@@ -69,12 +69,16 @@ bool fast_plan_build(const QpPlan &pl, FastHost &fh) {
   }
   build_sell(pl.n_e, pl.e_ptr, pl.pair_core, ident, fh.Ce);            // K_CE by eliminated: idx = core index
   fh.TR = std::max(1, (pl.n_c + GI - 1) / GI);
+  fh.TC = 2 * fh.TR;
+  if (fh.TR == 5 && pl.n_c <= GJ * 9) fh.TC = 9;        // 140-order core: 5 x 9 tile
+  auto maxw = [](const SellHost &h) { int w = 0; for (int x : h.width) w = std::max(w, x); return w; };
+  fh.capped = maxw(fh.Ac) <= 12 && maxw(fh.Ar) <= 8 && maxw(fh.Ca) <= 12 && maxw(fh.Ce) <= 8;
   const int ps = GI * fh.TR + 1;
   const size_t scratch = std::max<size_t>((size_t)GJ * ps, 2 * (size_t)pl.n + 2 * (size_t)pl.m);
   fh.lds_doubles = (size_t)fh.Ac.total + fh.Ar.total + fh.Ca.total + fh.Ce.total +   // values
-                   pl.n + pl.m + pl.n_e + (size_t)GJ * 2 * fh.TR + (size_t)GI * fh.TR +  // xt, t, ge, r, xc
+                   pl.n + pl.m + pl.n_e + (size_t)GJ * fh.TC + (size_t)GI * fh.TR +  // xt, t, ge, r, xc
                    scratch + FW * 8;
-  fh.lds_bytes = fh.lds_doubles * 8 + 2 * ((size_t)fh.Ac.total + fh.Ar.total + fh.Ca.total + fh.Ce.total + 8);
+  fh.lds_bytes = fh.lds_doubles * 8 + 2 * ((size_t)fh.Ac.total + fh.Ar.total + fh.Ca.total + fh.Ce.total + 8 + 64 * 12);
   return fh.lds_bytes <= 160 * 1024;
 }
 
@@ -113,19 +117,39 @@ __device__ __forceinline__ void fblock_reduce(double (&v)[NR], double *red) {
 
 struct SellLds { const double *V; const unsigned short *I; int off, width; };
 
-// sum_k V[k] * vec[I[k]] over the calling thread's item (off = base[slice] + lane)
+// sum_k V[k] * vec[I[k]] over the calling thread's item (off = base[slice] + lane).
+// CAP > 0: the trip count is a compile-time bound, every index and value load is
+// issued before the first gather, so a dot product costs two LDS round trips
+// instead of two per entry (entries past `width` are read -- they stay inside the
+// LDS allocation -- and masked).  CAP == 0: plain loop for patterns wider than the
+// instantiated caps.  Summation order is k = 0, 1, ... in both forms.
+template <int CAP>
 __device__ __forceinline__ double sell_dot(const SellLds &s, const double *vec) {
-  double acc = 0.0;
   const double *V = s.V + s.off; const unsigned short *I = s.I + s.off;
-  for (int k = 0; k < s.width; k++) acc += V[64 * k] * vec[I[64 * k]];
+  double acc = 0.0;
+  if constexpr (CAP == 0) {
+    for (int k = 0; k < s.width; k++) acc += V[64 * k] * vec[I[64 * k]];
+  } else {
+    unsigned int ix[CAP]; double vv[CAP];
+#pragma unroll
+    for (int k = 0; k < CAP; k++) {
+      const unsigned int i = I[64 * k]; const double v = V[64 * k];
+      const bool on = k < s.width;
+      ix[k] = on ? i : 0u; vv[k] = on ? v : 0.0;
+    }
+    double g[CAP];
+#pragma unroll
+    for (int k = 0; k < CAP; k++) g[k] = vec[ix[k]];
+#pragma unroll
+    for (int k = 0; k < CAP; k++) acc += vv[k] * g[k];
+  }
   return acc;
 }
 
 struct FastRow { double ls, us, rho, z, y, w; SellLds ar; int i; bool on; };
 
-template <int TR>
+template <int TR, int TC, int CW, int RW, int PA, int PE>
 __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f) {
-  constexpr int TC = 2 * TR;
   constexpr int PS = GI * TR + 1;            // padded row stride of the partial-sum slab
   const QpDev &d = a.d;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -215,14 +239,14 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
     // (1) rhs_j = sigma x_j - q_j + sum_i A_ij t_i ; eliminated part pre-scaled by 1/K_ee
     double gev = 0.0;
     if (colon) {
-      double v = sell_dot(ac, tv);
+      double v = sell_dot<CW>(ac, tv);
       v += sigma * xj - qj;
       xt[j] = v;
       if (ej >= 0) { gev = v * kinv; ge[ej] = gev; }
     }
     __syncthreads();
     // (2) core rhs  r = rhs_C - K_CE K_EE^-1 rhs_E
-    if (coreon) rv[tid] = xt[cvar] - sell_dot(ca, ge);
+    if (coreon) rv[tid] = xt[cvar] - sell_dot<PA>(ca, ge);
     __syncthreads();
     // (3a) register-tile mat-vec: TR partial sums per thread
     {
@@ -247,13 +271,13 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
     }
     __syncthreads();
     // (4) back-substitute eliminated variables; x~ into xt
-    if (colon) xt[j] = (ej >= 0) ? (gev - kinv * sell_dot(ce, xc)) : xc[cj];
+    if (colon) xt[j] = (ej >= 0) ? (gev - kinv * sell_dot<PE>(ce, xc)) : xc[cj];
     __syncthreads();
     // (5) z~ = A x~, then z / y / x updates and next iteration's t
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       if (R[q].on) {
-        const double zt = sell_dot(R[q].ar, xt);
+        const double zt = sell_dot<RW>(R[q].ar, xt);
         const double rho = R[q].rho, rinv = 1.0 / rho;
         const double zr = alpha * zt + (1.0 - alpha) * R[q].z;
         double zn = zr + rinv * R[q].y;
@@ -284,7 +308,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
 #pragma unroll
       for (int q = 0; q < 2; q++)
         if (R[q].on) {
-          const double ax = sell_dot(R[q].ar, sx);
+          const double ax = sell_dot<RW>(R[q].ar, sx);
           const double ei = 1.0 / Eg[R[q].i];
           v[0] = fmax(v[0], fabs(ei * (ax - R[q].z)));
           v[1] = fmax(v[1], fabs(ei * R[q].z));
@@ -293,7 +317,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
       if (colon) {
         double px = 0.0;
         for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * sx[d.Fi[t]];
-        const double aty = sell_dot(ac, swy);
+        const double aty = sell_dot<CW>(ac, swy);
         const double dj = 1.0 / Dg[j];
         v[3] = fabs(dj * (qj + px + aty)); v[4] = fabs(dj * qj); v[5] = fabs(dj * aty); v[6] = fabs(dj * px);
       }
@@ -331,7 +355,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
             for (int q = 0; q < 2; q++) if (R[q].on) swy[R[q].i] = R[q].w * sdy[R[q].i];
             __syncthreads();
             double nat[1] = {0.0};
-            if (colon) nat[0] = fabs(sell_dot(ac, swy) / Dg[j]);
+            if (colon) nat[0] = fabs(sell_dot<CW>(ac, swy) / Dg[j]);
             fblock_reduce<1, true>(nat, red);
             // restore w*y for a possible second (approximate) pass
 #pragma unroll
@@ -363,7 +387,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
 #pragma unroll
               for (int q = 0; q < 2; q++)
                 if (R[q].on) {
-                  const double adx = sell_dot(R[q].ar, sdx) / Eg[R[q].i];
+                  const double adx = sell_dot<RW>(R[q].ar, sdx) / Eg[R[q].i];
                   if ((R[q].us < SCO_INFTY * SCO_MIN_SCALING && adx > edi * ndx) ||
                       (R[q].ls > -SCO_INFTY * SCO_MIN_SCALING && adx < -edi * ndx)) bad[0] = 1.0;
                 }
@@ -427,25 +451,33 @@ int fast_upload(const FastHost &fh, std::vector<void *> &allocs, FastDev &fd) {
   return SCO_OK;
 }
 
-template <int TR>
-static int launch_tr(const AdmmArgs &a, const FastDev &fd, size_t lds, hipStream_t st) {
+template <int TR, int TC, int CW, int RW, int PA, int PE>
+static int launch_one(const AdmmArgs &a, const FastDev &fd, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_fast_kernel<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_fast_kernel<TR, TC, CW, RW, PA, PE>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(qp_admm_fast_kernel<TR>, dim3(a.d.batch), dim3(FT), lds, st, a, fd);
+  hipLaunchKernelGGL((qp_admm_fast_kernel<TR, TC, CW, RW, PA, PE>), dim3(a.d.batch), dim3(FT), lds, st, a, fd);
   SCO_HIP(hipGetLastError());
   return SCO_OK;
 }
 
+template <int TR, int TC>
+static int launch_tile(const AdmmArgs &a, const FastHost &fh, const FastDev &fd, hipStream_t st) {
+  if (fh.capped) return launch_one<TR, TC, 12, 8, 12, 8>(a, fd, fh.lds_bytes, st);
+  return launch_one<TR, TC, 0, 0, 0, 0>(a, fd, fh.lds_bytes, st);
+}
+
 int fast_launch(const AdmmArgs &a, const FastHost &fh, const FastDev &fd, hipStream_t st) {
-  switch (fh.TR) {
-    case 1: return launch_tr<1>(a, fd, fh.lds_bytes, st);
-    case 2: return launch_tr<2>(a, fd, fh.lds_bytes, st);
-    case 3: return launch_tr<3>(a, fd, fh.lds_bytes, st);
-    case 4: return launch_tr<4>(a, fd, fh.lds_bytes, st);
-    case 5: return launch_tr<5>(a, fd, fh.lds_bytes, st);
+  switch (fh.TR * 100 + fh.TC) {
+    case 102: return launch_tile<1, 2>(a, fh, fd, st);
+    case 204: return launch_tile<2, 4>(a, fh, fd, st);
+    case 306: return launch_tile<3, 6>(a, fh, fd, st);
+    case 408: return launch_tile<4, 8>(a, fh, fd, st);
+    case 509: return launch_tile<5, 9>(a, fh, fd, st);
+    case 510: return launch_tile<5, 10>(a, fh, fd, st);
   }
   sco_set_error("fast_launch: unsupported tile");
   return SCO_ERR_CAPACITY;

@@ -57,7 +57,7 @@ struct SellHost {
   std::vector<unsigned short> idx;
 };
 struct SellDev { const int *base, *width, *src; const unsigned short *idx; int total; };
-struct FastHost { SellHost Ac, Ar, Ca, Ce; int TR = 1; size_t lds_doubles = 0, lds_bytes = 0; };
+struct FastHost { SellHost Ac, Ar, Ca, Ce; int TR = 1, TC = 2; bool capped = false; size_t lds_doubles = 0, lds_bytes = 0; };
 struct FastDev { SellDev Ac, Ar, Ca, Ce; };
 
 struct AdmmArgs {
