@@ -34,7 +34,7 @@
 // --------------------------------------------------------------------------
 // host: sliced-ELL construction
 // --------------------------------------------------------------------------
-static void build_sell(int nitems, const std::vector<int> &ptr, const std::vector<int> &idx,
+void build_sell(int nitems, const std::vector<int> &ptr, const std::vector<int> &idx,
                        const std::vector<int> &src, SellHost &out) {
   out.nitems = nitems;
   const int ns = (nitems + 63) / 64;

@@ -70,9 +70,28 @@ bool fast_plan_build(const QpPlan &pl, FastHost &fh);
 int fast_upload(const FastHost &fh, std::vector<void *> &allocs, FastDev &fd);
 int fast_launch(const AdmmArgs &a, const FastHost &fh, const FastDev &fd, hipStream_t st);
 
+// ---- register-resident ADMM path (sco_admm_reg.hip) -------------------------
+// Per-thread programs: slot s of thread t at [s * 512 + t]; slots = CW column
+// entries, 2 x RW row entries, PX coupling entries.
+struct RegHost {
+  int TR = 1, TC = 2, CW = 0, RW = 0, PX = 0;
+  SellHost Ac, Ar, Ca, Ce;
+  size_t lds_bytes = 0;
+  std::vector<int> role;
+  std::vector<unsigned short> off;
+};
+struct RegDev { const unsigned short *off; const int *role; const int *srcAc, *srcAr, *srcCa, *srcCe; };
+int reg_caps_for(const QpPlan &pl, int *CW, int *RW, int *PX);
+bool reg_plan_build(const QpPlan &pl, int CW, int RW, int PX, RegHost &rh);
+int reg_upload(const RegHost &rh, std::vector<void *> &allocs, RegDev &rd);
+int reg_launch(const AdmmArgs &a, const RegHost &rh, const RegDev &rd, hipStream_t st);
+
 struct sco_qp {
   int device = 0;
   QpPlan plan;
+  RegHost reg;
+  RegDev regd{};
+  bool use_reg = false;
   FastHost fast;
   FastDev fastd{};
   bool use_fast = false;

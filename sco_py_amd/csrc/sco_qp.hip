@@ -616,6 +616,15 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
   SCO_HIP(hipFuncSetAttribute((const void *)qp_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   {
+    const char *no_reg = getenv("SCO_QP_NO_REG");
+    int CW = 0, RW = 0, PX = 0;
+    if (!(no_reg && no_reg[0] == '1') && reg_caps_for(pl, &CW, &RW, &PX) && reg_plan_build(pl, CW, RW, PX, qp->reg)) {
+      int r_ = reg_upload(qp->reg, qp->allocs, qp->regd);
+      if (r_) return r_;
+      qp->use_reg = true;
+    }
+  }
+  {
     const char *no_fast = getenv("SCO_QP_NO_FAST");
     if (!(no_fast && no_fast[0] == '1') && fast_plan_build(pl, qp->fast)) {
       int r_ = fast_upload(qp->fast, qp->allocs, qp->fastd);
@@ -689,7 +698,10 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
   SCO_HIP(hipGetLastError());
   SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
   if (mid) SCO_HIP(hipEventRecord(mid, qp->stream));
-  if (qp->use_fast) {
+  if (qp->use_reg) {
+    int r_ = reg_launch(aa, qp->reg, qp->regd, qp->stream);
+    if (r_) return r_;
+  } else if (qp->use_fast) {
     int r_ = fast_launch(aa, qp->fast, qp->fastd, qp->stream);
     if (r_) return r_;
   } else {
@@ -727,7 +739,7 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
 extern "C" int sco_qp_info(const sco_qp *qp, int info[4]) {
   if (!qp || !info) return SCO_ERR_ARG;
   info[0] = qp->plan.n_e; info[1] = qp->plan.n_c;
-  info[2] = (int)(qp->use_fast ? qp->fast.lds_bytes : qp->lds_admm); info[3] = qp->plan.ncpl;
+  info[2] = (int)(qp->use_reg ? 44032 + qp->reg.lds_bytes : (qp->use_fast ? qp->fast.lds_bytes : qp->lds_admm)); info[3] = qp->plan.ncpl;
   return SCO_OK;
 }
 

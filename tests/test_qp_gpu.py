@@ -83,14 +83,30 @@ def test_7x20_shape_batch(gpu):
     assert info["lds_admm"] <= 160 * 1024                       # fits the CU's LDS
 
 
-def test_generic_and_fast_admm_kernels_agree(gpu, monkeypatch):
+def test_three_admm_kernel_tiers_agree(gpu, monkeypatch):
+    """register-offset kernel (default) vs LDS sliced-ELL kernel vs generic kernel."""
     rng = np.random.default_rng(17)
-    probs = [penalty_qp(rng, 6, 3, 4) for _ in range(4)]
+    probs = [penalty_qp(rng, 6, 3, 4) for _ in range(4)] + [penalty_qp(rng, 6, 3, 4, )]
+    _, x_reg, st_reg, it_reg = _check(probs)
+    monkeypatch.setenv("SCO_QP_NO_REG", "1")
+    _, x_sell, st_sell, it_sell = _check(probs)
     monkeypatch.setenv("SCO_QP_NO_FAST", "1")
-    _, x0, st0, it0 = _check(probs)
-    monkeypatch.delenv("SCO_QP_NO_FAST")
-    _, x1, st1, it1 = _check(probs)
-    assert np.array_equal(st0, st1) and np.array_equal(it0, it1) and np.abs(x0 - x1).max() < 1e-10
+    _, x_gen, st_gen, it_gen = _check(probs)
+    for x, st, it in ((x_sell, st_sell, it_sell), (x_gen, st_gen, it_gen)):
+        assert np.array_equal(st, st_reg) and np.array_equal(it, it_reg) and np.abs(x - x_reg).max() < 1e-10
+
+
+def test_wide_rows_fall_back_to_the_looping_kernels(gpu):
+    """A pattern wider than the register-offset caps (row > 8 entries) still solves correctly."""
+    rng = np.random.default_rng(23)
+    n, m_c = 14, 6
+    P = np.diag(rng.random(n) + 0.5)
+    A = np.vstack([rng.standard_normal((m_c, n)), np.eye(n)])          # dense rows: 14 entries each
+    probs = []
+    for _ in range(3):
+        l = np.concatenate([-rng.random(m_c) - 0.5, -np.ones(n)]); u = np.concatenate([rng.random(m_c) + 0.5, np.ones(n)])
+        probs.append((P, rng.standard_normal(n), A, l, u))
+    _check(probs)
 
 
 def test_elimination_can_be_disabled_and_agrees(gpu, monkeypatch):
