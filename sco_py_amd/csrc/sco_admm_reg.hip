@@ -181,25 +181,24 @@ __device__ __forceinline__ double gat(const double *base, unsigned int byte_off)
 
 // N-entry dot product: values V[64 k] (sliced-ELL image in LDS, immediate offsets),
 // gathered operand at byte offset o[k] (two 16-bit offsets per register).
+// N-entry dot product: values V[64 k] (sliced-ELL image in LDS, immediate offsets),
+// gathered operand at byte offset o[k] (two 16-bit offsets per register).  The empty
+// asm keeps the offsets PACKED: without it the compiler hoists the 38 unpacked
+// offsets out of the ADMM loop, runs out of VGPRs and reloads them from scratch
+// every iteration (profiles/r01_v4_*).
 template <int N>
-__device__ __forceinline__ double reg_dot(const double *V, const unsigned int (&o)[(N + 1) / 2], const double *vec) {
-  double acc = 0.0;
-  // chunks of 4: four value loads and four gathers in flight, then their FMAs
-  // (keeps the temporaries to 16 VGPRs; the summation order stays k = 0, 1, ...)
+__device__ __forceinline__ double reg_dot(const double *V, unsigned int (&o)[(N + 1) / 2], const double *vec) {
+  double val[N], g[N];
 #pragma unroll
-  for (int k0 = 0; k0 < N; k0 += 4) {
-    double val[4], g[4];
+  for (int h = 0; h < (N + 1) / 2; h++) asm volatile("" : "+v"(o[h]));
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int k = k0 + u;
-      if (k < N) {
-        val[u] = V[64 * k];
-        g[u] = gat(vec, (k & 1) ? (o[k / 2] >> 16) : (o[k / 2] & 0xffffu));
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) if (k0 + u < N) acc += val[u] * g[u];
+  for (int k = 0; k < N; k++) {
+    val[k] = V[64 * k];
+    g[k] = gat(vec, (k & 1) ? (o[k / 2] >> 16) : (o[k / 2] & 0xffffu));
   }
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; k++) acc += val[k] * g[k];
   return acc;
 }
 
