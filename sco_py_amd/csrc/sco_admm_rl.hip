@@ -1,0 +1,705 @@
+// sco_admm_rl.hip -- "row-local" ADMM kernel for gfx950 (MI355X): the fastest tier.
+//
+// Same ADMM as the other tiers (OSQP's algorithm, the third-party call behind
+// /root/reference/sco_py/sco_osqp/osqp_utils.py:216) with the two-level solve
+//     x~_C = W (rhs_C - K_CE g),  g = K_EE^-1 rhs_E,  x~_E = g - K_EE^-1 K_EC x~_C
+// rewritten so that the coupling block K_CE never materialises.  K's graph gives
+// every row at most ONE eliminated variable e(i) (E is an independent set), hence
+//     K_CE g      = A_C' u,          u_i = rw_i A_{i,e(i)} g_{e(i)}
+//     K_EC x~_C   = sum_{i has e} rw_i A_{i,e} (A_{i,C} x~_C)
+// so with  t'_i = t_i - u_i  the core right-hand side is one gather-dot over a core
+// variable's column,  r_c = sigma x_c - q_c + sum_i A_ic t'_i,  and x~_e falls out of
+// the core part of the row dot products its owner computes anyway.  All rows of an
+// eliminated variable live in the SAME thread, so everything about e (x_e, q_e,
+// 1/K_ee, g_e, u_i) is thread-local.
+//
+// One iteration = 3 phases / 3 barriers (the profile of the 6-phase kernel,
+// profiles/r01_v4_pmc_summary.txt, showed 54 % of wave time in s_waitcnt/s_barrier):
+//   (1)  core-variable owners:  r_c                     (CW-entry gather-dot)
+//   (3)  all 512 threads:       register-tile W mat-vec; the 16 partial sums of a row
+//                                 are added across a DPP row (row_shr), no LDS hop
+//   (Y)  row owners:            core part of A x~, x~_e, z / y / x updates, t'
+// Data placement as in sco_admm_reg.hip: W tile and packed byte offsets in
+// registers, sparse values in LDS sliced-ELL images built in thread order
+// (conflict-free, immediate offsets), padded slots gather an always-zero element.
+#include "sco_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#define LT 512
+#define LWV (LT / 64)
+#define LGJ 16
+#define LGI (LT / LGJ)
+#define LCAP_M 1024
+#define LCAP_NC 160
+#define LCW 12          // entries of a core variable's column
+#define LRW 8           // core entries of a row
+
+// Paired sliced-ELL: slices of 64 items (one wavefront); entries 2h and 2h+1 of lane l
+// sit next to each other at base[s] + (64 h + l) * 2, so one ds_read_b128 per lane
+// (contiguous 1 KiB per wave instruction, conflict-free) fetches two values.
+static void build_sell2(int nitems, const std::vector<int> &ptr, const std::vector<int> &src, SellHost &out) {
+  out.nitems = nitems;
+  const int ns = (nitems + 63) / 64;
+  out.base.assign(ns + 1, 0); out.width.assign(std::max(ns, 1), 0);
+  for (int s = 0; s < ns; s++) {
+    int w = 0;
+    for (int it = s * 64; it < std::min(nitems, s * 64 + 64); it++) w = std::max(w, ptr[it + 1] - ptr[it]);
+    w = (w + 1) & ~1;
+    out.width[s] = w; out.base[s + 1] = out.base[s] + 64 * w;
+  }
+  out.total = out.base[ns];
+  out.idx.clear(); out.src.assign(std::max(out.total, 1), -1);
+  for (int it = 0; it < nitems; it++) {
+    const int s = it / 64, l = it % 64;
+    for (int k = 0; k < ptr[it + 1] - ptr[it]; k++)
+      out.src[out.base[s] + (64 * (k / 2) + l) * 2 + (k & 1)] = src[ptr[it] + k];
+  }
+}
+
+// --------------------------------------------------------------------------
+// host: thread assignment and per-thread programs
+// --------------------------------------------------------------------------
+bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
+  if (pl.n_c >= LCAP_NC || pl.m >= LCAP_M || pl.n_e > LT || pl.n_c > LT || pl.nnzA >= 65536 || pl.n > 2 * LT) return false;
+  const int n = pl.n, m = pl.m;
+  // rows of every eliminated variable; every row's eliminated variable
+  std::vector<int> row_elim(m, -1), row_epos(m, -1);
+  std::vector<std::vector<int>> erows(pl.n_e);
+  for (int i = 0; i < m; i++)
+    for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
+      const int e = pl.elim_of[pl.Rj[s]];
+      if (e >= 0) {
+        if (row_elim[i] >= 0) return false;          // two eliminated variables in one row
+        row_elim[i] = e; row_epos[i] = pl.Rpos[s]; erows[e].push_back(i);
+      }
+    }
+  for (int e = 0; e < pl.n_e; e++) if (erows[e].size() > 2) return false;
+  // ---- thread assignment: slot (q, t) -> row
+  std::vector<int> slot_row(2 * LT, -1);
+  for (int e = 0; e < pl.n_e; e++)                 // eliminated variable e -> thread e
+    for (size_t q = 0; q < erows[e].size(); q++) slot_row[q * LT + e] = erows[e][q];
+  {
+    int cur = 0;
+    std::vector<int> order;                        // free slots: threads without an eliminated variable first
+    for (int q = 0; q < 2; q++) for (int t = pl.n_e; t < LT; t++) order.push_back(q * LT + t);
+    for (int q = 0; q < 2; q++) for (int t = 0; t < pl.n_e; t++) order.push_back(q * LT + t);
+    for (int i = 0; i < m; i++) {
+      if (row_elim[i] >= 0) continue;
+      while (cur < (int)order.size() && slot_row[order[cur]] >= 0) cur++;
+      if (cur >= (int)order.size()) return false;
+      slot_row[order[cur]] = i;
+    }
+  }
+  // core variable c -> thread LT - 1 - c (far from the eliminated-variable threads)
+  // ---- sliced-ELL images in thread order
+  {
+    // columns of core variables, item = thread
+    std::vector<int> ptr(LT + 1, 0), idx, src;
+    for (int t = 0; t < LT; t++) {
+      const int c = LT - 1 - t;
+      if (c < pl.n_c) {
+        const int j = pl.core_var[c];
+        if (pl.Ap[j + 1] - pl.Ap[j] > LCW) return false;
+        for (int p = pl.Ap[j]; p < pl.Ap[j + 1]; p++) { idx.push_back(pl.Ai[p]); src.push_back(p); }
+      }
+      ptr[t + 1] = (int)idx.size();
+    }
+    build_sell2(LT, ptr, src, rh.Ac);
+  }
+  for (int q = 0; q < 2; q++) {
+    std::vector<int> ptr(LT + 1, 0), idx, src;
+    for (int t = 0; t < LT; t++) {
+      const int i = slot_row[q * LT + t];
+      if (i >= 0) {
+        int cnt = 0;
+        for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
+          const int c = pl.core_of[pl.Rj[s]];
+          if (c >= 0) { idx.push_back(c); src.push_back(pl.Rpos[s]); cnt++; }
+        }
+        if (cnt > LRW) return false;
+      }
+      ptr[t + 1] = (int)idx.size();
+    }
+    build_sell2(LT, ptr, src, q == 0 ? rh.Ar0 : rh.Ar1);
+  }
+  rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rh.Ar0.total + rh.Ar1.total + 64 * 16);
+  // ---- per-thread tables: packed gather offsets and roles
+  const int slots = LCW + 2 * LRW;
+  rh.off.assign((size_t)slots * LT, 0);
+  rh.role.assign((size_t)16 * LT, -1);
+  for (int t = 0; t < LT; t++) {
+    for (int k = 0; k < LCW; k++) rh.off[(size_t)k * LT + t] = (unsigned short)(8 * m);             // zero of t'
+    for (int k = 0; k < 2 * LRW; k++) rh.off[(size_t)(LCW + k) * LT + t] = (unsigned short)(8 * pl.n_c);   // zero of x_C
+    // role table: 0 core idx, 1 core var, 2 elim idx, 3 elim var, 4/5 row of slot 0/1,
+    //             6/7 CSC position of the row's eliminated coefficient, 8 col base, 9/10 row bases,
+    //             11/12 position of P_jj for the core / eliminated variable
+    rh.role[(size_t)8 * LT + t] = rh.Ac.base[t / 64] + 2 * (t % 64);
+    rh.role[(size_t)9 * LT + t] = rh.Ac.total + rh.Ar0.base[t / 64] + 2 * (t % 64);
+    rh.role[(size_t)10 * LT + t] = rh.Ac.total + rh.Ar0.total + rh.Ar1.base[t / 64] + 2 * (t % 64);
+    rh.role[(size_t)13 * LT + t] = rh.Ac.width[t / 64];      // wave-uniform trip counts
+    rh.role[(size_t)14 * LT + t] = rh.Ar0.width[t / 64];
+    rh.role[(size_t)15 * LT + t] = rh.Ar1.width[t / 64];
+    const int c = LT - 1 - t;
+    if (c < pl.n_c) {
+      const int j = pl.core_var[c];
+      rh.role[t] = c; rh.role[(size_t)LT + t] = j; rh.role[(size_t)11 * LT + t] = pl.Pdiag[j];
+      int k = 0;
+      for (int p = pl.Ap[j]; p < pl.Ap[j + 1]; p++, k++) rh.off[(size_t)k * LT + t] = (unsigned short)(8 * pl.Ai[p]);
+    }
+    if (t < pl.n_e) {
+      rh.role[(size_t)2 * LT + t] = t; rh.role[(size_t)3 * LT + t] = pl.elim_var[t];
+      rh.role[(size_t)12 * LT + t] = pl.Pdiag[pl.elim_var[t]];
+    }
+    for (int q = 0; q < 2; q++) {
+      const int i = slot_row[q * LT + t];
+      rh.role[(size_t)(4 + q) * LT + t] = i;
+      if (i < 0) continue;
+      if (row_elim[i] >= 0) {
+        if (row_elim[i] != t) return false;
+        rh.role[(size_t)(6 + q) * LT + t] = row_epos[i];
+      }
+      int k = 0;
+      for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
+        const int c2 = pl.core_of[pl.Rj[s]];
+        if (c2 >= 0) { rh.off[(size_t)(LCW + q * LRW + k) * LT + t] = (unsigned short)(8 * c2); k++; }
+      }
+    }
+  }
+  // P restricted to the core (for the dual residual): core c -> (position in triu values, core index)
+  rh.pc_ptr.assign(pl.n_c + 1, 0);
+  for (int c = 0; c < pl.n_c; c++) {
+    const int j = pl.core_var[c];
+    for (int p = pl.Fp[j]; p < pl.Fp[j + 1]; p++) {
+      const int c2 = pl.core_of[pl.Fi[p]];
+      if (c2 < 0) return false;                    // an eliminated variable has no off-diagonal P entry
+      rh.pc_pos.push_back(pl.Fpos[p]); rh.pc_core.push_back(c2);
+    }
+    rh.pc_ptr[c + 1] = (int)rh.pc_pos.size();
+  }
+  rh.TR = std::max(1, (pl.n_c + LGI - 1) / LGI);
+  rh.TC = 2 * rh.TR;
+  if (rh.TR == 5 && pl.n_c <= LGJ * 9) rh.TC = 9;
+  return rh.lds_bytes + 32 * 1024 <= 160 * 1024;   // + 30.2 KB of static LDS
+}
+
+// --------------------------------------------------------------------------
+// device
+// --------------------------------------------------------------------------
+struct RlArgs {
+  int n, m, n_e, n_c, nnzA, nnzP, max_iter, check;
+  double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+  const unsigned short *off; const int *role;
+  const int *srcAc, *srcAr0, *srcAr1, *pc_ptr, *pc_pos, *pc_core;
+  int totAc, totAr0, totAr1;
+  const double *As, *W, *qs, *kee_inv, *ls, *us, *rho, *cscale, *Ps, *D, *E;
+  const int *w, *active;
+  double *x, *y, *resid;
+  int *status, *iters;
+  double *stamp;     // diagnostic build only (SCO_STAMP), else unused
+};
+
+__device__ __forceinline__ double lwmax(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double lwsum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <int NR, bool IS_MAX>
+__device__ __forceinline__ void lblock_reduce(double (&v)[NR], double *red) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NR; k++) v[k] = IS_MAX ? lwmax(v[k]) : lwsum(v[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NR; k++) red[wv * NR + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    double r = red[k];
+#pragma unroll
+    for (int w = 1; w < LWV; w++) r = IS_MAX ? fmax(r, red[w * NR + k]) : r + red[w * NR + k];
+    v[k] = r;
+  }
+}
+
+__device__ __forceinline__ double lgat(const double *base, unsigned int byte_off) {
+  return *(const double *)((const char *)base + byte_off);
+}
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+// N-entry gather-dot on the paired image: values V[128 h .. 128 h + 1] (one 16-byte
+// LDS read per pair), gathered operand at byte offset o[h] lo/hi half.  Offsets stay
+// packed two per VGPR (the empty asm stops the compiler from hoisting the unpack out
+// of the ADMM loop, which costs 2x the registers and spills).
+template <int N>
+__device__ __forceinline__ double rl_dot(const double *V, unsigned int *o, const double *vec) {
+  dbl2 val[N / 2]; double g[N];
+#pragma unroll
+  for (int h = 0; h < N / 2; h++) {
+    asm volatile("" : "+v"(o[h]));
+    val[h] = *(const dbl2 *)(V + 128 * h);
+    g[2 * h] = lgat(vec, o[h] & 0xffffu);
+    g[2 * h + 1] = lgat(vec, o[h] >> 16);
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int h = 0; h < N / 2; h++) { acc += val[h].x * g[2 * h]; acc += val[h].y * g[2 * h + 1]; }
+  return acc;
+}
+
+// dispatch on the wave-uniform trip count so padded slots cost nothing
+__device__ __forceinline__ double rl_dot_col(int w, const double *V, unsigned int *o, const double *vec) {
+  if (w <= 0) return 0.0;
+  if (w <= 4) return rl_dot<4>(V, o, vec);
+  if (w <= 8) return rl_dot<8>(V, o, vec);
+  return rl_dot<LCW>(V, o, vec);
+}
+__device__ __forceinline__ double rl_dot_row(int w, const double *V, unsigned int *o, const double *vec) {
+  if (w <= 0) return 0.0;
+  if (w <= 2) return rl_dot<2>(V, o, vec);
+  if (w <= 4) return rl_dot<4>(V, o, vec);
+  return rl_dot<LRW>(V, o, vec);
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15); the total lands in
+// lane 15 of the row.  Inclusive scan by doubling with row_shr 1, 2, 4, 8.
+__device__ __forceinline__ double row16_sum(double v) {
+#pragma unroll
+  for (int sh = 1; sh < 16; sh <<= 1) {
+    const int ctrl = 0x110 + sh;                      // row_shr:sh
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2, hi2;
+    switch (sh) {
+      case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
+      case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
+      case 4: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
+      default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
+    }
+    (void)ctrl;
+    v += __hiloint2double(hi2, lo2);
+  }
+  return v;
+}
+
+template <int TR, int TC>
+__global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (a.active && !a.active[b]) return;
+  const int n = a.n, m = a.m, n_e = a.n_e, n_c = a.n_c;
+
+  __shared__ double s_tv[LCAP_M];                 // t' (by row), element m stays 0
+  __shared__ double s_rv[LCAP_NC];                // core right-hand side, zero padded
+  __shared__ double s_xc[LCAP_NC];                // x~_C, element n_c stays 0
+  __shared__ double s_chk[2 * LCAP_M + 2 * LCAP_NC];   // check scratch: w*y, dy (by row), x_C, dx_C
+  __shared__ double s_red[LWV * 8];
+  double *swy = s_chk, *sdy = swy + LCAP_M, *sxc = sdy + LCAP_M, *sdxc = sxc + LCAP_NC;
+  extern __shared__ double s_val[];
+
+  // ---- prologue ----------------------------------------------------------------
+  const double *gAs = a.As + (size_t)b * a.nnzA;
+  {
+    double *V = s_val;
+    for (int p = tid; p < a.totAc; p += LT) { const int s = a.srcAc[p]; V[p] = s >= 0 ? gAs[s] : 0.0; }
+    V += a.totAc;
+    for (int p = tid; p < a.totAr0; p += LT) { const int s = a.srcAr0[p]; V[p] = s >= 0 ? gAs[s] : 0.0; }
+    V += a.totAr0;
+    for (int p = tid; p < a.totAr1; p += LT) { const int s = a.srcAr1[p]; V[p] = s >= 0 ? gAs[s] : 0.0; }
+    V += a.totAr1;
+    for (int p = tid; p < 64 * 16; p += LT) V[p] = 0.0;
+  }
+  auto pack = [&](int slot) -> unsigned int {
+    return (unsigned int)a.off[(size_t)slot * LT + tid] | ((unsigned int)a.off[(size_t)(slot + 1) * LT + tid] << 16);
+  };
+  unsigned int co[LCW / 2], ro[2][LRW / 2];
+#pragma unroll
+  for (int k = 0; k < LCW / 2; k++) co[k] = pack(2 * k);
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int k = 0; k < LRW / 2; k++) ro[q][k] = pack(LCW + q * LRW + 2 * k);
+  const double *vcol = s_val + a.role[(size_t)8 * LT + tid];
+  const double *vr0 = s_val + a.role[(size_t)9 * LT + tid];
+  const double *vr1 = s_val + a.role[(size_t)10 * LT + tid];
+  const int wcol = __builtin_amdgcn_readfirstlane(a.role[(size_t)13 * LT + tid]);
+  const int wr0 = __builtin_amdgcn_readfirstlane(a.role[(size_t)14 * LT + tid]);
+  const int wr1 = __builtin_amdgcn_readfirstlane(a.role[(size_t)15 * LT + tid]);
+  const int gi = tid / LGJ, gj = tid % LGJ;
+  double wreg[TR][TC];
+  {
+    const double *W = a.W + (size_t)b * n_c * n_c;
+#pragma unroll
+    for (int rr = 0; rr < TR; rr++)
+#pragma unroll
+      for (int cc = 0; cc < TC; cc++) {
+        const int row = gi * TR + rr, col = gj * TC + cc;
+        wreg[rr][cc] = (row < n_c && col < n_c) ? W[(size_t)row * n_c + col] : 0.0;
+      }
+  }
+  // core-variable state
+  const int cown = a.role[tid];
+  const int cvar = cown >= 0 ? a.role[(size_t)LT + tid] : 0;
+  double xcv = 0.0, qc = 0.0;
+  if (cown >= 0) qc = a.qs[(size_t)b * n + cvar];
+  // eliminated-variable state
+  const int eown = a.role[(size_t)2 * LT + tid];
+  const int evar = eown >= 0 ? a.role[(size_t)3 * LT + tid] : 0;
+  double xe = 0.0, qe = 0.0, kinv = 0.0, ge = 0.0;
+  if (eown >= 0) { qe = a.qs[(size_t)b * n + evar]; kinv = a.kee_inv[(size_t)b * n_e + eown]; ge = -qe * kinv; }
+  // row state
+  int r_i[2]; double r_ls[2], r_us[2], r_rho[2], r_rinv[2], r_z[2], r_y[2], r_w[2], r_ae[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    r_i[q] = a.role[(size_t)(4 + q) * LT + tid];
+    r_ls[q] = r_us[q] = r_z[q] = r_y[q] = r_ae[q] = 0.0; r_rho[q] = r_rinv[q] = r_w[q] = 1.0;
+    if (r_i[q] >= 0) {
+      const int i = r_i[q];
+      r_ls[q] = a.ls[(size_t)b * m + i]; r_us[q] = a.us[(size_t)b * m + i];
+      r_rho[q] = a.rho[(size_t)b * m + i]; r_rinv[q] = 1.0 / r_rho[q];
+      r_w[q] = (double)a.w[(size_t)b * m + i];
+      const int ep = a.role[(size_t)(6 + q) * LT + tid];
+      if (ep >= 0) r_ae[q] = gAs[ep];
+    }
+  }
+  for (int i = tid; i < LCAP_M; i += LT) s_tv[i] = 0.0;
+  for (int i = tid; i < LCAP_NC; i += LT) { s_rv[i] = 0.0; s_xc[i] = 0.0; }
+  __syncthreads();
+  // t' of the start point x = z = y = 0:  t = 0, g_e = -q_e / K_ee, t'_i = -rw_i a_ie g_e
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+    if (r_i[q] >= 0) s_tv[r_i[q]] = -(r_w[q] * r_rho[q]) * r_ae[q] * ge;
+  const double cscale = a.cscale[b];
+  const double alpha = a.alpha, sigma = a.sigma;
+  __syncthreads();
+
+  int status = 0, iter = 0;
+  double pri = 0.0, dua = 0.0;
+#ifdef SCO_STAMP
+  // diagnostic build only: cycles per phase per wavefront (never compiled into the product)
+  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
+#define STAMP(k) { const long long now_ = __builtin_readcyclecounter(); st_acc[k] += now_ - st_t; st_t = now_; }
+#else
+#define STAMP(k)
+#endif
+  // One ADMM iteration.  `chk` is a compile-time constant at both call sites: the
+  // unchecked copy forms a tight inner loop with its latch right behind it (the
+  // far jump over the termination test cost ~900 cycles per iteration,
+  // profiles/r01_v5_stamps.txt), the checked copy runs every `check`-th iteration.
+  double dxe = 0.0, dxc = 0.0;
+  auto step = [&](const bool chk) __attribute__((always_inline)) {
+    STAMP(6)
+    // (1) core right-hand side
+    {
+      const double dv = rl_dot_col(wcol, vcol, co, s_tv);
+      if (cown >= 0) s_rv[cown] = (sigma * xcv - qc) + dv;
+    }
+    STAMP(0)
+    __syncthreads();
+    STAMP(1)
+    // (3) register-tile mat-vec; the 16 partial sums of a row sit in the 16 lanes of a
+    //     DPP row and are added with row shifts (no LDS round trip, no extra barrier)
+    {
+      double rr_[TC];
+#pragma unroll
+      for (int cc = 0; cc < TC; cc++) rr_[cc] = s_rv[gj * TC + cc];
+#pragma unroll
+      for (int rr = 0; rr < TR; rr++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < TC; cc++) acc += wreg[rr][cc] * rr_[cc];
+        acc = row16_sum(acc);
+        if (gj == LGJ - 1 && gi * TR + rr < n_c) s_xc[gi * TR + rr] = acc;
+      }
+    }
+    STAMP(2)
+    __syncthreads();
+    STAMP(3)
+    // (Y) rows, eliminated variable, updates, next t'
+    {
+      double zc[2];
+      zc[0] = rl_dot_row(wr0, vr0, ro[0], s_xc);
+      zc[1] = rl_dot_row(wr1, vr1, ro[1], s_xc);
+      // x~_e = g_e - (1/K_ee) sum_i rw_i a_ie (A_iC x~_C)
+      const double xte = ge - kinv * ((r_w[0] * r_rho[0]) * r_ae[0] * zc[0] + (r_w[1] * r_rho[1]) * r_ae[1] * zc[1]);
+      double tq[2], dyq[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const double zt = zc[q] + r_ae[q] * xte;
+        const double zr = alpha * zt + (1.0 - alpha) * r_z[q];
+        double zn = zr + r_rinv[q] * r_y[q];
+        zn = fmin(fmax(zn, r_ls[q]), r_us[q]);
+        dyq[q] = r_rho[q] * (zr - zn);
+        r_y[q] += dyq[q]; r_z[q] = zn;
+        tq[q] = r_w[q] * (r_rho[q] * zn - r_y[q]);
+      }
+      if (eown >= 0) {
+        const double xn = alpha * xte + (1.0 - alpha) * xe;
+        dxe = xn - xe; xe = xn;
+        const double rhs_e = (sigma * xe - qe) + r_ae[0] * tq[0] + r_ae[1] * tq[1];
+        ge = rhs_e * kinv;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (r_i[q] >= 0) {
+          s_tv[r_i[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
+          if (chk) { swy[r_i[q]] = r_w[q] * r_y[q]; sdy[r_i[q]] = dyq[q]; }
+        }
+      if (cown >= 0) {
+        const double xn = alpha * s_xc[cown] + (1.0 - alpha) * xcv;
+        dxc = xn - xcv; xcv = xn;
+        if (chk) { sxc[cown] = xn; sdxc[cown] = dxc; }
+      }
+      if (chk && tid == 0) { swy[m] = 0.0; sxc[n_c] = 0.0; sdxc[n_c] = 0.0; }
+      STAMP(4)
+      __syncthreads();
+      STAMP(5)
+    }
+  };
+  iter = 0;
+  while (!status && iter < a.max_iter) {
+    int next = a.max_iter;
+    if (a.check > 0) { next = (iter / a.check + 1) * a.check; if (next > a.max_iter) next = a.max_iter; }
+    while (iter + 1 < next) { iter++; step(false); }
+    iter++; step(true);
+    {
+      // ---- termination test (formulas of admm_check in sco_qp.hip) ---------------------
+      for (int approximate = 0; approximate < 2 && !status; approximate++) {
+        if (approximate && iter < a.max_iter) break;
+        const double *Ps = a.Ps + (size_t)b * a.nnzP;
+        const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
+        const double cinv = 1.0 / cscale;
+        double ea = a.eps_abs, er = a.eps_rel, epi = a.eps_prim_inf, edi = a.eps_dual_inf;
+        if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+        double v[7] = {0, 0, 0, 0, 0, 0, 0};
+        {
+          double axc[2];
+          axc[0] = rl_dot_row(wr0, vr0, ro[0], sxc); axc[1] = rl_dot_row(wr1, vr1, ro[1], sxc);
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+            if (r_i[q] >= 0) {
+              const double ax = axc[q] + r_ae[q] * xe;
+              const double ei = 1.0 / Eg[r_i[q]];
+              v[0] = fmax(v[0], fabs(ei * (ax - r_z[q])));
+              v[1] = fmax(v[1], fabs(ei * r_z[q]));
+              v[2] = fmax(v[2], fabs(ei * ax));
+            }
+        }
+        const double aty_c = rl_dot_col(wcol, vcol, co, swy);     // whole wave: the trip count is wave-uniform
+        if (cown >= 0) {
+          const double aty = aty_c;
+          double px = 0.0;
+          for (int t = a.pc_ptr[cown]; t < a.pc_ptr[cown + 1]; t++) px += Ps[a.pc_pos[t]] * sxc[a.pc_core[t]];
+          const double dj = 1.0 / Dg[cvar];
+          v[3] = fabs(dj * (qc + px + aty)); v[4] = fabs(dj * qc); v[5] = fabs(dj * aty); v[6] = fabs(dj * px);
+        }
+        if (eown >= 0) {
+          const int pd = a.role[(size_t)12 * LT + tid];
+          const double px = pd >= 0 ? Ps[pd] * xe : 0.0;
+          const double aty = r_ae[0] * (r_w[0] * r_y[0]) + r_ae[1] * (r_w[1] * r_y[1]);
+          const double dj = 1.0 / Dg[evar];
+          v[3] = fmax(v[3], fabs(dj * (qe + px + aty))); v[4] = fmax(v[4], fabs(dj * qe));
+          v[5] = fmax(v[5], fabs(dj * aty)); v[6] = fmax(v[6], fabs(dj * px));
+        }
+        lblock_reduce<7, true>(v, s_red);
+        pri = v[0]; dua = cinv * v[3];
+        if (!(pri <= SCO_INFTY) || !(dua <= SCO_INFTY)) { status = SCO_QP_NON_CVX; break; }
+        const double eps_p = ea + er * fmax(v[1], v[2]);
+        const double eps_d = ea + er * cinv * fmax(v[4], fmax(v[5], v[6]));
+        const bool prim_ok = (m == 0) || (pri < eps_p), dual_ok = dua < eps_d;
+        if (prim_ok && dual_ok) { status = approximate ? SCO_QP_SOLVED_INACCURATE : SCO_QP_SOLVED; break; }
+        if (!prim_ok) {            // primal infeasibility certificate from delta_y
+          double r1[1] = {0.0};
+          double dyp[2] = {0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+            if (r_i[q] >= 0) {
+              double dy = sdy[r_i[q]];
+              if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
+                if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
+              } else if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
+              sdy[r_i[q]] = dy; dyp[q] = dy;
+              r1[0] = fmax(r1[0], fabs(Eg[r_i[q]] * dy));
+            }
+          lblock_reduce<1, true>(r1, s_red);
+          const double ndy = r1[0];
+          if (ndy > epi) {
+            double lhs[1] = {0.0};
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+              if (r_i[q] >= 0) lhs[0] += r_w[q] * (r_us[q] * fmax(dyp[q], 0.0) + r_ls[q] * fmin(dyp[q], 0.0));
+            lblock_reduce<1, false>(lhs, s_red);
+            if (lhs[0] < -epi * ndy) {
+              __syncthreads();
+#pragma unroll
+              for (int q = 0; q < 2; q++) if (r_i[q] >= 0) swy[r_i[q]] = r_w[q] * dyp[q];
+              __syncthreads();
+              double nat[1] = {0.0};
+              {
+                const double dv = rl_dot_col(wcol, vcol, co, swy);
+                if (cown >= 0) nat[0] = fabs(dv / Dg[cvar]);
+              }
+              if (eown >= 0) nat[0] = fmax(nat[0], fabs((r_ae[0] * (r_w[0] * dyp[0]) + r_ae[1] * (r_w[1] * dyp[1])) / Dg[evar]));
+              lblock_reduce<1, true>(nat, s_red);
+#pragma unroll
+              for (int q = 0; q < 2; q++) if (r_i[q] >= 0) swy[r_i[q]] = r_w[q] * r_y[q];
+              __syncthreads();
+              if (nat[0] < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
+            }
+          }
+        }
+        if (!dual_ok) {            // dual infeasibility certificate from delta_x
+          double r1[1] = {0.0};
+          if (cown >= 0) r1[0] = fabs(Dg[cvar] * dxc);
+          if (eown >= 0) r1[0] = fmax(r1[0], fabs(Dg[evar] * dxe));
+          lblock_reduce<1, true>(r1, s_red);
+          const double ndx = r1[0];
+          if (ndx > edi) {
+            double qdx[1] = {0.0};
+            if (cown >= 0) qdx[0] = qc * dxc;
+            if (eown >= 0) qdx[0] += qe * dxe;
+            lblock_reduce<1, false>(qdx, s_red);
+            if (qdx[0] < -cscale * edi * ndx) {
+              double npx[1] = {0.0};
+              if (cown >= 0) {
+                double px = 0.0;
+                for (int t = a.pc_ptr[cown]; t < a.pc_ptr[cown + 1]; t++) px += Ps[a.pc_pos[t]] * sdxc[a.pc_core[t]];
+                npx[0] = fabs(px / Dg[cvar]);
+              }
+              if (eown >= 0) {
+                const int pd = a.role[(size_t)12 * LT + tid];
+                if (pd >= 0) npx[0] = fmax(npx[0], fabs(Ps[pd] * dxe / Dg[evar]));
+              }
+              lblock_reduce<1, true>(npx, s_red);
+              if (npx[0] < cscale * edi * ndx) {
+                double bad[1] = {0.0};
+                double adc[2];
+                adc[0] = rl_dot_row(wr0, vr0, ro[0], sdxc); adc[1] = rl_dot_row(wr1, vr1, ro[1], sdxc);
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+                  if (r_i[q] >= 0) {
+                    const double adx = (adc[q] + r_ae[q] * dxe) / Eg[r_i[q]];
+                    if ((r_us[q] < SCO_INFTY * SCO_MIN_SCALING && adx > edi * ndx) ||
+                        (r_ls[q] > -SCO_INFTY * SCO_MIN_SCALING && adx < -edi * ndx)) bad[0] = 1.0;
+                  }
+                lblock_reduce<1, true>(bad, s_red);
+                if (bad[0] == 0.0) { status = approximate ? SCO_QP_DUAL_INFEASIBLE_INACCURATE : SCO_QP_DUAL_INFEASIBLE; break; }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!status) status = SCO_QP_MAX_ITER_REACHED;
+  if (iter > a.max_iter) iter = a.max_iter;
+#ifdef SCO_STAMP
+  if ((tid & 63) == 0 && b == 0 && a.stamp) {
+    for (int k = 0; k < 7; k++) a.stamp[(tid >> 6) * 8 + k] = (double)st_acc[k];
+    a.stamp[(tid >> 6) * 8 + 7] = (double)iter;
+  }
+#endif
+  {
+    const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
+    const double cinv = 1.0 / cscale;
+    if (cown >= 0) a.x[(size_t)b * n + cvar] = Dg[cvar] * xcv;
+    if (eown >= 0) a.x[(size_t)b * n + evar] = Dg[evar] * xe;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (r_i[q] >= 0) a.y[(size_t)b * m + r_i[q]] = cinv * Eg[r_i[q]] * r_y[q] * r_w[q];
+    if (tid == 0) {
+      a.status[b] = status; a.iters[b] = iter;
+      a.resid[2 * (size_t)b] = pri; a.resid[2 * (size_t)b + 1] = dua;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// host glue
+// --------------------------------------------------------------------------
+#ifdef SCO_STAMP
+double *sco_debug_stamp_ptr = nullptr;
+extern "C" int sco_debug_stamps(double *out) {      // diagnostic build only
+  if (!sco_debug_stamp_ptr) return -1;
+  return hipMemcpy(out, sco_debug_stamp_ptr, 64 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+template <typename T>
+static int upl(std::vector<void *> &allocs, const std::vector<T> &v, const T **out) {
+  void *p = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  SCO_HIP(hipMalloc(&p, bytes));
+  allocs.push_back(p);
+  if (!v.empty()) SCO_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T *)p;
+  return SCO_OK;
+}
+
+int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd) {
+  int rc;
+  if ((rc = upl(allocs, rh.off, &rd.off))) return rc;
+  if ((rc = upl(allocs, rh.role, &rd.role))) return rc;
+  if ((rc = upl(allocs, rh.Ac.src, &rd.srcAc))) return rc;
+  if ((rc = upl(allocs, rh.Ar0.src, &rd.srcAr0))) return rc;
+  if ((rc = upl(allocs, rh.Ar1.src, &rd.srcAr1))) return rc;
+  if ((rc = upl(allocs, rh.pc_ptr, &rd.pc_ptr))) return rc;
+  if ((rc = upl(allocs, rh.pc_pos, &rd.pc_pos))) return rc;
+  if ((rc = upl(allocs, rh.pc_core, &rd.pc_core))) return rc;
+  return SCO_OK;
+}
+
+template <int TR, int TC>
+static int rl_launch_one(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                108 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC>), dim3(batch), dim3(LT), lds, st, ra);
+  SCO_HIP(hipGetLastError());
+  return SCO_OK;
+}
+
+int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t st) {
+  const QpDev &d = a.d;
+  RlArgs ra;
+  ra.n = d.n; ra.m = d.m; ra.n_e = d.n_e; ra.n_c = d.n_c; ra.nnzA = d.nnzA; ra.nnzP = d.nnzP;
+  ra.max_iter = a.max_iter; ra.check = a.check;
+  ra.sigma = a.sigma; ra.alpha = a.alpha; ra.eps_abs = a.eps_abs; ra.eps_rel = a.eps_rel;
+  ra.eps_prim_inf = a.eps_prim_inf; ra.eps_dual_inf = a.eps_dual_inf;
+  ra.off = rd.off; ra.role = rd.role; ra.srcAc = rd.srcAc; ra.srcAr0 = rd.srcAr0; ra.srcAr1 = rd.srcAr1;
+  ra.pc_ptr = rd.pc_ptr; ra.pc_pos = rd.pc_pos; ra.pc_core = rd.pc_core;
+  ra.totAc = rh.Ac.total; ra.totAr0 = rh.Ar0.total; ra.totAr1 = rh.Ar1.total;
+  ra.As = d.As; ra.W = d.W; ra.qs = d.qs; ra.kee_inv = d.kee_inv; ra.ls = d.ls; ra.us = d.us; ra.rho = d.rho;
+  ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
+  ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
+  ra.stamp = nullptr;
+#ifdef SCO_STAMP
+  {
+    static double *g_stamp = nullptr;
+    if (!g_stamp) { SCO_HIP(hipMalloc((void **)&g_stamp, 64 * sizeof(double))); SCO_HIP(hipMemset(g_stamp, 0, 64 * sizeof(double))); }
+    ra.stamp = g_stamp;
+    extern double *sco_debug_stamp_ptr; sco_debug_stamp_ptr = g_stamp;
+  }
+#endif
+  switch (rh.TR * 100 + rh.TC) {
+    case 102: return rl_launch_one<1, 2>(ra, d.batch, rh.lds_bytes, st);
+    case 204: return rl_launch_one<2, 4>(ra, d.batch, rh.lds_bytes, st);
+    case 306: return rl_launch_one<3, 6>(ra, d.batch, rh.lds_bytes, st);
+    case 408: return rl_launch_one<4, 8>(ra, d.batch, rh.lds_bytes, st);
+    case 509: return rl_launch_one<5, 9>(ra, d.batch, rh.lds_bytes, st);
+    case 510: return rl_launch_one<5, 10>(ra, d.batch, rh.lds_bytes, st);
+  }
+  sco_set_error("rl_launch: unsupported tile");
+  return SCO_ERR_CAPACITY;
+}

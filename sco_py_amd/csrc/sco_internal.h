@@ -86,9 +86,25 @@ bool reg_plan_build(const QpPlan &pl, int CW, int RW, int PX, RegHost &rh);
 int reg_upload(const RegHost &rh, std::vector<void *> &allocs, RegDev &rd);
 int reg_launch(const AdmmArgs &a, const RegHost &rh, const RegDev &rd, hipStream_t st);
 
+// ---- row-local ADMM path (sco_admm_rl.hip): the coupling block never materialises
+struct RlHost {
+  int TR = 1, TC = 2;
+  SellHost Ac, Ar0, Ar1;
+  size_t lds_bytes = 0;
+  std::vector<unsigned short> off;
+  std::vector<int> role, pc_ptr, pc_pos, pc_core;
+};
+struct RlDev { const unsigned short *off; const int *role, *srcAc, *srcAr0, *srcAr1, *pc_ptr, *pc_pos, *pc_core; };
+bool rl_plan_build(const QpPlan &pl, RlHost &rh);
+int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd);
+int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t st);
+
 struct sco_qp {
   int device = 0;
   QpPlan plan;
+  RlHost rl;
+  RlDev rld{};
+  bool use_rl = false;
   RegHost reg;
   RegDev regd{};
   bool use_reg = false;

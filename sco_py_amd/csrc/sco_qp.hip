@@ -616,6 +616,14 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
   SCO_HIP(hipFuncSetAttribute((const void *)qp_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   {
+    const char *no_rl = getenv("SCO_QP_NO_RL");
+    if (!(no_rl && no_rl[0] == '1') && rl_plan_build(pl, qp->rl)) {
+      int r_ = rl_upload(qp->rl, qp->allocs, qp->rld);
+      if (r_) return r_;
+      qp->use_rl = true;
+    }
+  }
+  {
     const char *no_reg = getenv("SCO_QP_NO_REG");
     int CW = 0, RW = 0, PX = 0;
     if (!(no_reg && no_reg[0] == '1') && reg_caps_for(pl, &CW, &RW, &PX) && reg_plan_build(pl, CW, RW, PX, qp->reg)) {
@@ -698,7 +706,10 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
   SCO_HIP(hipGetLastError());
   SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
   if (mid) SCO_HIP(hipEventRecord(mid, qp->stream));
-  if (qp->use_reg) {
+  if (qp->use_rl) {
+    int r_ = rl_launch(aa, qp->rl, qp->rld, qp->stream);
+    if (r_) return r_;
+  } else if (qp->use_reg) {
     int r_ = reg_launch(aa, qp->reg, qp->regd, qp->stream);
     if (r_) return r_;
   } else if (qp->use_fast) {
@@ -739,7 +750,7 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
 extern "C" int sco_qp_info(const sco_qp *qp, int info[4]) {
   if (!qp || !info) return SCO_ERR_ARG;
   info[0] = qp->plan.n_e; info[1] = qp->plan.n_c;
-  info[2] = (int)(qp->use_reg ? 44032 + qp->reg.lds_bytes : (qp->use_fast ? qp->fast.lds_bytes : qp->lds_admm)); info[3] = qp->plan.ncpl;
+  info[2] = (int)(qp->use_rl ? 30208 + qp->rl.lds_bytes : qp->use_reg ? 44032 + qp->reg.lds_bytes : (qp->use_fast ? qp->fast.lds_bytes : qp->lds_admm)); info[3] = qp->plan.ncpl;
   return SCO_OK;
 }
 

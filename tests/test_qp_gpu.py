@@ -83,11 +83,14 @@ def test_7x20_shape_batch(gpu):
     assert info["lds_admm"] <= 160 * 1024                       # fits the CU's LDS
 
 
-def test_three_admm_kernel_tiers_agree(gpu, monkeypatch):
-    """register-offset kernel (default) vs LDS sliced-ELL kernel vs generic kernel."""
+def test_all_admm_kernel_tiers_agree(gpu, monkeypatch):
+    """row-local kernel (default) vs register-offset vs LDS sliced-ELL vs generic kernel."""
     rng = np.random.default_rng(17)
     probs = [penalty_qp(rng, 6, 3, 4) for _ in range(4)] + [penalty_qp(rng, 6, 3, 4, )]
+    _, x_rl, st_rl, it_rl = _check(probs)
+    monkeypatch.setenv("SCO_QP_NO_RL", "1")
     _, x_reg, st_reg, it_reg = _check(probs)
+    assert np.array_equal(st_rl, st_reg) and np.array_equal(it_rl, it_reg) and np.abs(x_rl - x_reg).max() < 1e-10
     monkeypatch.setenv("SCO_QP_NO_REG", "1")
     _, x_sell, st_sell, it_sell = _check(probs)
     monkeypatch.setenv("SCO_QP_NO_FAST", "1")
