@@ -99,9 +99,23 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh);
 int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd);
 int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t st);
 
+// ---- big tier (sco_qp_big.hip): everything in HBM/L2, 1024 threads per problem
+struct BigHost {
+  std::vector<int> row_elim, row_epos, er_ptr, er_row, free_rows, pc_ptr, pc_pos, pc_core;
+  size_t ws_doubles = 0;
+};
+struct BigDev { const int *row_elim, *row_epos, *er_ptr, *er_row, *free_rows, *pc_ptr, *pc_pos, *pc_core; double *ws; };
+bool big_plan_build(const QpPlan &pl, BigHost &bh);
+int big_upload(const BigHost &bh, int batch, std::vector<void *> &allocs, BigDev &bd);
+int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, const BigHost &bh, const BigDev &bd,
+               hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2);
+
 struct sco_qp {
   int device = 0;
   QpPlan plan;
+  BigHost big;
+  BigDev bigd{};
+  bool use_big = false;
   RlHost rl;
   RlDev rld{};
   bool use_rl = false;

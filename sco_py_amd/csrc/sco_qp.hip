@@ -583,11 +583,16 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
   qp->lds_setup = setup_lds_doubles(pl) * sizeof(double);
   qp->lds_admm = admm_lds_doubles(n, m, pl.nnzA, pl.n_e, pl.n_c, pl.ncpl) * sizeof(double) + (size_t)m * sizeof(int);
   const size_t lds_cap = 160 * 1024;
-  if (qp->lds_setup > lds_cap || qp->lds_admm > lds_cap || pl.n_c > 4 * SCO_BLOCK) {
-    char buf[256];
-    snprintf(buf, sizeof buf, "sco_qp_create: working set exceeds 160 KiB LDS (setup %zu B, admm %zu B, core %d)",
-             qp->lds_setup, qp->lds_admm, pl.n_c);
-    delete qp; sco_set_error(buf); return SCO_ERR_CAPACITY;
+  const char *force_big = getenv("SCO_QP_FORCE_BIG");
+  if (qp->lds_setup > lds_cap || qp->lds_admm > lds_cap || pl.n_c > SCO_BLOCK || (force_big && force_big[0] == '1')) {
+    // working set beyond a CU's LDS: the global-memory tier (sco_qp_big.hip)
+    if (pl.n_c > 1024 || !big_plan_build(pl, qp->big)) {
+      char buf[256];
+      snprintf(buf, sizeof buf, "sco_qp_create: pattern not supported (setup %zu B, admm %zu B of LDS, core %d)",
+               qp->lds_setup, qp->lds_admm, pl.n_c);
+      delete qp; sco_set_error(buf); return SCO_ERR_CAPACITY;
+    }
+    qp->use_big = true;
   }
   if (stream) { qp->stream = stream; qp->own_stream = false; }
   else { SCO_HIP(hipStreamCreate(&qp->stream)); qp->own_stream = true; }
@@ -615,6 +620,12 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
 #undef AL
   SCO_HIP(hipFuncSetAttribute((const void *)qp_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+  if (qp->use_big) {
+    int r_ = big_upload(qp->big, batch, qp->allocs, qp->bigd);
+    if (r_) return r_;
+    *out = qp;
+    return SCO_OK;
+  }
   {
     const char *no_rl = getenv("SCO_QP_NO_RL");
     if (!(no_rl && no_rl[0] == '1') && rl_plan_build(pl, qp->rl)) {
@@ -702,6 +713,12 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
               st->max_iter, st->check_termination};
   SCO_HIP(hipEventRecord(qp->ev[0], qp->stream));
+  if (qp->use_big) {
+    int r_ = big_launch(aa, st->scaling, qp->Pp_dev, qp->Pi_dev, qp->big, qp->bigd, qp->stream, qp->ev[1], mid);
+    if (r_) return r_;
+    SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
+    return SCO_OK;
+  }
   hipLaunchKernelGGL(qp_setup_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_setup, qp->stream, sa);
   SCO_HIP(hipGetLastError());
   SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
@@ -750,7 +767,7 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
 extern "C" int sco_qp_info(const sco_qp *qp, int info[4]) {
   if (!qp || !info) return SCO_ERR_ARG;
   info[0] = qp->plan.n_e; info[1] = qp->plan.n_c;
-  info[2] = (int)(qp->use_rl ? 30208 + qp->rl.lds_bytes : qp->use_reg ? 44032 + qp->reg.lds_bytes : (qp->use_fast ? qp->fast.lds_bytes : qp->lds_admm)); info[3] = qp->plan.ncpl;
+  info[2] = (int)(qp->use_big ? 0 : qp->use_rl ? 30208 + qp->rl.lds_bytes : qp->use_reg ? 44032 + qp->reg.lds_bytes : (qp->use_fast ? qp->fast.lds_bytes : qp->lds_admm)); info[3] = qp->plan.ncpl;
   return SCO_OK;
 }
 

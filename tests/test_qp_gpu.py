@@ -184,3 +184,25 @@ def test_results_are_run_to_run_deterministic(gpu):
         qp.load(Pval, q, Aval, l, u)
         outs.append(qp.solve()); qp.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][3], outs[1][3])
+
+
+def test_global_memory_tier_matches_oracle(gpu, monkeypatch):
+    """sco_qp_big.hip (forced): the tier BASELINE config 5 (12-DOF x 50) runs on."""
+    monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    rng = np.random.default_rng(41)
+    probs = [penalty_qp(rng, 6, 3, 4) for _ in range(3)]
+    m = len(probs[0][3])
+    w = np.ones((3, m), dtype=np.int32); w[:, 3:3 + 24] = 2
+    info, x_big, st_big, it_big = _check(probs, w=w)
+    assert info["lds_admm"] == 0
+    monkeypatch.delenv("SCO_QP_FORCE_BIG")
+    _, x_rl, st_rl, it_rl = _check(probs, w=w)
+    assert np.array_equal(st_big, st_rl) and np.array_equal(it_big, it_rl) and np.abs(x_big - x_rl).max() < 1e-10
+
+
+def test_global_memory_tier_infeasible_status(gpu, monkeypatch):
+    monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    A = np.array([[1.0], [1.0]])
+    prim = (np.array([[1.0]]), np.array([0.0]), A, np.array([1.0, -np.inf]), np.array([np.inf, 0.0]))
+    _, _, st, _ = _check([prim])
+    assert st[0] == -3

@@ -125,3 +125,25 @@ def test_descriptor_validation(gpu):
         with pytest.raises(_lib.ScoHipError) as e:
             tb.solve()                     # solve before load
         assert e.value.code == -4
+
+
+def test_sqp_through_the_global_memory_tier(gpu, monkeypatch):
+    monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    arrays, probs = af.make_batch(3, **SMALL)
+    _compare(sb.solve_batch(arrays), probs, range(3))
+
+
+def test_12dof_50step_problem_against_stored_oracle_run(gpu):
+    """BASELINE configs[4]: 12-DOF x 50 timesteps, 5000 non-linear rows (n = 5600,
+    m = 10 624).  The oracle needs minutes on a CPU for this size, so its answer is a
+    committed fixture (tests/golden/trajopt_12x50_oracle.npz, made by
+    tests/golden/make_big_oracle.py)."""
+    path = os.path.join(GOLD, "trajopt_12x50_oracle.npz")
+    g = np.load(path)
+    arrays, _ = af.make_batch(1, d=12, T=50, K=10, O=10)
+    res = sb.solve_batch(arrays)
+    tr = res.trace[0]
+    assert np.array_equal(tr[:, 0], g["trace"][:, 0])                 # same decisions
+    assert np.array_equal(tr[:, 6:8], g["trace"][:, 6:8])             # same QP status / iterations
+    assert np.abs(res.x[0] - g["x"]).max() < TOL
+    assert bool(res.success[0]) == bool(g["success"])
