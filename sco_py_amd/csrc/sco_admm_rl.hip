@@ -468,6 +468,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   while (!status && iter < a.max_iter) {
     int next = a.max_iter;
     if (a.check > 0) { next = (iter / a.check + 1) * a.check; if (next > a.max_iter) next = a.max_iter; }
+    // four iterations per trip: a loop trip costs several hundred cycles of refetch (profiles/r01_v6_stamps.txt)
+    while (iter + 4 < next) { iter += 4; step(false); step(false); step(false); step(false); }
     while (iter + 1 < next) { iter++; step(false); }
     iter++; step(true);
     {
