@@ -61,9 +61,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    # rehearsal on a 1-GPU box: SCO_BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo
+    # (RCCL refuses two ranks on one device); the driver's real multi-GPU run never sets it
+    rehearse = os.environ.get("SCO_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE %d; launch with torch.distributed.run" % (args.gpus, world),
@@ -130,7 +138,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
