@@ -145,6 +145,11 @@ typedef struct sco_sqp_params {
                                (prob.py:508-509) -> row multiplicity k                 */
   int max_sqp_iters;        /* safety cap on QP solves per problem; the reference's
                                loops are unbounded (solver.py:126, 136), 0 = 10000     */
+  int memoize_rounded;      /* Q3: Expr.eval and Eq/LEqExpr.convexify memoise on the point
+                               rounded to 6 decimals (expr.py:13, 31-41, 323-332, 362-371): a
+                               point within rounding of an earlier one reuses that point's
+                               f values / affine model.  1 = reproduce (default)            */
+  int reserved;
 } sco_sqp_params;
 
 void sco_sqp_default_params(sco_sqp_params *p);

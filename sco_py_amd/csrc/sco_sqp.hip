@@ -58,6 +58,12 @@ struct SqpDev {
   int *active, *n_active;
   const int *jpos;   // [T*d] CSC position of J[t][0][j] in qp1's A values
   const int *bpos;   // CSC positions are not needed for bounds: rows are contiguous
+  // Q3 emulation: per timestep block, the points already seen (keys = rint(x * 1e6), the
+  // reference's tuple(x.round(6))) with their f values, and the points already
+  // convexified with their affine model
+  int H, HC;
+  double *hkey, *hval, *ckey, *cJ, *cb;   // [B][T][H][d], [B][T][H][R], [B][T][HC][d], [B][T][HC][R*d], [B][T][HC][R]
+  int *hn, *cn;                            // [B][T]
 };
 
 struct sco_sqp {
@@ -148,6 +154,17 @@ __device__ __forceinline__ double arm_row_grad(const double *th, const double *l
   return -(dx * sx + dy * sy) / sqrt(dx * dx + dy * dy);
 }
 
+// index of the stored point whose rounded key equals that of x (d coordinates), or -1
+__device__ __forceinline__ int memo_find(const double *keys, int count, int d, const double *x) {
+  for (int h = 0; h < count; h++) {
+    const double *k = keys + (size_t)h * d;
+    bool same = true;
+    for (int j = 0; j < d; j++) same = same && (k[j] == rint(x[j] * 1e6));
+    if (same) return h;
+  }
+  return -1;
+}
+
 __device__ __forceinline__ double traj_obj_partial(const double *x, int d, int T, int tid) {
   double s = 0.0;
   for (int e = tid; e < (T - 1) * d; e += SCO_BLOCK) {
@@ -188,13 +205,14 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
     sc.slack_cost = 1.0; sc.merit = 0.0; sc.merit_viol = 0.0;
     s.active[b] = 1;
   }
+  for (int t = tid; t < s.T; t += SCO_BLOCK) { s.hn[(size_t)b * s.T + t] = 0; s.cn[(size_t)b * s.T + t] = 0; }
 }
 
 struct SqpParamsDev {
   double improve_ratio_threshold, min_trust_region_size, min_approx_improve, trust_shrink_ratio,
       trust_expand_ratio, cnt_tolerance, merit_coeff_increase_ratio, initial_trust_region_size,
       initial_penalty_coeff;
-  int max_merit_coeff_increases, compound_penalty, duplicate_rows, max_qp_solves;
+  int max_merit_coeff_increases, compound_penalty, duplicate_rows, max_qp_solves, memo;
 };
 
 __device__ __forceinline__ void trace_row(const SqpDev &s, int b, SqpScalars &sc, int kind, double merit,
@@ -284,19 +302,39 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
   double slack_cost = sc.slack_cost;
 
   if (state == ST_CONVEXIFY) {
-    // S1: f(x) per row (expr.py:34-41)
+    // Q3: which blocks sit on an already-seen / already-convexified rounded point
+    __shared__ int ev_hit[256], cv_hit[256];
+    const int H = s.H, HC = s.HC;
+    double *hkey = s.hkey + (size_t)b * T * H * d, *hval = s.hval + (size_t)b * T * H * R;
+    double *ckey = s.ckey + (size_t)b * T * HC * d, *cJ = s.cJ + (size_t)b * T * HC * R * d, *cb = s.cb + (size_t)b * T * HC * R;
+    int *hn = s.hn + (size_t)b * T, *cn = s.cn + (size_t)b * T;
+    for (int t = tid; t < T; t += SCO_BLOCK) {
+      ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * d, hn[t], d, x + t * d) : -1;
+      cv_hit[t] = p.memo ? memo_find(ckey + (size_t)t * HC * d, cn[t], d, x + t * d) : -1;
+    }
+    __syncthreads();
+    // S1: f(x) per row, memoised on the rounded point (expr.py:34-41)
     for (int e = tid; e < T * R; e += SCO_BLOCK) {
       const int t = e / R, r = e % R, kp = r / O, o = r % O;
-      gs[e] = arm_row(x + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
+      double g;
+      if (ev_hit[t] >= 0) g = hval[((size_t)t * H + ev_hit[t]) * R + r];
+      else {
+        g = arm_row(x + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
+        if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * R + r] = g;
+      }
+      gs[e] = g;
     }
-    // S1: Jacobian entry per thread (expr.py:61-69 numeric / :88 analytic)
+    // S1/S2: Jacobian entry per thread (expr.py:61-69 numeric / :88 analytic); a block whose
+    // rounded point was convexified before reuses that affine model (expr.py:362-365)
     for (int e = tid; e < T * R * d; e += SCO_BLOCK) {
       const int j = e % d, r = (e / d) % R, t = e / (d * R), kp = r / O, o = r % O;
       const double *th = x + t * d;
       const int lk = s.point_link[kp];
       const double fr = s.point_frac[kp], cx = obs[3 * o], cy = obs[3 * o + 1], rad = obs[3 * o + 2];
       double val;
-      if (s.analytic_jac) {
+      if (cv_hit[t] >= 0) {
+        val = cJ[(((size_t)t * HC + cv_hit[t]) * R + r) * d + j];
+      } else if (s.analytic_jac) {
         val = arm_row_grad(th, len, lk, fr, cx, cy, j);
       } else {
         // central differences on a halving ladder + Richardson extrapolation
@@ -320,6 +358,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         val = tab[FD_LEVELS - 1];
       }
       J[e] = val;
+      if (p.memo && cv_hit[t] < 0 && cn[t] < HC) cJ[(((size_t)t * HC + cn[t]) * R + r) * d + j] = val;
       if (!spawned) mask[e] = (val != 0.0) ? 1 : 0;   // creation-time pattern (prob.py:264, 440)
     }
     __syncthreads();
@@ -333,7 +372,10 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
       const int t = e / R;
       double acc = 0.0;
       for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * x[t * d + j];
-      const double bb = gs[e] - acc;
+      double bb = gs[e] - acc;
+      const int r_ = e % R;
+      if (cv_hit[t] >= 0) bb = cb[((size_t)t * HC + cv_hit[t]) * R + r_];
+      else if (p.memo && cn[t] < HC) cb[((size_t)t * HC + cn[t]) * R + r_] = bb;
       bm[e] = bb;
       u[s.m_lin + e] = -bb;            // -inf <= a x - t <= -b  (prob.py:265-275, 486)
       w[s.m_lin + e] = k_rows;         // row present k times (prob.py:508-509)
@@ -349,6 +391,18 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     for (int e = tid; e < T * R; e += SCO_BLOCK) v[1] += fmax(gs[e], 0.0);
     block_reduce_sm<2, 0>(v, red);
     for (int i = tid; i < n_x; i += SCO_BLOCK) xs[i] = x[i];
+    // commit the new history entries (keys last, after every value has been written)
+    if (p.memo)
+      for (int t = tid; t < T; t += SCO_BLOCK) {
+        if (ev_hit[t] < 0 && hn[t] < H) {
+          for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(x[t * d + j] * 1e6);
+          hn[t] += 1;
+        }
+        if (cv_hit[t] < 0 && cn[t] < HC) {
+          for (int j = 0; j < d; j++) ckey[((size_t)t * HC + cn[t]) * d + j] = rint(x[t * d + j] * 1e6);
+          cn[t] += 1;
+        }
+      }
     if (tid == 0) {
       sc.merit_viol = v[1];
       sc.merit = v[0] + penalty * v[1];
@@ -385,17 +439,37 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   const int qp_solves0 = sc.qp_solves;
   const bool ok = (status == 1 || status == 2);                 // prob.py:197
   const double *xq = ok ? (q1.x + (size_t)b * n) : xs;          // failed QP leaves the variables alone
-  // model violation uses the FULL Jacobian (prob.py:627-628), new violation fresh f (prob.py:575-577)
+  // Q3: blocks of the trial point that round onto an already-seen point reuse its f values
+  __shared__ int ev_hit[256];
+  const int H = s.H;
+  double *hkey = s.hkey + (size_t)b * T * H * d, *hval = s.hval + (size_t)b * T * H * R;
+  int *hn = s.hn + (size_t)b * T;
+  for (int t = tid; t < T; t += SCO_BLOCK)
+    ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * d, hn[t], d, xq + t * d) : -1;
+  __syncthreads();
+  // model violation uses the FULL Jacobian (prob.py:627-628), new violation f at the new point (prob.py:575-577)
   double v[4] = {traj_obj_partial(xq, d, T, tid), 0.0, 0.0, 0.0};
   for (int e = tid; e < T * R; e += SCO_BLOCK) {
     const int t = e / R, r = e % R, kp = r / O, o = r % O;
     double acc = 0.0;
     for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * xq[t * d + j];
     v[1] += fmax(acc + bm[e], 0.0);
-    const double g = arm_row(xq + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
+    double g;
+    if (ev_hit[t] >= 0) g = hval[((size_t)t * H + ev_hit[t]) * R + r];
+    else {
+      g = arm_row(xq + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
+      if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * R + r] = g;
+    }
     v[2] += fmax(g, 0.0);
     v[3] = fmax(v[3], fmax(gs[e], 0.0));                        // max violation at the SAVED point
   }
+  __syncthreads();
+  if (p.memo)
+    for (int t = tid; t < T; t += SCO_BLOCK)
+      if (ev_hit[t] < 0 && hn[t] < H) {
+        for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(xq[t * d + j] * 1e6);
+        hn[t] += 1;
+      }
   block_reduce_sm<3, 1>(v, red);
   const double model_merit = v[0] + pen * v[1], new_merit = v[0] + pen * v[2];
   double approx = merit - model_merit;
@@ -468,6 +542,7 @@ extern "C" void sco_sqp_default_params(sco_sqp_params *p) {
   p->trust_shrink_ratio = 0.1; p->trust_expand_ratio = 1.5; p->cnt_tolerance = 1e-4;
   p->merit_coeff_increase_ratio = 10.0; p->initial_trust_region_size = 1.0; p->initial_penalty_coeff = 1e3;
   p->max_merit_coeff_increases = 1; p->compound_penalty = 1; p->duplicate_rows = 1; p->max_sqp_iters = 0;
+  p->memoize_rounded = 1; p->reserved = 0;
 }
 
 template <typename T>
@@ -484,7 +559,7 @@ static int sq_alloc(sco_sqp *h, size_t count, T **out) {
 extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
   if (!desc || !out) { sco_set_error("sco_sqp_create: null pointer"); return SCO_ERR_ARG; }
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
-      desc->family != SCO_FAM_ARM_CIRCLES) {
+      desc->horizon > 256 || desc->family != SCO_FAM_ARM_CIRCLES) {
     sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
   }
   int ndev = 0;
@@ -558,6 +633,9 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
   AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
   AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
   AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, 1)
+  s.H = 40; s.HC = 24;
+  AL(hkey, (size_t)B * T * s.H * d) AL(hval, (size_t)B * T * s.H * R) AL(ckey, (size_t)B * T * s.HC * d)
+  AL(cJ, (size_t)B * T * s.HC * R * d) AL(cb, (size_t)B * T * s.HC * R) AL(hn, (size_t)B * T) AL(cn, (size_t)B * T)
 #undef AL
   { int *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_link = p; }
   { double *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_frac = p; }
@@ -620,7 +698,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
                  params->trust_shrink_ratio, params->trust_expand_ratio, params->cnt_tolerance,
                  params->merit_coeff_increase_ratio, params->initial_trust_region_size, params->initial_penalty_coeff,
                  params->max_merit_coeff_increases, params->compound_penalty, params->duplicate_rows,
-                 params->max_sqp_iters > 0 ? params->max_sqp_iters : 10000};
+                 params->max_sqp_iters > 0 ? params->max_sqp_iters : 10000, params->memoize_rounded ? 1 : 0};
   const dim3 grid(s.batch), block(SCO_BLOCK);
   size_t ec = 0;
   std::vector<int> stage;   // stage id of the interval that ENDS at event i

@@ -46,13 +46,13 @@ def test_default_settings_are_the_reference_values():
     assert (p.trust_shrink_ratio, p.trust_expand_ratio, p.cnt_tolerance) == (0.1, 1.5, 1e-4)
     assert (p.max_merit_coeff_increases, p.merit_coeff_increase_ratio) == (1, 10.0)
     assert (p.initial_trust_region_size, p.initial_penalty_coeff) == (1.0, 1e3)
-    assert (p.compound_penalty, p.duplicate_rows) == (1, 1)
+    assert (p.compound_penalty, p.duplicate_rows, p.memoize_rounded) == (1, 1, 1)
 
 
 def test_struct_layouts_match_the_c_side():
     # sizes the C compiler gives the same declarations
     assert ctypes.sizeof(_lib.QpSettings) == 7 * 8 + 4 * 4
-    assert ctypes.sizeof(_lib.SqpParams) == 9 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.SqpParams) == 9 * 8 + 6 * 4
     assert ctypes.sizeof(_lib.TrajoptDesc) == 8 * 4
 
 

@@ -16,9 +16,9 @@ TOL = 1e-6          # abs, BASELINE.json north_star
 SMALL = dict(d=3, T=6, K=2, O=2)
 
 
-def _compare(res, probs, which, oracle_params=None, analytic=False):
+def _compare(res, probs, which, oracle_params=None, analytic=False, memo=True):
     for b in which:
-        ref = sr.penalty_sqp(sr.trajopt_flat(probs[b], analytic_jac=analytic), oracle_params, emulate_memo=False)
+        ref = sr.penalty_sqp(sr.trajopt_flat(probs[b], analytic_jac=analytic), oracle_params, emulate_memo=memo)
         tr = res.trace[b]
         assert tr.shape == ref.trace.shape, (b, tr.shape, ref.trace.shape)
         assert np.array_equal(tr[:, 0], ref.trace[:, 0]), (b, tr[:, 0], ref.trace[:, 0])      # same decisions
@@ -49,6 +49,18 @@ def test_penalty_escalation_and_custom_knobs(gpu):
               min_trust_region_size=1e-3, improve_ratio_threshold=0.2)
     p = _lib.default_sqp_params(**kw)
     _compare(sb.solve_batch(arrays, params=p), probs, range(6), sr.SolverParams(**kw))
+
+
+def test_memoisation_on_rounded_points_is_reproduced_and_can_be_switched_off(gpu):
+    """Q3 (expr.py:13, 31-41, 323-332): problems 15 and 16 of the 7x20 workload take a different
+    decision (group-converged instead of y-converged) because a block of the point being
+    convexified rounds onto an already convexified point and reuses its old affine model."""
+    arrays, probs = af.make_batch(2, first=15)
+    on = sb.solve_batch(arrays)
+    _compare(on, probs, range(2), memo=True)
+    off = sb.solve_batch(arrays, params=_lib.default_sqp_params(memoize_rounded=0))
+    _compare(off, probs, range(2), memo=False)
+    assert [int(t[-1, 0]) for t in on.trace] == [6, 6] and [int(t[-1, 0]) for t in off.trace] == [3, 3]
 
 
 def test_analytic_jacobian_path(gpu):
