@@ -29,11 +29,15 @@ class OSQPVar(object):
     """One scalar QP variable: name, bounds (the trust region is written here),
     last solver value (osqp_utils.py:17-51)."""
 
+    _created = 0     # creation counter: deterministic tie-break among equal names (all slacks share one)
+
     def __init__(self, var_name, lb=-np.inf, ub=np.inf, val=None):
         self.var_name = var_name
         self._lower_bound = lb
         self._upper_bound = ub
         self.val = val
+        OSQPVar._created += 1
+        self._serial = OSQPVar._created
 
     def __lt__(self, other_osqp_var):
         # ordering by name only: columns of the QP are the name-sorted variables
@@ -118,14 +122,34 @@ def _scalar(v):
     return v if isinstance(v, float) else np.asarray(v, dtype=np.float64).reshape(-1)[0]
 
 
+def fold_repeated_constraints(osqp_lin_cnt_exprs):
+    """The reference appends the SAME penalty-row objects to its constraint list on
+    every update_obj call (prob.py:508-509), so the k-th QP carries k
+    identical copies of each of them.  Identical rows behave in ADMM exactly like one
+    row of multiplicity k, which is what the device ABI takes
+    (`row_weight`).  Returns (unique constraint objects in first-seen order, counts)."""
+    first = {}
+    uniq, count = [], []
+    for cnt in osqp_lin_cnt_exprs:
+        k = first.get(id(cnt))
+        if k is None:
+            first[id(cnt)] = len(uniq)
+            uniq.append(cnt); count.append(1)
+        else:
+            count[k] += 1
+    return uniq, np.asarray(count, dtype=np.int32)
+
+
 def assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs):
     """Returns (P_triu csc, q, A csc, l, u, var_to_index_dict).
 
-    Column order: variables sorted by name, ties in container order
-    (osqp_utils.py:136-142).  Row order: the constraints in list order, then one
-    bound row per variable in container order (osqp_utils.py:173-189)."""
-    ordered = list(osqp_vars)
-    ordered.sort()
+    Column order: variables sorted by name (osqp_utils.py:136-142).  The reference leaves
+    ties (every slack is named "z+_pos_osqp_var") and the order of the bound rows to set
+    iteration, i.e. to object ids; here ties go by creation order and the
+    bound rows follow the columns, so structurally identical problems get identical
+    sparsity patterns (a QP's solution does not depend on either order).
+    Row order: the constraints in list order, then one bound row per variable."""
+    ordered = sorted(osqp_vars, key=lambda v: (v.var_name, getattr(v, "_serial", 0)))
     index = {v: k for k, v in enumerate(ordered)}
     n = len(osqp_vars)
 
@@ -158,7 +182,7 @@ def assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs):
         for k in range(cnt.coeffs.shape[0]):
             cells[(row, index[cnt.osqp_vars[k]])] = cnt.coeffs[k]
     row = len(osqp_lin_cnt_exprs)
-    for v in osqp_vars:
+    for v in ordered:
         cells[(row, index[v])] = 1.0
         l[row] = v.get_lower_bound()
         u[row] = v.get_upper_bound()
@@ -175,18 +199,43 @@ def assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs):
     return P, q, A, l, u, index
 
 
-def _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma):
-    """One QP on the GPU through the C ABI (batch of 1).  Returns (x, status, iters)."""
-    n, m = A.shape[1], A.shape[0]
-    qp = _lib.BatchedQP(1, n, m, P.indptr, P.indices, A.indptr, A.indices)
+def _solve_qp_batch(requests):
+    """Solve a list of QPs that share ONE sparsity pattern and one settings tuple in a
+    single device launch.  Each request is a dict with P, q, A, l, u, w (row weights or
+    None) and settings = (eps_abs, eps_rel, max_iter, rho, sigma).
+    Returns a list of (x, status, iters)."""
+    r0 = requests[0]
+    P0, A0 = r0["P"], r0["A"]
+    n, m = A0.shape[1], A0.shape[0]
+    eps_abs, eps_rel, max_iter, rho, sigma = r0["settings"]
+    B = len(requests)
+    qp = _lib.BatchedQP(B, n, m, P0.indptr, P0.indices, A0.indptr, A0.indices)
     try:
-        qp.load(P.data[None, :], q[None, :], A.data[None, :], l[None, :], u[None, :])
+        Pv = np.stack([r["P"].data for r in requests]) if P0.nnz else np.zeros((B, 0))
+        Av = np.stack([r["A"].data for r in requests]) if A0.nnz else np.zeros((B, 0))
+        w = None
+        if any(r["w"] is not None for r in requests):
+            w = np.stack([r["w"] if r["w"] is not None else np.ones(m, dtype=np.int32) for r in requests])
+        qp.load(Pv, np.stack([r["q"] for r in requests]), Av,
+                np.stack([r["l"] for r in requests]), np.stack([r["u"] for r in requests]), w)
         st = _lib.default_qp_settings(rho=rho, sigma=sigma, eps_abs=eps_abs, eps_rel=eps_rel,
                                       max_iter=int(max_iter))
         x, _y, status, iters, _res = qp.solve(st)
     finally:
         qp.close()
-    return x[0], int(status[0]), int(iters[0])
+    return [(x[b], int(status[b]), int(iters[b])) for b in range(B)]
+
+
+def _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma, w=None):
+    """One QP on the GPU through the C ABI.  Inside ``batching.solve_many`` the call is
+    parked until every concurrently running solve has reached its next QP, and QPs with
+    the same pattern go to the device together.  Returns (x, status, iters)."""
+    req = dict(P=P, q=q, A=A, l=l, u=u, w=w, settings=(eps_abs, eps_rel, max_iter, rho, sigma))
+    from . import batching
+    server = batching.current_server()
+    if server is not None:
+        return server.submit(req)
+    return _solve_qp_batch([req])[0]
 
 
 # @profile
@@ -211,8 +260,12 @@ def optimize(
     if adaptive_rho:
         # the reference default is False (osqp_utils.py:13) and OpenTAMP never enables it
         raise NotImplementedError("adaptive_rho=True is not supported by the MI355X solver")
-    P, q, A, l, u, index = assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs)
-    x, status, iters = _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma)
+    uniq_cnts, counts = fold_repeated_constraints(osqp_lin_cnt_exprs)
+    P, q, A, l, u, index = assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, uniq_cnts)
+    w = None
+    if counts.size and int(counts.max()) > 1:
+        w = np.concatenate([counts, np.ones(len(osqp_vars), dtype=np.int32)])     # bound rows appear once
+    x, status, iters = _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma, w=w)
     solve_res = SimpleNamespace(x=x, info=SimpleNamespace(status_val=status, iter=iters))
     if status == -2 and verbose:
         print("ERROR! OSQP Solver hit max iteration limit. Either reduce your tolerances "

@@ -56,14 +56,19 @@ def oracle_qp_backend(monkeypatch):
     from sco_py_amd.sco_osqp import osqp_utils
     log = []
 
-    def cpu_solve(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma):
-        r = osqp_ref.solve(P, q, A, l, u, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=int(max_iter),
-                           rho=rho, sigma=sigma)
-        log.append(dict(P=P.toarray(), q=q.copy(), A=A.toarray(), l=l.copy(), u=u.copy(), x=r.x.copy(),
-                        status=r.info.status_val, iters=r.info.iter))
-        return r.x, r.info.status_val, r.info.iter
+    def cpu_batch(requests):
+        out = []
+        for rq in requests:
+            eps_abs, eps_rel, max_iter, rho, sigma = rq["settings"]
+            r = osqp_ref.solve(rq["P"], rq["q"], rq["A"], rq["l"], rq["u"], w=rq["w"], eps_abs=eps_abs,
+                               eps_rel=eps_rel, max_iter=int(max_iter), rho=rho, sigma=sigma)
+            log.append(dict(P=rq["P"].toarray(), q=rq["q"].copy(), A=rq["A"].toarray(), l=rq["l"].copy(),
+                            u=rq["u"].copy(), w=None if rq["w"] is None else rq["w"].copy(), x=r.x.copy(),
+                            status=r.info.status_val, iters=r.info.iter))
+            out.append((r.x, r.info.status_val, r.info.iter))
+        return out
 
-    monkeypatch.setattr(osqp_utils, "_solve_qp", cpu_solve)
+    monkeypatch.setattr(osqp_utils, "_solve_qp_batch", cpu_batch)
     return log
 
 
@@ -71,16 +76,17 @@ def oracle_qp_backend(monkeypatch):
 def hip_qp_log(monkeypatch):
     """Record the QPs the mirror API sends through the real HIP seam."""
     from sco_py_amd.sco_osqp import osqp_utils
-    real = osqp_utils._solve_qp
+    real = osqp_utils._solve_qp_batch
     log = []
 
-    def logged(P, q, A, l, u, *a):
-        x, st, it = real(P, q, A, l, u, *a)
-        log.append(dict(P=P.copy(), q=q.copy(), A=A.copy(), l=l.copy(), u=u.copy(), x=x.copy(), status=st, iters=it,
-                        args=a))
-        return x, st, it
+    def logged(requests):
+        res = real(requests)
+        for rq, (x, st, it) in zip(requests, res):
+            log.append(dict(P=rq["P"].copy(), q=rq["q"].copy(), A=rq["A"].copy(), l=rq["l"].copy(), u=rq["u"].copy(),
+                            w=rq["w"], x=x.copy(), status=st, iters=it))
+        return res
 
-    monkeypatch.setattr(osqp_utils, "_solve_qp", logged)
+    monkeypatch.setattr(osqp_utils, "_solve_qp_batch", logged)
     return log
 
 
@@ -119,7 +125,7 @@ def load_golden_qps(g, prefix, sparse=False):
 def expand_weighted_qp(qp):
     """Oracle QP with row multiplicities -> physical rows in the reference's order
     [linear rows, k copies of the penalty rows, bound rows] (prob.py:508-509)."""
-    A, l, u, w = qp["A"], qp["l"], qp["u"], qp["w"]
+    A, l, u, w = qp["A"], qp["l"], qp["u"], qp.get("w")
     if w is None or int(np.max(w)) == 1:
         return qp["P"], qp["q"], A, l, u
     n = qp["q"].shape[0]; m = A.shape[0]; k = int(np.max(w))

@@ -309,3 +309,59 @@ def test_tol_argument_overwrites_thresholds(backend):
     assert s.solve(prob, method="penalty_sqp", tol=1e-3) in (True, False)
     assert (s.min_trust_region_size, s.min_approx_improve, s.cnt_tolerance) == (1e-3, 1e-3, 1e-3)   # Q8
     assert np.allclose(var.get_value(), 1.0, atol=1e-3)
+
+
+# ------------------------------------------------------------------ concurrent solves, batched QPs
+def _small_trajopt_probs(n):
+    import trajopt_build as tb
+    from oracle import arm_family as af
+    return [tb.build_prob(M, af.make_problem(i, d=3, T=6, K=2, O=2)) for i in range(n)]
+
+
+def test_solve_many_equals_sequential_solves_and_batches_the_qps(backend):
+    from sco_py_amd.sco_osqp import batching
+    seq = _small_trajopt_probs(5)
+    seq_ok = [M.Solver().solve(p[0], method="penalty_sqp") for p in seq]
+    par = _small_trajopt_probs(5)
+    par_ok, stats = batching.solve_many([p[0] for p in par])
+    assert par_ok == seq_ok
+    for a, b in zip(seq, par):
+        assert np.abs(a[1].get_value() - b[1].get_value()).max() < 1e-9
+    # 5 problems x 3 QPs each, same pattern at every round: 3 launches instead of 15
+    assert stats["qps"] == 15 and stats["device_launches"] == 3
+
+
+def test_solve_many_handles_problems_that_finish_at_different_times(backend):
+    from sco_py_amd.sco_osqp import batching
+
+    def make(target):
+        prob, var, _ = _one_var_prob(0.0)
+        prob.add_obj_expr(M.BoundExpr(M.QuadExpr(2 * np.eye(1), -2 * target * np.ones((1, 1)), np.zeros((1, 1))), var))
+        if target > 2:          # a non-linear constraint makes this one run more QPs
+            prob.add_cnt_expr(M.BoundExpr(M.LEqExpr(M.Expr(lambda x: x ** 2), np.array([[4.0]])), var))
+        return prob, var
+
+    seq = [make(t) for t in (1.0, 3.0, 0.5)]
+    seq_ok = [M.Solver().solve(p, method="penalty_sqp") for p, _ in seq]
+    items = [make(t) for t in (1.0, 3.0, 0.5)]
+    oks, stats = batching.solve_many([p for p, _ in items])
+    assert oks == seq_ok
+    for (_, a), (_, b) in zip(seq, items):
+        assert np.abs(a.get_value() - b.get_value()).max() < 1e-9
+    assert np.allclose(items[0][1].get_value(), 1.0, atol=1e-4) and np.allclose(items[2][1].get_value(), 0.5, atol=1e-4)
+    assert items[1][1].get_value()[0, 0] ** 2 <= 4.0 + 1e-3          # the constrained one stays feasible
+    assert stats["device_launches"] < stats["qps"]
+
+
+def test_repeated_penalty_rows_are_folded_into_weights(backend):
+    log = None
+    prob, var, _ = _one_var_prob(1.0)
+    prob.add_obj_expr(M.BoundExpr(M.QuadExpr(2 * np.eye(1), -2 * np.ones((1, 1)), np.zeros((1, 1))), var))
+    prob.add_cnt_expr(M.BoundExpr(M.EqExpr(M.Expr(lambda x: x ** 2), np.array([[4.0]])), var))
+    from sco_py_amd.sco_osqp import osqp_utils
+    for k in range(1, 4):
+        prob.convexify(); prob.update_obj(1.0)
+        assert len(prob._osqp_lin_cnt_exprs) == k                  # the reference's list keeps growing (Q2)
+        uniq, counts = osqp_utils.fold_repeated_constraints(prob._osqp_lin_cnt_exprs)
+        assert len(uniq) == 1 and counts.tolist() == [k]           # ... the device sees one row of weight k
+        assert prob.optimize()
