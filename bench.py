@@ -152,7 +152,7 @@ def main():
             with open(tpath) as fh:
                 traffic = json.load(fh)["hbm_bytes_per_launch"]
         out = {
-            "metric": "SCO iters/sec (batch of trajopt QPs)",
+            "metric": "SCO iters/sec (batch of N trajopt QPs)",
             "value": sco_iters / elapsed,
             "unit": "sco_iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
