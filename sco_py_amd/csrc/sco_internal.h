@@ -107,8 +107,19 @@ struct BigHost {
 struct BigDev { const int *row_elim, *row_epos, *er_ptr, *er_row, *free_rows, *pc_ptr, *pc_pos, *pc_core; double *ws; };
 bool big_plan_build(const QpPlan &pl, BigHost &bh);
 int big_upload(const BigHost &bh, int batch, std::vector<void *> &allocs, BigDev &bd);
+// structured variant of the big tier: block-tridiagonal core solve (factors in LDS) and
+// dense row blocks addressed without index arrays
+struct BtHost {
+  int bs = 0, nb = 0, nchunks = 0;
+  size_t blk_doubles = 0, ws_doubles = 0, lds_bytes = 0;
+  std::vector<int> ch_desc, it;     // it: 8 ints per chunk slot (e, j, r0, r1, ep0, ep1, core idx, core pos)
+};
+struct BtDev { const int *ch_desc, *it; double *blk, *ws; };
+bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th);
+int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &td);
+// th/td null = dense route
 int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, const BigHost &bh, const BigDev &bd,
-               hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2);
+               const BtHost *th, const BtDev *td, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2);
 
 struct sco_qp {
   int device = 0;
@@ -116,6 +127,9 @@ struct sco_qp {
   BigHost big;
   BigDev bigd{};
   bool use_big = false;
+  BtHost bt;
+  BtDev btd{};
+  bool use_bt = false;
   RlHost rl;
   RlDev rld{};
   bool use_rl = false;

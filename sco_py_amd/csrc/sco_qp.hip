@@ -593,6 +593,8 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
       delete qp; sco_set_error(buf); return SCO_ERR_CAPACITY;
     }
     qp->use_big = true;
+    const char *no_bt = getenv("SCO_QP_NO_BT");
+    qp->use_bt = !(no_bt && no_bt[0] == '1') && bt_plan_build(pl, qp->big, qp->bt);
   }
   if (stream) { qp->stream = stream; qp->own_stream = false; }
   else { SCO_HIP(hipStreamCreate(&qp->stream)); qp->own_stream = true; }
@@ -615,14 +617,15 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
 #define AL(field, count) { int r_ = dev_alloc(qp, (count), &d.field); if (r_) return r_; }
   AL(Pval, B * pl.nnzP) AL(q, B * n) AL(Aval, B * pl.nnzA) AL(l, B * m) AL(u, B * m) AL(w, B * m)
   AL(Ps, B * pl.nnzP) AL(As, B * pl.nnzA) AL(qs, B * n) AL(ls, B * m) AL(us, B * m) AL(D, B * n) AL(E, B * m)
-  AL(cscale, B) AL(rho, B * m) AL(kee_inv, B * pl.n_e) AL(cpl, B * pl.ncpl) AL(W, B * pl.n_c * pl.n_c)
+  AL(cscale, B) AL(rho, B * m) AL(kee_inv, B * pl.n_e) AL(cpl, B * pl.ncpl) AL(W, (qp->use_bt ? 1 : B) * pl.n_c * pl.n_c)
   AL(x, B * n) AL(y, B * m) AL(resid, B * 2) AL(status, B) AL(iters, B)
 #undef AL
   SCO_HIP(hipFuncSetAttribute((const void *)qp_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   if (qp->use_big) {
-    int r_ = big_upload(qp->big, batch, qp->allocs, qp->bigd);
+    int r_ = big_upload(qp->big, qp->use_bt ? 1 : batch, qp->allocs, qp->bigd);   // dense workspace unused by bt
     if (r_) return r_;
+    if (qp->use_bt && (r_ = bt_upload(qp->bt, batch, qp->allocs, qp->btd))) return r_;
     *out = qp;
     return SCO_OK;
   }
@@ -714,7 +717,8 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
               st->max_iter, st->check_termination};
   SCO_HIP(hipEventRecord(qp->ev[0], qp->stream));
   if (qp->use_big) {
-    int r_ = big_launch(aa, st->scaling, qp->Pp_dev, qp->Pi_dev, qp->big, qp->bigd, qp->stream, qp->ev[1], mid);
+    int r_ = big_launch(aa, st->scaling, qp->Pp_dev, qp->Pi_dev, qp->big, qp->bigd, qp->use_bt ? &qp->bt : nullptr,
+                        qp->use_bt ? &qp->btd : nullptr, qp->stream, qp->ev[1], mid);
     if (r_) return r_;
     SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
     return SCO_OK;
@@ -767,7 +771,7 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
 extern "C" int sco_qp_info(const sco_qp *qp, int info[4]) {
   if (!qp || !info) return SCO_ERR_ARG;
   info[0] = qp->plan.n_e; info[1] = qp->plan.n_c;
-  info[2] = (int)(qp->use_big ? 0 : qp->use_rl ? 30208 + qp->rl.lds_bytes : qp->use_reg ? 44032 + qp->reg.lds_bytes : (qp->use_fast ? qp->fast.lds_bytes : qp->lds_admm)); info[3] = qp->plan.ncpl;
+  info[2] = (int)(qp->use_big ? (qp->use_bt ? qp->bt.lds_bytes : 0) : qp->use_rl ? 30208 + qp->rl.lds_bytes : qp->use_reg ? 44032 + qp->reg.lds_bytes : (qp->use_fast ? qp->fast.lds_bytes : qp->lds_admm)); info[3] = qp->plan.ncpl;
   return SCO_OK;
 }
 

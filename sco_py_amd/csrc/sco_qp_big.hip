@@ -64,7 +64,7 @@ __device__ __forceinline__ double bwsum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-template <int NR, bool IS_MAX>
+template <int NR, bool IS_MAX, int NT = BT>
 __device__ __forceinline__ void bblock_reduce(double (&v)[NR], double *red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -78,7 +78,7 @@ __device__ __forceinline__ void bblock_reduce(double (&v)[NR], double *red) {
 #pragma unroll
   for (int k = 0; k < NR; k++) {
     double r = red[k];
-    for (int w = 1; w < BWV; w++) r = IS_MAX ? fmax(r, red[w * NR + k]) : r + red[w * NR + k];
+    for (int w = 1; w < NT / 64; w++) r = IS_MAX ? fmax(r, red[w * NR + k]) : r + red[w * NR + k];
     v[k] = r;
   }
 }
@@ -95,6 +95,12 @@ struct BigArgs {
   double *ws; size_t ws_stride;
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   int max_iter, check, scaling;
+  // block-tridiagonal core (bt_bs > 0): S goes to block storage instead of the dense array
+  int bt_bs, bt_nb;
+  double *bt_blk; size_t bt_stride;
+  const int *ch_desc, *it;
+  int nchunks;
+  double *stamp;     // diagnostic build only (SCO_STAMP)
 };
 
 // --------------------------------------------------------------------------
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(BT) void qp_setup_big_kernel(BigArgs a) {
   double *ws = a.ws + (size_t)b * a.ws_stride;
   double *Dt = ws;                 // n   (scratch during scaling)
   double *Et = ws + n;             // m   (later: rw)
-  double *S = ws + (a.ws_stride - (size_t)n_c * n_c);   // n_c x n_c
+  double *S = a.bt_bs ? nullptr : ws + (a.ws_stride - (size_t)n_c * n_c);   // n_c x n_c (dense route only)
   const double *Pval = d.Pval + (size_t)b * nnzP, *Aval = d.Aval + (size_t)b * nnzA;
   for (int t = tid; t < nnzP; t += BT) Ps[t] = Pval[t];
   for (int t = tid; t < nnzA; t += BT) As[t] = Aval[t];
@@ -185,7 +191,19 @@ __global__ __launch_bounds__(BT) void qp_setup_big_kernel(BigArgs a) {
     for (int t = d.cp_ptr[k]; t < d.cp_ptr[k + 1]; t++) v += Et[d.cp_row[t]] * As[d.cp_pa[t]] * As[d.cp_pe[t]];
     cpl[k] = v;
   }
-  for (size_t t = tid; t < (size_t)n_c * n_c; t += BT) S[t] = 0.0;
+  const int bs = a.bt_bs;
+  double *blk = bs ? a.bt_blk + (size_t)b * a.bt_stride : nullptr;
+  if (bs) {
+    // block storage [t][0] = S_tt (full), [t][1] = S_{t,t-1}; padding rows get a unit diagonal
+    const int bb = bs * bs;
+    for (size_t t = tid; t < a.bt_stride; t += BT) {
+      const int blkid = (int)(t / (2 * bb)), r = (int)(t % (2 * bb));
+      const int i = r / bs, j = r % bs;
+      blk[t] = (r < bb && i == j && blkid * bs + i >= n_c) ? 1.0 : 0.0;
+    }
+  } else {
+    for (size_t t = tid; t < (size_t)n_c * n_c; t += BT) S[t] = 0.0;
+  }
   __syncthreads();
   for (int id = tid; id < d.nS; id += BT) {
     const int sa = d.s_a[id], sb = d.s_b[id];
@@ -193,8 +211,16 @@ __global__ __launch_bounds__(BT) void qp_setup_big_kernel(BigArgs a) {
     if (d.s_ppos[id] >= 0) v += Ps[d.s_ppos[id]];
     for (int t = d.sa_ptr[id]; t < d.sa_ptr[id + 1]; t++) v += Et[d.sa_row[t]] * As[d.sa_pa[t]] * As[d.sa_pb[t]];
     for (int t = d.ss_ptr[id]; t < d.ss_ptr[id + 1]; t++) v -= cpl[d.ss_k1[t]] * cpl[d.ss_k2[t]] * kinv[d.ss_e[t]];
-    S[(size_t)sa * n_c + sb] = v;       // lower triangle (sa >= sb)
+    if (bs) {
+      const int ta = sa / bs, tb = sb / bs, i = sa % bs, j = sb % bs;
+      double *base = blk + (size_t)ta * 2 * bs * bs;
+      if (ta == tb) { base[i * bs + j] = v; base[j * bs + i] = v; }
+      else base[bs * bs + i * bs + j] = v;          // ta == tb + 1 (the plan checked the bandwidth)
+    } else {
+      S[(size_t)sa * n_c + sb] = v;       // lower triangle (sa >= sb)
+    }
   }
+  if (bs) return;                        // factorisation: qp_bt_factor_kernel
   __syncthreads();
   // Cholesky S = L L' on the lower triangle (left-looking; every thread recomputes the pivot)
   for (int j = 0; j < n_c; j++) {
@@ -250,6 +276,116 @@ __device__ __forceinline__ double big_row_core_dot(const QpDev &d, const double 
     if (c >= 0) v += As[d.Rpos[s]] * vec[c];
   }
   return v;
+}
+
+// Termination test on the unscaled residuals + infeasibility certificates (formulas of
+// admm_check in sco_qp.hip); every thread of the workgroup calls it.  Returns the status
+// (0 = keep iterating).
+struct BigChk {
+  const double *As, *Ps, *qs, *ls, *us, *Dg, *Eg, *x, *y, *z, *sdx;
+  double *sdy;
+  const int *w;
+  double cscale;
+};
+template <int NT>
+__device__ int big_check(const BigArgs &a, const BigChk &k, int iter, double *red, double &pri, double &dua) {
+  const QpDev &d = a.d;
+  const int tid = threadIdx.x, n = d.n, m = d.m;
+  const double *As = k.As, *Ps = k.Ps, *qs = k.qs, *ls = k.ls, *us = k.us, *Dg = k.Dg, *Eg = k.Eg;
+  const double *x = k.x, *y = k.y, *z = k.z, *sdx = k.sdx;
+  double *sdy = k.sdy;
+  const int *w = k.w;
+  const double cscale = k.cscale;
+  int status = 0;
+  for (int approximate = 0; approximate < 2 && !status; approximate++) {
+    if (approximate && iter < a.max_iter) break;
+    const double cinv = 1.0 / cscale;
+    double ea = a.eps_abs, er = a.eps_rel, epi = a.eps_prim_inf, edi = a.eps_dual_inf;
+    if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < m; i += NT) {
+      double ax = 0.0;
+      for (int s = d.Rp[i]; s < d.Rp[i + 1]; s++) ax += As[d.Rpos[s]] * x[d.Rj[s]];
+      const double ei = 1.0 / Eg[i];
+      v[0] = fmax(v[0], fabs(ei * (ax - z[i]))); v[1] = fmax(v[1], fabs(ei * z[i])); v[2] = fmax(v[2], fabs(ei * ax));
+    }
+    for (int j = tid; j < n; j += NT) {
+      double px = 0.0, aty = 0.0;
+      for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * x[d.Fi[t]];
+      for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) { const int i = d.Ai[t]; aty += As[t] * y[i] * (double)w[i]; }
+      const double dj = 1.0 / Dg[j];
+      v[3] = fmax(v[3], fabs(dj * (qs[j] + px + aty))); v[4] = fmax(v[4], fabs(dj * qs[j]));
+      v[5] = fmax(v[5], fabs(dj * aty)); v[6] = fmax(v[6], fabs(dj * px));
+    }
+    bblock_reduce<7, true, NT>(v, red);
+    pri = v[0]; dua = cinv * v[3];
+    if (!(pri <= SCO_INFTY) || !(dua <= SCO_INFTY)) { status = SCO_QP_NON_CVX; break; }
+    const double eps_p = ea + er * fmax(v[1], v[2]);
+    const double eps_d = ea + er * cinv * fmax(v[4], fmax(v[5], v[6]));
+    const bool prim_ok = (m == 0) || (pri < eps_p), dual_ok = dua < eps_d;
+    if (prim_ok && dual_ok) { status = approximate ? SCO_QP_SOLVED_INACCURATE : SCO_QP_SOLVED; break; }
+    if (!prim_ok) {
+      double r1[1] = {0.0};
+      for (int i = tid; i < m; i += NT) {
+        double dy = sdy[i];
+        if (us[i] > SCO_INFTY * SCO_MIN_SCALING) {
+          if (ls[i] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
+        } else if (ls[i] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
+        sdy[i] = dy;
+        r1[0] = fmax(r1[0], fabs(Eg[i] * dy));
+      }
+      bblock_reduce<1, true, NT>(r1, red);
+      const double ndy = r1[0];
+      if (ndy > epi) {
+        double lhs[1] = {0.0};
+        for (int i = tid; i < m; i += NT) lhs[0] += (double)w[i] * (us[i] * fmax(sdy[i], 0.0) + ls[i] * fmin(sdy[i], 0.0));
+        bblock_reduce<1, false, NT>(lhs, red);
+        if (lhs[0] < -epi * ndy) {
+          double nat[1] = {0.0};
+          for (int j = tid; j < n; j += NT) {
+            double aty = 0.0;
+            for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) { const int i = d.Ai[t]; aty += As[t] * sdy[i] * (double)w[i]; }
+            nat[0] = fmax(nat[0], fabs(aty / Dg[j]));
+          }
+          bblock_reduce<1, true, NT>(nat, red);
+          if (nat[0] < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
+        }
+      }
+    }
+    if (!dual_ok) {
+      double r1[1] = {0.0};
+      for (int j = tid; j < n; j += NT) r1[0] = fmax(r1[0], fabs(Dg[j] * sdx[j]));
+      bblock_reduce<1, true, NT>(r1, red);
+      const double ndx = r1[0];
+      if (ndx > edi) {
+        double qdx[1] = {0.0};
+        for (int j = tid; j < n; j += NT) qdx[0] += qs[j] * sdx[j];
+        bblock_reduce<1, false, NT>(qdx, red);
+        if (qdx[0] < -cscale * edi * ndx) {
+          double npx[1] = {0.0};
+          for (int j = tid; j < n; j += NT) {
+            double px = 0.0;
+            for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * sdx[d.Fi[t]];
+            npx[0] = fmax(npx[0], fabs(px / Dg[j]));
+          }
+          bblock_reduce<1, true, NT>(npx, red);
+          if (npx[0] < cscale * edi * ndx) {
+            double bad[1] = {0.0};
+            for (int i = tid; i < m; i += NT) {
+              double adx = 0.0;
+              for (int s = d.Rp[i]; s < d.Rp[i + 1]; s++) adx += As[d.Rpos[s]] * sdx[d.Rj[s]];
+              adx /= Eg[i];
+              if ((us[i] < SCO_INFTY * SCO_MIN_SCALING && adx > edi * ndx) ||
+                  (ls[i] > -SCO_INFTY * SCO_MIN_SCALING && adx < -edi * ndx)) bad[0] = 1.0;
+            }
+            bblock_reduce<1, true, NT>(bad, red);
+            if (bad[0] == 0.0) { status = approximate ? SCO_QP_DUAL_INFEASIBLE_INACCURATE : SCO_QP_DUAL_INFEASIBLE; break; }
+          }
+        }
+      }
+    }
+  }
+  return status;
 }
 
 __global__ __launch_bounds__(BT) void qp_admm_big_kernel(BigArgs a) {
@@ -350,93 +486,9 @@ __global__ __launch_bounds__(BT) void qp_admm_big_kernel(BigArgs a) {
     __syncthreads();
     if (!chk) continue;
 
-    for (int approximate = 0; approximate < 2 && !status; approximate++) {
-      if (approximate && iter < a.max_iter) break;
-      const double cinv = 1.0 / cscale;
-      double ea = a.eps_abs, er = a.eps_rel, epi = a.eps_prim_inf, edi = a.eps_dual_inf;
-      if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
-      double v[7] = {0, 0, 0, 0, 0, 0, 0};
-      for (int i = tid; i < m; i += BT) {
-        double ax = 0.0;
-        for (int s = d.Rp[i]; s < d.Rp[i + 1]; s++) ax += As[d.Rpos[s]] * x[d.Rj[s]];
-        const double ei = 1.0 / Eg[i];
-        v[0] = fmax(v[0], fabs(ei * (ax - z[i]))); v[1] = fmax(v[1], fabs(ei * z[i])); v[2] = fmax(v[2], fabs(ei * ax));
-      }
-      for (int j = tid; j < n; j += BT) {
-        double px = 0.0, aty = 0.0;
-        for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * x[d.Fi[t]];
-        for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) { const int i = d.Ai[t]; aty += As[t] * y[i] * (double)w[i]; }
-        const double dj = 1.0 / Dg[j];
-        v[3] = fmax(v[3], fabs(dj * (qs[j] + px + aty))); v[4] = fmax(v[4], fabs(dj * qs[j]));
-        v[5] = fmax(v[5], fabs(dj * aty)); v[6] = fmax(v[6], fabs(dj * px));
-      }
-      bblock_reduce<7, true>(v, red);
-      pri = v[0]; dua = cinv * v[3];
-      if (!(pri <= SCO_INFTY) || !(dua <= SCO_INFTY)) { status = SCO_QP_NON_CVX; break; }
-      const double eps_p = ea + er * fmax(v[1], v[2]);
-      const double eps_d = ea + er * cinv * fmax(v[4], fmax(v[5], v[6]));
-      const bool prim_ok = (m == 0) || (pri < eps_p), dual_ok = dua < eps_d;
-      if (prim_ok && dual_ok) { status = approximate ? SCO_QP_SOLVED_INACCURATE : SCO_QP_SOLVED; break; }
-      if (!prim_ok) {
-        double r1[1] = {0.0};
-        for (int i = tid; i < m; i += BT) {
-          double dy = sdy[i];
-          if (us[i] > SCO_INFTY * SCO_MIN_SCALING) {
-            if (ls[i] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
-          } else if (ls[i] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
-          sdy[i] = dy;
-          r1[0] = fmax(r1[0], fabs(Eg[i] * dy));
-        }
-        bblock_reduce<1, true>(r1, red);
-        const double ndy = r1[0];
-        if (ndy > epi) {
-          double lhs[1] = {0.0};
-          for (int i = tid; i < m; i += BT) lhs[0] += (double)w[i] * (us[i] * fmax(sdy[i], 0.0) + ls[i] * fmin(sdy[i], 0.0));
-          bblock_reduce<1, false>(lhs, red);
-          if (lhs[0] < -epi * ndy) {
-            double nat[1] = {0.0};
-            for (int j = tid; j < n; j += BT) {
-              double aty = 0.0;
-              for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) { const int i = d.Ai[t]; aty += As[t] * sdy[i] * (double)w[i]; }
-              nat[0] = fmax(nat[0], fabs(aty / Dg[j]));
-            }
-            bblock_reduce<1, true>(nat, red);
-            if (nat[0] < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
-          }
-        }
-      }
-      if (!dual_ok) {
-        double r1[1] = {0.0};
-        for (int j = tid; j < n; j += BT) r1[0] = fmax(r1[0], fabs(Dg[j] * sdx[j]));
-        bblock_reduce<1, true>(r1, red);
-        const double ndx = r1[0];
-        if (ndx > edi) {
-          double qdx[1] = {0.0};
-          for (int j = tid; j < n; j += BT) qdx[0] += qs[j] * sdx[j];
-          bblock_reduce<1, false>(qdx, red);
-          if (qdx[0] < -cscale * edi * ndx) {
-            double npx[1] = {0.0};
-            for (int j = tid; j < n; j += BT) {
-              double px = 0.0;
-              for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * sdx[d.Fi[t]];
-              npx[0] = fmax(npx[0], fabs(px / Dg[j]));
-            }
-            bblock_reduce<1, true>(npx, red);
-            if (npx[0] < cscale * edi * ndx) {
-              double bad[1] = {0.0};
-              for (int i = tid; i < m; i += BT) {
-                double adx = 0.0;
-                for (int s = d.Rp[i]; s < d.Rp[i + 1]; s++) adx += As[d.Rpos[s]] * sdx[d.Rj[s]];
-                adx /= Eg[i];
-                if ((us[i] < SCO_INFTY * SCO_MIN_SCALING && adx > edi * ndx) ||
-                    (ls[i] > -SCO_INFTY * SCO_MIN_SCALING && adx < -edi * ndx)) bad[0] = 1.0;
-              }
-              bblock_reduce<1, true>(bad, red);
-              if (bad[0] == 0.0) { status = approximate ? SCO_QP_DUAL_INFEASIBLE_INACCURATE : SCO_QP_DUAL_INFEASIBLE; break; }
-            }
-          }
-        }
-      }
+    {
+      BigChk ck{As, Ps, qs, ls, us, Dg, Eg, x, y, z, sdx, sdy, w, cscale};
+      status = big_check<BT>(a, ck, iter, red, pri, dua);
     }
     __syncthreads();
     if (status) break;
@@ -448,6 +500,566 @@ __global__ __launch_bounds__(BT) void qp_admm_big_kernel(BigArgs a) {
     const double cinv = 1.0 / cscale;
     for (int j = tid; j < n; j += BT) x[j] = Dg[j] * x[j];
     for (int i = tid; i < m; i += BT) y[i] = cinv * Eg[i] * y[i] * (double)w[i];
+    if (tid == 0) {
+      d.status[b] = status; d.iters[b] = iter;
+      d.resid[2 * (size_t)b] = pri; d.resid[2 * (size_t)b + 1] = dua;
+    }
+  }
+}
+
+
+// ==========================================================================
+// Structured tier ("bt"): block-tridiagonal core + dense row blocks
+// ==========================================================================
+// When the Schur complement S of the core is banded (half-bandwidth hb <= 16: a
+// trajectory problem whose cost couples step t with t+1 and whose constraints touch
+// one step each, hb = DOF) it is block tridiagonal with blocks of order BS >= hb, and
+// the dense inverse W (n_c^2 doubles, 2.9 MB at 12x50, streamed from L2 every iteration
+// by the dense route above) is replaced by the block LDL' factors
+//     S = (I + E) D (I + E)',   E_t = S_{t,t-1} D_{t-1}^-1,   D_t = S_tt - E_t S_{t,t-1}'
+// (2 nb BS^2 doubles: 115 KB at 12x50, resident in LDS).  One solve = forward sweep
+// y_t = r_t - E_t y_{t-1} (one wavefront, nb dependent steps), z_t = D_t^-1 y_t (all
+// threads), backward sweep x_t = z_t - E_{t+1}' x_{t+1}.
+//
+// Rows are processed in wavefront-sized chunks.  A "dense" chunk is a run of
+// consecutive rows with the same core columns (one 100 x 12 block of the constraint
+// Jacobian per timestep): its values are addressed as pos0[k] + lane, so the sweep over
+// A reads coalesced lines and no index arrays.  A' t' is formed by scattering the
+// products A_ic t'_i into CSC order (coalesced for the same reason) and summing every
+// core column's contiguous segment with 16 lanes.
+#define CH_STRIDE 16      // kind, nact, ncols, r0, c0, pos0, col stride, e0, j0, r1, ep0, ep0 stride, ep1, ep1 stride, pad, pad
+#define BT_MAXBS 16
+#define BTT 512           // threads of the structured ADMM kernel (256 VGPRs per thread)
+#define BTWV (BTT / 64)
+
+bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th) {
+  int hb = 0;
+  for (int id = 0; id < pl.nS; id++) hb = std::max(hb, pl.s_a[id] - pl.s_b[id]);
+  if (hb > BT_MAXBS || pl.n_c <= 0) return false;
+  th.bs = hb <= 4 ? 4 : hb <= 8 ? 8 : hb <= 12 ? 12 : 16;
+  th.nb = (pl.n_c + th.bs - 1) / th.bs;
+  const size_t ncp = (size_t)th.nb * th.bs;
+  th.blk_doubles = 2 * ncp * th.bs;
+  th.lds_bytes = 8 * (th.blk_doubles + 5 * ncp + 64) + 4 * 3 * ncp;   // factors, r/y/x~/x/q, column metadata (+ chunk descriptors, below)
+  const int m = pl.m;
+  // core entries of every row: (core index, CSC position)
+  auto row_core = [&](int i, std::vector<int> &cols, std::vector<int> &pos) {
+    cols.clear(); pos.clear();
+    for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
+      const int c = pl.core_of[pl.Rj[s]];
+      if (c >= 0) { cols.push_back(c); pos.push_back(pl.Rpos[s]); }
+    }
+  };
+  // one item = an eliminated variable with its (at most two) rows, or a row without one
+  struct Item { int e, j, r0, r1, ep0, ep1; bool dense_ok, simple; std::vector<int> cols, pos; };
+  std::vector<Item> items;
+  std::vector<int> c0, p0, c1, p1;
+  for (int e = 0; e < pl.n_e; e++) {
+    Item it; it.e = e; it.j = pl.elim_var[e]; it.r0 = it.r1 = it.ep0 = it.ep1 = -1; it.dense_ok = false; it.simple = true;
+    const int nr = bh.er_ptr[e + 1] - bh.er_ptr[e];
+    if (nr == 0) { items.push_back(it); continue; }
+    int ra = bh.er_row[bh.er_ptr[e]], rb = nr > 1 ? bh.er_row[bh.er_ptr[e] + 1] : -1;
+    row_core(ra, c0, p0);
+    c1.clear(); p1.clear();
+    if (rb >= 0) { row_core(rb, c1, p1); if (c1.size() > c0.size()) { std::swap(ra, rb); std::swap(c0, c1); std::swap(p0, p1); } }
+    it.r0 = ra; it.r1 = rb; it.ep0 = bh.row_epos[ra]; it.ep1 = rb >= 0 ? bh.row_epos[rb] : -1;
+    // dense: the primary row carries every core entry, in consecutive core columns at a constant CSC stride
+    it.dense_ok = c1.empty() && !c0.empty() && (int)c0.size() <= 16;
+    for (size_t k = 1; it.dense_ok && k < c0.size(); k++)
+      it.dense_ok = c0[k] == c0[0] + (int)k && p0[k] - p0[k - 1] == p0[1] - p0[0];
+    it.cols = c0; it.pos = p0;
+    it.simple = c1.empty() && c0.size() <= 1;
+    items.push_back(it);
+  }
+  th.ch_desc.clear(); th.it.clear();
+  auto push_chunk = [&](int kind, const std::vector<Item> &its, size_t first, size_t cnt) {
+    std::vector<int> dsc(CH_STRIDE, 0);
+    const Item &f = its[first];
+    dsc[0] = kind; dsc[1] = (int)cnt;
+    if (kind == 0) {
+      dsc[2] = (int)f.cols.size(); dsc[3] = f.r0; dsc[4] = f.cols[0]; dsc[5] = f.pos[0];
+      dsc[6] = f.pos.size() > 1 ? f.pos[1] - f.pos[0] : 0;
+      dsc[7] = f.e; dsc[8] = f.j; dsc[9] = f.r1; dsc[10] = f.ep0; dsc[12] = f.ep1;
+      if (cnt > 1) { dsc[11] = its[first + 1].ep0 - f.ep0; dsc[13] = its[first + 1].ep1 - f.ep1; }
+    }
+    th.ch_desc.insert(th.ch_desc.end(), dsc.begin(), dsc.end());
+    for (size_t l = 0; l < 64; l++) {
+      const bool on = l < cnt;
+      const Item *t = on ? &its[first + l] : nullptr;
+      const bool one = on && t->cols.size() == 1;
+      const int rec[8] = {on ? t->e : -1, on ? t->j : -1, on ? t->r0 : -1, on ? t->r1 : -1, on ? t->ep0 : -1,
+                          on ? t->ep1 : -1, one ? t->cols[0] : -1, one ? t->pos[0] : -1};
+      th.it.insert(th.it.end(), rec, rec + 8);
+    }
+  };
+  // dense runs: consecutive eliminated variables whose primary rows are consecutive rows with the
+  // same core columns, and whose every index is an affine function of the position in the run
+  std::vector<Item> generic;
+  size_t i0 = 0;
+  while (i0 < items.size()) {
+    size_t i1 = i0 + 1;
+    if (items[i0].dense_ok) {
+      while (i1 < items.size() && items[i1].dense_ok) {
+        const Item &p = items[i1 - 1], &c = items[i1], &f = items[i0], &g = items[i0 + 1];
+        bool ok = c.r0 == p.r0 + 1 && c.j == p.j + 1 && c.cols == f.cols && (c.r1 < 0) == (f.r1 < 0) &&
+                  (c.r1 < 0 || c.r1 == p.r1 + 1) && c.ep0 - p.ep0 == g.ep0 - f.ep0 && c.ep1 - p.ep1 == g.ep1 - f.ep1;
+        for (size_t k = 0; ok && k < f.pos.size(); k++) ok = c.pos[k] == p.pos[k] + 1;
+        if (!ok) break;
+        i1++;
+      }
+    }
+    if (items[i0].dense_ok && i1 - i0 >= 16) {
+      for (size_t f = i0; f < i1; f += 64) push_chunk(0, items, f, std::min<size_t>(64, i1 - f));
+    } else {
+      for (size_t f = i0; f < i1; f++) generic.push_back(items[f]);
+    }
+    i0 = i1;
+  }
+  for (int i : bh.free_rows) {
+    Item it; it.e = it.j = it.r1 = it.ep0 = it.ep1 = -1; it.r0 = i; it.dense_ok = false; it.simple = true;
+    row_core(i, it.cols, it.pos);
+    if (it.cols.size() > 1) it.simple = false;
+    generic.push_back(it);
+  }
+  // kind 2: items whose rows hold at most one core entry (bound rows, pins) -- direct indices;
+  // kind 1: everything else walks the CSR arrays
+  std::vector<Item> simple, complex_;
+  for (const Item &it : generic) (it.simple ? simple : complex_).push_back(it);
+  for (size_t f = 0; f < simple.size(); f += 64) push_chunk(2, simple, f, std::min<size_t>(64, simple.size() - f));
+  for (size_t f = 0; f < complex_.size(); f += 64) push_chunk(1, complex_, f, std::min<size_t>(64, complex_.size() - f));
+  th.nchunks = (int)(th.ch_desc.size() / CH_STRIDE);
+  th.lds_bytes += 4 * th.ch_desc.size();
+  if (th.lds_bytes + 1024 > 160 * 1024) return false;
+  th.ws_doubles = 3 * (size_t)m + pl.n_e + pl.n + pl.nnzA + 64;
+  return true;
+}
+
+// ---- block LDL' of S in place: [t][0] <- D_t^-1, [t][1] <- E_t ------------------------
+template <int BS>
+__global__ __launch_bounds__(256) void qp_bt_factor_kernel(BigArgs a) {
+  const QpDev &d = a.d;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (d.active && !d.active[b]) return;
+  constexpr int BB = BS * BS;
+  __shared__ double M[BB], Sub[BB], Ev[BB], rowk[BS], colk[BS];
+  double *blk = a.bt_blk + (size_t)b * a.bt_stride;
+  const int i = tid / BS, j = tid % BS;
+  const bool on = tid < BB;
+  if (on) M[tid] = blk[tid];
+  __syncthreads();
+  for (int t = 0; t < a.bt_nb; t++) {
+    // Gauss-Jordan inversion of the symmetric positive definite D_t (no pivoting needed)
+    for (int k = 0; k < BS; k++) {
+      if (tid < BS) {
+        const double piv = M[k * BS + k];
+        rowk[tid] = (tid == k ? 1.0 : M[k * BS + tid]) / piv;
+        colk[tid] = M[tid * BS + k];
+      }
+      __syncthreads();
+      if (on) {
+        const double v = (j == k) ? 0.0 : M[tid];
+        M[tid] = (i == k) ? rowk[j] : v - colk[i] * rowk[j];
+      }
+      __syncthreads();
+    }
+    double *cur = blk + (size_t)t * 2 * BB;
+    if (on) cur[tid] = M[tid];
+    if (t + 1 < a.bt_nb) {
+      double *nxt = cur + 2 * BB;
+      if (on) Sub[tid] = nxt[BB + tid];
+      __syncthreads();
+      if (on) {
+        double e = 0.0;
+#pragma unroll
+        for (int k = 0; k < BS; k++) e += Sub[i * BS + k] * M[k * BS + j];
+        Ev[tid] = e; nxt[BB + tid] = e;
+      }
+      __syncthreads();
+      if (on) {
+        double v = nxt[tid];
+#pragma unroll
+        for (int k = 0; k < BS; k++) v -= Ev[i * BS + k] * Sub[j * BS + k];
+        M[tid] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- ADMM ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double bt_row16_sum(double v) {     // total of a 16-lane DPP row, valid in its lane 15
+  int lo, hi, lo2, hi2;
+#define BT_DPP_STEP(ctrl)                                                                    \
+  lo = __double2loint(v); hi = __double2hiint(v);                                            \
+  lo2 = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, true);                            \
+  hi2 = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, true);                            \
+  v += __hiloint2double(hi2, lo2);
+  BT_DPP_STEP(0x111) BT_DPP_STEP(0x112) BT_DPP_STEP(0x114) BT_DPP_STEP(0x118)
+#undef BT_DPP_STEP
+  return v;
+}
+
+// per-problem pointers of the structured kernel
+struct BtPtrs {
+  const double *As, *rho, *ls, *us, *kinv, *qs;
+  const int *w;
+  double *x, *y, *z, *sdy, *sdx, *ge, *prod;
+  const double *s_xc;
+  double alpha, sigma;
+};
+struct BtRow { double zc, ae, rh, w, z, y, l, u; };
+// one row of the ADMM update; returns t_i = w (rho z+ - y+)
+__device__ __forceinline__ double bt_row_step(const BtRow &r, double alpha, double xte, double &zn, double &yn, double &dy) {
+  const double zt = r.zc + r.ae * xte;
+  const double zr = alpha * zt + (1.0 - alpha) * r.z;
+  zn = zr + (1.0 / r.rh) * r.y;
+  zn = fmin(fmax(zn, r.l), r.u);
+  dy = r.rh * (zr - zn);
+  yn = r.y + dy;
+  return r.w * (r.rh * zn - yn);
+}
+
+// Dense chunk: up to 64 consecutive rows r0 + lane with core entries in columns c0 .. c0 + ncols - 1
+// at CSC positions pos0 + k cs + lane; their eliminated variables e0 + lane (QP variable j0 + lane)
+// each with an optional second row r1 + lane that has no core entry.  Every address is a
+// descriptor scalar plus the lane and every load is unconditional (absent pieces re-read a valid
+// address and are masked afterwards), so a chunk costs one memory round trip; two chunks are
+// kept in flight per wavefront.
+template <int NC>
+struct BtDenseRegs {
+  double av[NC];
+  BtRow p, s;
+  double g, ki, xo, qj;
+  int r0, r1, e, j, ncols, pos0, cs, c0;
+  bool two;
+};
+template <int NC>
+__device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int lane, const BtPtrs &q, BtDenseRegs<NC> &R) {
+  R.ncols = dsc[2]; R.pos0 = dsc[5]; R.cs = dsc[6]; R.c0 = dsc[4];
+  R.r0 = dsc[3] + lane; R.e = dsc[7] + lane; R.j = dsc[8] + lane;
+  R.two = dsc[9] >= 0;
+  R.r1 = R.two ? dsc[9] + lane : R.r0;
+#pragma unroll
+  for (int k = 0; k < NC; k++) R.av[k] = q.As[R.pos0 + (k < R.ncols ? k : 0) * R.cs + lane];
+  const int ep0 = dsc[10] + dsc[11] * lane, ep1 = R.two ? dsc[12] + dsc[13] * lane : ep0;
+  R.p = BtRow{0.0, q.As[ep0], q.rho[R.r0], (double)q.w[R.r0], q.z[R.r0], q.y[R.r0], q.ls[R.r0], q.us[R.r0]};
+  R.s = BtRow{0.0, q.As[ep1], q.rho[R.r1], (double)q.w[R.r1], q.z[R.r1], q.y[R.r1], q.ls[R.r1], q.us[R.r1]};
+  R.g = q.ge[R.e]; R.ki = q.kinv[R.e]; R.xo = q.x[R.j]; R.qj = q.qs[R.j];
+}
+template <int NC>
+__device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, bool chk, const BtPtrs &q) {
+  const double *xc = q.s_xc + R.c0;
+  double xv[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) xv[k] = xc[k];             // the slack behind s_xc is zero
+  double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < NC; k += 2) {
+    z0 += (k < R.ncols ? R.av[k] : 0.0) * xv[k];
+    z1 += (k + 1 < R.ncols ? R.av[k + 1] : 0.0) * xv[k + 1];
+  }
+  R.p.zc = z0 + z1;
+  if (!R.two) { R.s.ae = 0.0; R.s.w = 0.0; }
+  const double rwp = R.p.w * R.p.rh;
+  const double xte = R.g - R.ki * (rwp * R.p.ae * R.p.zc);         // the second row has no core entry
+  double zn, yn, dy;
+  const double tq0 = bt_row_step(R.p, q.alpha, xte, zn, yn, dy);
+  q.z[R.r0] = zn; q.y[R.r0] = yn; if (chk) q.sdy[R.r0] = dy;
+  double tq1 = 0.0;
+  if (R.two) { tq1 = bt_row_step(R.s, q.alpha, xte, zn, yn, dy); q.z[R.r1] = zn; q.y[R.r1] = yn; if (chk) q.sdy[R.r1] = dy; }
+  const double xn = q.alpha * xte + (1.0 - q.alpha) * R.xo;
+  if (chk) q.sdx[R.j] = xn - R.xo;
+  q.x[R.j] = xn;
+  const double gn = ((q.sigma * xn - R.qj) + R.p.ae * tq0 + R.s.ae * tq1) * R.ki;
+  q.ge[R.e] = gn;
+  const double t0 = tq0 - rwp * R.p.ae * gn;
+#pragma unroll
+  for (int k = 0; k < NC; k++)
+    if (k < R.ncols) q.prod[R.pos0 + k * R.cs + lane] = R.av[k] * t0;
+}
+// chunks A (lanes < nA) and, if nB > 0, B: loads of both before the arithmetic of either
+template <int NC>
+__device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const int (&dB)[CH_STRIDE], int nB, int lane, bool chk,
+                                              const BtPtrs &q) {
+  BtDenseRegs<NC> RA, RB;
+  const bool onA = lane < dA[1], onB = lane < nB;
+  if (onA) bt_dense_load<NC>(dA, lane, q, RA);
+  if (onB) bt_dense_load<NC>(dB, lane, q, RB);
+  if (onA) bt_dense_compute<NC>(RA, lane, chk, q);
+  if (onB) bt_dense_compute<NC>(RB, lane, chk, q);
+}
+
+template <int BS>
+__global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
+  const QpDev &d = a.d;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (d.active && !d.active[b]) return;
+  const int n = d.n, m = d.m, n_e = d.n_e, n_c = d.n_c, nb = a.bt_nb;
+  constexpr int BB = BS * BS;
+  const int ncp = nb * BS;
+  __shared__ double red[BTWV * 8];
+  extern __shared__ double s_dyn[];
+  double *s_blk = s_dyn;                       // [nb][2][BS][BS]: D_t^-1, E_t
+  double *s_r = s_blk + (size_t)nb * 2 * BB;   // core right-hand side, then z
+  double *s_y = s_r + ncp;                     // forward sweep result
+  double *s_x = s_y + ncp;                     // x_C (scaled iterate of the core variables)
+  double *s_q = s_x + ncp;                     // q_C
+  double *s_xc = s_q + ncp;                    // x~_C, followed by 64 zeros
+  int *s_cp0 = (int *)(s_xc + ncp + 64), *s_clen = s_cp0 + ncp, *s_cj = s_clen + ncp, *s_dsc = s_cj + ncp;
+  const double *As = d.As + (size_t)b * d.nnzA, *Ps = d.Ps + (size_t)b * d.nnzP;
+  const double *qs = d.qs + (size_t)b * n, *ls = d.ls + (size_t)b * m, *us = d.us + (size_t)b * m;
+  const double *rho = d.rho + (size_t)b * m, *kinv = d.kee_inv + (size_t)b * n_e;
+  const double *Dg = d.D + (size_t)b * n, *Eg = d.E + (size_t)b * m;
+  const int *w = d.w + (size_t)b * m;
+  double *x = d.x + (size_t)b * n, *y = d.y + (size_t)b * m;     // scaled iterates; unscaled at the end
+  double *ws = a.ws + (size_t)b * a.ws_stride;
+  double *z = ws, *tp = z + m, *sdy = tp + m, *ge = sdy + m, *sdx = ge + n_e, *prod = sdx + n;
+  const double cscale = d.cscale[b], alpha = a.alpha, sigma = a.sigma;
+  const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, alpha, sigma};
+
+  {
+    const double *blk = a.bt_blk + (size_t)b * a.bt_stride;
+    for (size_t t = tid; t < (size_t)nb * 2 * BB; t += BTT) s_blk[t] = blk[t];
+    for (int c = tid; c < 5 * ncp + 64; c += BTT) s_r[c] = 0.0;
+    for (int c = tid; c < ncp; c += BTT) {
+      int p0 = 0, len = 0, j = 0;
+      if (c < n_c) { j = d.core_var[c]; p0 = d.Ap[j]; len = d.Ap[j + 1] - p0; }
+      s_cp0[c] = p0; s_clen[c] = len; s_cj[c] = j;
+    }
+    for (int t = tid; t < a.nchunks * CH_STRIDE; t += BTT) s_dsc[t] = a.ch_desc[t];
+  }
+  for (int j = tid; j < n; j += BTT) { x[j] = 0.0; sdx[j] = 0.0; }
+  for (int i = tid; i < m; i += BTT) { z[i] = 0.0; y[i] = 0.0; tp[i] = 0.0; sdy[i] = 0.0; }
+  __syncthreads();
+  for (int c = tid; c < n_c; c += BTT) s_q[c] = qs[s_cj[c]];
+  for (int e = tid; e < n_e; e += BTT) {
+    const double g = -qs[d.elim_var[e]] * kinv[e];
+    ge[e] = g;
+    for (int r = a.er_ptr[e]; r < a.er_ptr[e + 1]; r++) {
+      const int i = a.er_row[r];
+      tp[i] = -((double)w[i] * rho[i]) * As[a.row_epos[i]] * g;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < n; j += BTT)
+    for (int p = d.Ap[j]; p < d.Ap[j + 1]; p++) prod[p] = As[p] * tp[d.Ai[p]];
+  __syncthreads();
+
+  int status = 0, iter = 0;
+  double pri = 0.0, dua = 0.0;
+#ifdef SCO_STAMP
+  // diagnostic build only: cycles per phase per wavefront (never compiled into the product)
+  long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
+#define BSTAMP(k) { const long long now_ = __builtin_readcyclecounter(); st_acc[k] += now_ - st_t; st_t = now_; }
+#else
+#define BSTAMP(k)
+#endif
+  for (iter = 1; iter <= a.max_iter; iter++) {
+    const bool chk = (a.check > 0 && iter % a.check == 0) || iter == a.max_iter;
+    BSTAMP(11)
+    // (1) core right-hand side: 16 lanes per core column sum its CSC segment of products,
+    //     four columns in flight per lane group
+    for (int c4 = (tid >> 4) * 4; c4 < n_c; c4 += (BTT / 16) * 4) {
+      double pv[4][8];
+      int pp[4], ln[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { pp[u] = s_cp0[c4 + u] + (tid & 15); ln[u] = s_clen[c4 + u] - (tid & 15); }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) pv[u][k] = prod[pp[u] + (16 * k < ln[u] ? 16 * k : 0)];     // unconditional loads
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) pv[u][k] = (16 * k < ln[u]) ? pv[u][k] : 0.0;
+        double v = ((pv[u][0] + pv[u][1]) + (pv[u][2] + pv[u][3])) + ((pv[u][4] + pv[u][5]) + (pv[u][6] + pv[u][7]));
+        for (int k = 128; k < ln[u]; k += 16) v += prod[pp[u] + k];
+        v = bt_row16_sum(v);
+        if ((tid & 15) == 15 && c4 + u < n_c) s_r[c4 + u] = (sigma * s_x[c4 + u] - s_q[c4 + u]) + v;
+      }
+    }
+    BSTAMP(0)
+    __syncthreads();
+    BSTAMP(1)
+    // (3) block-tridiagonal solve.  Forward: lane i < BS owns row i of every block; the row of
+    // E_{t+1} is fetched while step t waits for y_{t-1}.
+    if (wave == 0 && lane < BS) {
+      const int i = lane;
+      s_y[i] = s_r[i];
+      double e0[BS], e1[BS];
+#pragma unroll
+      for (int k = 0; k < BS; k++) e0[k] = nb > 1 ? s_blk[2 * BB + BB + i * BS + k] : 0.0;
+      wave_lds_fence();
+      auto fstep = [&](int t, const double (&ec)[BS], double (&en)[BS]) {
+        double yv[BS];
+        const double rt = s_r[t * BS + i];
+#pragma unroll
+        for (int k = 0; k < BS; k++) yv[k] = s_y[(t - 1) * BS + k];
+        if (t + 1 < nb) {
+          const double *En = s_blk + (size_t)(t + 1) * 2 * BB + BB + i * BS;
+#pragma unroll
+          for (int k = 0; k < BS; k++) en[k] = En[k];
+        }
+        double a0 = rt, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < BS; k += 2) { a0 -= ec[k] * yv[k]; a1 -= ec[k + 1] * yv[k + 1]; }
+        s_y[t * BS + i] = a0 + a1;
+        wave_lds_fence();
+      };
+      int t = 1;
+      for (; t + 1 < nb; t += 2) { fstep(t, e0, e1); fstep(t + 1, e1, e0); }
+      if (t < nb) fstep(t, e0, e1);
+    }
+    BSTAMP(2)
+    __syncthreads();
+    BSTAMP(3)
+    for (int c = tid; c < ncp; c += BTT) {
+      const int t = c / BS, i = c % BS;
+      const double *Dv = s_blk + (size_t)t * 2 * BB + i * BS;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < BS; k++) acc += Dv[k] * s_y[t * BS + k];
+      s_r[c] = acc;
+    }
+    __syncthreads();
+    BSTAMP(4)
+    if (wave == 0 && lane < BS) {
+      const int i = lane;
+      s_xc[(nb - 1) * BS + i] = s_r[(nb - 1) * BS + i];
+      double e0[BS], e1[BS];                             // column i of E_{t+1}
+#pragma unroll
+      for (int k = 0; k < BS; k++) e0[k] = nb > 1 ? s_blk[(size_t)(nb - 1) * 2 * BB + BB + k * BS + i] : 0.0;
+      wave_lds_fence();
+      auto bstep = [&](int t, const double (&ec)[BS], double (&en)[BS]) {
+        double xv[BS];
+        const double zt = s_r[t * BS + i];
+#pragma unroll
+        for (int k = 0; k < BS; k++) xv[k] = s_xc[(t + 1) * BS + k];
+        if (t > 0) {
+          const double *En = s_blk + (size_t)t * 2 * BB + BB + i;
+#pragma unroll
+          for (int k = 0; k < BS; k++) en[k] = En[k * BS];
+        }
+        double a0 = zt, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < BS; k += 2) { a0 -= ec[k] * xv[k]; a1 -= ec[k + 1] * xv[k + 1]; }
+        s_xc[t * BS + i] = a0 + a1;
+        wave_lds_fence();
+      };
+      int t = nb - 2;
+      for (; t >= 1; t -= 2) { bstep(t, e0, e1); bstep(t - 1, e1, e0); }
+      if (t >= 0) bstep(t, e0, e1);
+    }
+    BSTAMP(5)
+    __syncthreads();
+    BSTAMP(6)
+    // (Y) rows in wavefront-sized chunks, two dense chunks in flight per wavefront
+    for (int ch = wave; ch < a.nchunks; ch += BTWV) {
+      int dsc[CH_STRIDE], dsb[CH_STRIDE];          // wave-uniform: descriptor words in SGPRs
+#pragma unroll
+      for (int k = 0; k < CH_STRIDE; k++) dsc[k] = __builtin_amdgcn_readfirstlane(s_dsc[ch * CH_STRIDE + k]);
+      const int kind = dsc[0], nact = dsc[1];
+      if (kind == 0) {
+        const int ncols = dsc[2], chb = ch + BTWV;
+        int nB = 0;
+        if (chb < a.nchunks) {
+#pragma unroll
+          for (int k = 0; k < CH_STRIDE; k++) dsb[k] = __builtin_amdgcn_readfirstlane(s_dsc[chb * CH_STRIDE + k]);
+          if (dsb[0] == 0 && (dsb[2] + 3) / 4 == (ncols + 3) / 4) { nB = dsb[1]; ch = chb; }
+        }
+        if (ncols <= 4) bt_dense_pair<4>(dsc, dsb, nB, lane, chk, bp);
+        else if (ncols <= 8) bt_dense_pair<8>(dsc, dsb, nB, lane, chk, bp);
+        else if (ncols <= 12) bt_dense_pair<12>(dsc, dsb, nB, lane, chk, bp);
+        else bt_dense_pair<16>(dsc, dsb, nB, lane, chk, bp);
+        continue;
+      }
+      if (lane >= nact) continue;
+      const int *rec = a.it + ((size_t)ch * 64 + lane) * 8;
+      const int e = rec[0], r0 = rec[2], r1 = rec[3];
+      BtRow p{0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0}, q = p;
+      int cp = -1;
+      if (kind == 2) {
+        // at most one core entry, in the first row: direct indices, loads issued together
+        const int cc = rec[6];
+        cp = rec[7];
+        const int ra = r0 >= 0 ? r0 : 0, rb = r1 >= 0 ? r1 : ra;
+        const double a0 = As[cp >= 0 ? cp : 0];
+        BtRow pl{0.0, 0.0, rho[ra], (double)w[ra], z[ra], y[ra], ls[ra], us[ra]};
+        BtRow ql{0.0, 0.0, rho[rb], (double)w[rb], z[rb], y[rb], ls[rb], us[rb]};
+        if (r0 >= 0) { p = pl; if (cp >= 0) p.zc = a0 * s_xc[cc]; }
+        if (r1 >= 0) q = ql;
+      } else {
+        if (r0 >= 0) p = BtRow{big_row_core_dot(d, As, s_xc, r0), 0.0, rho[r0], (double)w[r0], z[r0], y[r0], ls[r0], us[r0]};
+        if (r1 >= 0) q = BtRow{big_row_core_dot(d, As, s_xc, r1), 0.0, rho[r1], (double)w[r1], z[r1], y[r1], ls[r1], us[r1]};
+      }
+      double g = 0.0, ki = 0.0, xte = 0.0;
+      const double rwp = p.w * p.rh, rwq = q.w * q.rh;
+      if (e >= 0) {
+        if (r0 >= 0) p.ae = As[rec[4]];
+        if (r1 >= 0) q.ae = As[rec[5]];
+        g = ge[e]; ki = kinv[e];
+        xte = g - ki * (rwp * p.ae * p.zc + rwq * q.ae * q.zc);
+      }
+      double zn, yn, dy, tq0 = 0.0, tq1 = 0.0;
+      if (r0 >= 0) { tq0 = bt_row_step(p, alpha, xte, zn, yn, dy); z[r0] = zn; y[r0] = yn; if (chk) sdy[r0] = dy; }
+      if (r1 >= 0) { tq1 = bt_row_step(q, alpha, xte, zn, yn, dy); z[r1] = zn; y[r1] = yn; if (chk) sdy[r1] = dy; }
+      double gn = 0.0;
+      if (e >= 0) {
+        const int j = rec[1];
+        const double xo = x[j], xn = alpha * xte + (1.0 - alpha) * xo;
+        if (chk) sdx[j] = xn - xo;
+        x[j] = xn;
+        gn = ((sigma * xn - qs[j]) + p.ae * tq0 + q.ae * tq1) * ki;
+        ge[e] = gn;
+      }
+      const double t0 = tq0 - rwp * p.ae * gn, t1 = tq1 - rwq * q.ae * gn;
+      if (kind == 2) {
+        if (cp >= 0) prod[cp] = As[cp] * t0;
+      } else {
+        if (r0 >= 0)
+          for (int s = d.Rp[r0]; s < d.Rp[r0 + 1]; s++)
+            if (d.core_of[d.Rj[s]] >= 0) prod[d.Rpos[s]] = As[d.Rpos[s]] * t0;
+        if (r1 >= 0)
+          for (int s = d.Rp[r1]; s < d.Rp[r1 + 1]; s++)
+            if (d.core_of[d.Rj[s]] >= 0) prod[d.Rpos[s]] = As[d.Rpos[s]] * t1;
+      }
+    }
+    BSTAMP(7)
+    for (int c = tid; c < n_c; c += BTT) {
+      const double xo = s_x[c], xn = alpha * s_xc[c] + (1.0 - alpha) * xo;
+      s_x[c] = xn;
+      if (chk) { const int j = s_cj[c]; sdx[j] = xn - xo; x[j] = xn; }
+    }
+    BSTAMP(8)
+    __syncthreads();
+    BSTAMP(9)
+    if (!chk) continue;
+    {
+      BigChk ck{As, Ps, qs, ls, us, Dg, Eg, x, y, z, sdx, sdy, w, cscale};
+      status = big_check<BTT>(a, ck, iter, red, pri, dua);
+    }
+    __syncthreads();
+    BSTAMP(10)
+    if (status) break;
+  }
+  if (!status) status = SCO_QP_MAX_ITER_REACHED;
+  if (iter > a.max_iter) iter = a.max_iter;
+#ifdef SCO_STAMP
+  if (lane == 0 && b == 0 && a.stamp) {
+    for (int k = 0; k < 12; k++) a.stamp[wave * 16 + k] = (double)st_acc[k];
+    a.stamp[wave * 16 + 15] = (double)iter;
+  }
+#endif
+  __syncthreads();
+  {
+    const double cinv = 1.0 / cscale;
+    for (int j = tid; j < n; j += BTT) x[j] = Dg[j] * x[j];
+    for (int i = tid; i < m; i += BTT) y[i] = cinv * Eg[i] * y[i] * (double)w[i];
     if (tid == 0) {
       d.status[b] = status; d.iters[b] = iter;
       d.resid[2 * (size_t)b] = pri; d.resid[2 * (size_t)b + 1] = dua;
@@ -487,9 +1099,57 @@ int big_upload(const BigHost &bh, int batch, std::vector<void *> &allocs, BigDev
   return SCO_OK;
 }
 
+#ifdef SCO_STAMP
+static double *sco_debug_stamp_bt_ptr = nullptr;
+extern "C" int sco_debug_stamps_bt(double *out) {      // diagnostic build only
+  if (!sco_debug_stamp_bt_ptr) return -1;
+  return hipMemcpy(out, sco_debug_stamp_bt_ptr, 256 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &td) {
+  int rc;
+  if ((rc = upb(allocs, th.ch_desc, &td.ch_desc))) return rc;
+  if ((rc = upb(allocs, th.it, &td.it))) return rc;
+  void *p = nullptr;
+  SCO_HIP(hipMalloc(&p, (size_t)batch * th.blk_doubles * sizeof(double)));
+  allocs.push_back(p);
+  td.blk = (double *)p;
+  SCO_HIP(hipMalloc(&p, (size_t)batch * th.ws_doubles * sizeof(double)));
+  SCO_HIP(hipMemset(p, 0, (size_t)batch * th.ws_doubles * sizeof(double)));
+  allocs.push_back(p);
+  td.ws = (double *)p;
+  return SCO_OK;
+}
+
+template <int BS>
+static int bt_launch_bs(const BigArgs &ba, int batch, size_t lds, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_bt_kernel<BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(qp_bt_factor_kernel<BS>, dim3(batch), dim3(256), 0, st, ba);
+  SCO_HIP(hipGetLastError());
+  if (ev_mid) SCO_HIP(hipEventRecord(ev_mid, st));
+  if (mid2) SCO_HIP(hipEventRecord(mid2, st));
+  hipLaunchKernelGGL(qp_admm_bt_kernel<BS>, dim3(batch), dim3(BTT), lds, st, ba);
+  SCO_HIP(hipGetLastError());
+  return SCO_OK;
+}
+
 int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, const BigHost &bh, const BigDev &bd,
-               hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2) {
+               const BtHost *th, const BtDev *td, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2) {
   BigArgs ba;
+  ba.stamp = nullptr;
+#ifdef SCO_STAMP
+  {
+    static double *g_stamp = nullptr;
+    if (!g_stamp) { SCO_HIP(hipMalloc((void **)&g_stamp, 256 * sizeof(double))); SCO_HIP(hipMemset(g_stamp, 0, 256 * sizeof(double))); }
+    ba.stamp = g_stamp; sco_debug_stamp_bt_ptr = g_stamp;
+  }
+#endif
+  ba.bt_bs = 0; ba.bt_nb = 0; ba.bt_blk = nullptr; ba.bt_stride = 0; ba.nchunks = 0;
+  ba.ch_desc = ba.it = nullptr;
   ba.d = a.d; ba.Pp = Pp; ba.Pi = Pi;
   ba.row_elim = bd.row_elim; ba.row_epos = bd.row_epos; ba.er_ptr = bd.er_ptr; ba.er_row = bd.er_row;
   ba.free_rows = bd.free_rows; ba.pc_ptr = bd.pc_ptr; ba.pc_pos = bd.pc_pos; ba.pc_core = bd.pc_core;
@@ -498,8 +1158,21 @@ int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, con
   ba.rho = a.rho; ba.sigma = a.sigma; ba.alpha = a.alpha; ba.eps_abs = a.eps_abs; ba.eps_rel = a.eps_rel;
   ba.eps_prim_inf = a.eps_prim_inf; ba.eps_dual_inf = a.eps_dual_inf;
   ba.max_iter = a.max_iter; ba.check = a.check; ba.scaling = scaling;
+  if (th) {
+    ba.bt_bs = th->bs; ba.bt_nb = th->nb; ba.bt_blk = td->blk; ba.bt_stride = th->blk_doubles;
+    ba.ch_desc = td->ch_desc; ba.it = td->it; ba.nchunks = th->nchunks;
+    ba.ws = td->ws; ba.ws_stride = th->ws_doubles;
+  }
   hipLaunchKernelGGL(qp_setup_big_kernel, dim3(a.d.batch), dim3(BT), 0, st, ba);
   SCO_HIP(hipGetLastError());
+  if (th) {
+    switch (th->bs) {
+      case 4: return bt_launch_bs<4>(ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
+      case 8: return bt_launch_bs<8>(ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
+      case 12: return bt_launch_bs<12>(ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
+      default: return bt_launch_bs<16>(ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
+    }
+  }
   if (ev_mid) SCO_HIP(hipEventRecord(ev_mid, st));
   if (mid2) SCO_HIP(hipEventRecord(mid2, st));
   hipLaunchKernelGGL(qp_admm_big_kernel, dim3(a.d.batch), dim3(BT), 0, st, ba);

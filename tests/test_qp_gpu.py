@@ -186,22 +186,42 @@ def test_results_are_run_to_run_deterministic(gpu):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][3], outs[1][3])
 
 
-def test_global_memory_tier_matches_oracle(gpu, monkeypatch):
-    """sco_qp_big.hip (forced): the tier BASELINE config 5 (12-DOF x 50) runs on."""
+@pytest.mark.parametrize("structured", [False, True])
+def test_global_memory_tier_matches_oracle(gpu, monkeypatch, structured):
+    """sco_qp_big.hip (forced): the tier BASELINE config 5 (12-DOF x 50) runs on, in its
+    dense-inverse form and in the structured form (block-tridiagonal core, dense row blocks)."""
     monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    monkeypatch.setenv("SCO_QP_NO_BT", "0" if structured else "1")
     rng = np.random.default_rng(41)
     probs = [penalty_qp(rng, 6, 3, 4) for _ in range(3)]
     m = len(probs[0][3])
     w = np.ones((3, m), dtype=np.int32); w[:, 3:3 + 24] = 2
     info, x_big, st_big, it_big = _check(probs, w=w)
-    assert info["lds_admm"] == 0
+    assert (info["lds_admm"] > 0) == structured
     monkeypatch.delenv("SCO_QP_FORCE_BIG")
     _, x_rl, st_rl, it_rl = _check(probs, w=w)
     assert np.array_equal(st_big, st_rl) and np.array_equal(it_big, it_rl) and np.abs(x_big - x_rl).max() < 1e-10
 
 
-def test_global_memory_tier_infeasible_status(gpu, monkeypatch):
+@pytest.mark.parametrize("shape", [(5, 7, 40), (4, 12, 70), (3, 16, 20), (6, 2, 3)])
+def test_structured_tier_dense_row_blocks(gpu, monkeypatch, shape):
+    """Row blocks long enough to be addressed as dense chunks (>= 16 consecutive rows with the
+    same core columns, here T blocks of r rows x d columns), block orders 8, 12, 16 and 4."""
     monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    T, d, r = shape
+    rng = np.random.default_rng(100 + T + d + r)
+    probs = [penalty_qp(rng, T, d, r) for _ in range(2)]
+    info, x_bt, st_bt, it_bt = _check(probs)
+    assert info["lds_admm"] > 0
+    monkeypatch.setenv("SCO_QP_NO_BT", "1")
+    _, x_d, st_d, it_d = _check(probs)
+    assert np.array_equal(st_bt, st_d) and np.array_equal(it_bt, it_d) and np.abs(x_bt - x_d).max() < 1e-10
+
+
+@pytest.mark.parametrize("structured", [False, True])
+def test_global_memory_tier_infeasible_status(gpu, monkeypatch, structured):
+    monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    monkeypatch.setenv("SCO_QP_NO_BT", "0" if structured else "1")
     A = np.array([[1.0], [1.0]])
     prim = (np.array([[1.0]]), np.array([0.0]), A, np.array([1.0, -np.inf]), np.array([np.inf, 0.0]))
     _, _, st, _ = _check([prim])
