@@ -50,7 +50,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="problems per GPU (default 1024; 256 for 12x50)")
+    ap.add_argument("--workload", choices=["7x20", "12x50"], default="7x20",
+                    help="7x20 = BASELINE configs[2] (headline); 12x50 = configs[4] shape (structured global-memory tier)")
     ap.add_argument("--cpu-problems", type=int, default=8, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--intended", action="store_true",
                     help="disable reference quirks Q1/Q2 (NOT the headline number)")
@@ -82,8 +84,11 @@ def main():
     from sco_py_amd import _lib, batch as sb
     from sco_py_amd import dist as sd
 
-    dims = dict(d=7, T=20, K=5, O=2)
-    B = args.batch
+    big = args.workload == "12x50"
+    dims = dict(d=12, T=50, K=10, O=10) if big else dict(d=7, T=20, K=5, O=2)
+    B = args.batch if args.batch is not None else (256 if big else 1024)
+    if big and args.cpu_problems == 8:
+        args.cpu_problems = 0          # one 12x50 oracle solve takes minutes (tests/golden/make_big_oracle.py)
     total = B * world
     lo, hi = sd.shard_range(total, rank, world)
     arrays, _ = af.make_batch(hi - lo, first=lo, **dims)
@@ -148,7 +153,7 @@ def main():
         # (scripts/gpu_pmc.sh), so the committed measurement is quoted, not re-measured live
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and B == 1024 and not args.intended:
+        if os.path.exists(tpath) and B == 1024 and not args.intended and not big:
             with open(tpath) as fh:
                 traffic = json.load(fh)["hbm_bytes_per_launch"]
         out = {
@@ -159,9 +164,12 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "batch=%d independent 7-DOF x 20-timestep planar-arm trajopt problems per GPU "
-                                   "(n=340, m=554 + duplicated penalty rows, 200 nonlinear rows), penalty SQP with "
-                                   "reference defaults" % B,
+            "config": {"workload": ("batch=%d independent 12-DOF x 50-timestep planar-arm trajopt problems per GPU "
+                                    "(n=5600, m=10624 + duplicated penalty rows, 5000 nonlinear rows), penalty SQP with "
+                                    "reference defaults" % B) if big else
+                                   ("batch=%d independent 7-DOF x 20-timestep planar-arm trajopt problems per GPU "
+                                    "(n=340, m=554 + duplicated penalty rows, 200 nonlinear rows), penalty SQP with "
+                                    "reference defaults" % B),
                        "global_batch": total, "mode": "intended" if args.intended else "parity",
                        "parallelism": "batch-shard x%d, no data-path collective" % world},
             "aux": {"qp_solves_per_s": qp_solves_total * world / elapsed,
@@ -169,10 +177,13 @@ def main():
                     "stage_ms_per_step": dict(zip(["convexify", "qp_setup", "admm", "decide", "total"],
                                                   (stage_ms / args.steps).round(3).tolist())),
                     "success_fraction": float(np.mean(allrec["success"] != 0))},
-            "roofline": {"bound": "hbm", "kernel": "qp_admm_rl_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "qp_admm_bt_kernel" if big else "qp_admm_rl_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
                          "traffic": traffic, "algorithmic_bytes_per_launch": admm_bytes / max(qp_launches, 1),
-                         "note": "achieved = algorithmic (5n+9m)*8 B per problem-iteration x iterations / kernel "
+                         "note": ("achieved = algorithmic (5n+9m)*8 B per problem-iteration x iterations / kernel time from "
+                                  "HIP events; one workgroup per problem streams A from L2/HBM every iteration and is "
+                                  "bound by the per-CU memory pipe (~29 B/clk, scripts/microbench/cu_stream.hip)") if big else
+                                 "achieved = algorithmic (5n+9m)*8 B per problem-iteration x iterations / kernel "
                                  "time from HIP events on the library stream; iterates live in LDS/registers, so the "
                                  "measured HBM traffic per launch (profiles/r01_traffic.json, PMC) is ~4 orders of magnitude "
                                  "below the algorithmic bytes and frac may exceed what an HBM-streaming kernel could reach"},

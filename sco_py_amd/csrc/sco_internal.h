@@ -110,11 +110,13 @@ int big_upload(const BigHost &bh, int batch, std::vector<void *> &allocs, BigDev
 // structured variant of the big tier: block-tridiagonal core solve (factors in LDS) and
 // dense row blocks addressed without index arrays
 struct BtHost {
-  int bs = 0, nb = 0, nchunks = 0;
+  int bs = 0, nb = 0, nchunks = 0, npart = 0;
+  bool use_part = false;          // dense chunks reduce A' t in the wavefront (no product round trip)
+  std::vector<int> cent;          // [n_c padded][4] column contributions: >= 0 partial index, <= -2 product position, -1 none
   size_t blk_doubles = 0, ws_doubles = 0, lds_bytes = 0;
   std::vector<int> ch_desc, it;     // it: 8 ints per chunk slot (e, j, r0, r1, ep0, ep1, core idx, core pos)
 };
-struct BtDev { const int *ch_desc, *it; double *blk, *ws; };
+struct BtDev { const int *ch_desc, *it, *cent; double *blk, *ws; };
 bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th);
 int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &td);
 // th/td null = dense route

@@ -98,8 +98,8 @@ struct BigArgs {
   // block-tridiagonal core (bt_bs > 0): S goes to block storage instead of the dense array
   int bt_bs, bt_nb;
   double *bt_blk; size_t bt_stride;
-  const int *ch_desc, *it;
-  int nchunks;
+  const int *ch_desc, *it, *cent;
+  int nchunks, npart, use_part;
   double *stamp;     // diagnostic build only (SCO_STAMP)
 };
 
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(BT) void qp_admm_big_kernel(BigArgs a) {
 // A reads coalesced lines and no index arrays.  A' t' is formed by scattering the
 // products A_ic t'_i into CSC order (coalesced for the same reason) and summing every
 // core column's contiguous segment with 16 lanes.
-#define CH_STRIDE 16      // kind, nact, ncols, r0, c0, pos0, col stride, e0, j0, r1, ep0, ep0 stride, ep1, ep1 stride, pad, pad
+#define CH_STRIDE 16      // kind, nact, ncols, r0, c0, pos0, col stride, e0, j0, r1, ep0, ep0 stride, ep1, ep1 stride, partial base, pad
 #define BT_MAXBS 16
 #define BTT 512           // threads of the structured ADMM kernel (256 VGPRs per thread)
 #define BTWV (BTT / 64)
@@ -540,7 +540,6 @@ bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th) {
   th.nb = (pl.n_c + th.bs - 1) / th.bs;
   const size_t ncp = (size_t)th.nb * th.bs;
   th.blk_doubles = 2 * ncp * th.bs;
-  th.lds_bytes = 8 * (th.blk_doubles + 5 * ncp + 64) + 4 * 3 * ncp;   // factors, r/y/x~/x/q, column metadata (+ chunk descriptors, below)
   const int m = pl.m;
   // core entries of every row: (core index, CSC position)
   auto row_core = [&](int i, std::vector<int> &cols, std::vector<int> &pos) {
@@ -571,7 +570,7 @@ bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th) {
     it.simple = c1.empty() && c0.size() <= 1;
     items.push_back(it);
   }
-  th.ch_desc.clear(); th.it.clear();
+  th.ch_desc.clear(); th.it.clear(); th.npart = 0;
   auto push_chunk = [&](int kind, const std::vector<Item> &its, size_t first, size_t cnt) {
     std::vector<int> dsc(CH_STRIDE, 0);
     const Item &f = its[first];
@@ -581,6 +580,7 @@ bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th) {
       dsc[6] = f.pos.size() > 1 ? f.pos[1] - f.pos[0] : 0;
       dsc[7] = f.e; dsc[8] = f.j; dsc[9] = f.r1; dsc[10] = f.ep0; dsc[12] = f.ep1;
       if (cnt > 1) { dsc[11] = its[first + 1].ep0 - f.ep0; dsc[13] = its[first + 1].ep1 - f.ep1; }
+      dsc[14] = th.npart; th.npart += (int)f.cols.size();
     }
     th.ch_desc.insert(th.ch_desc.end(), dsc.begin(), dsc.end());
     for (size_t l = 0; l < 64; l++) {
@@ -628,7 +628,35 @@ bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th) {
   for (size_t f = 0; f < simple.size(); f += 64) push_chunk(2, simple, f, std::min<size_t>(64, simple.size() - f));
   for (size_t f = 0; f < complex_.size(); f += 64) push_chunk(1, complex_, f, std::min<size_t>(64, complex_.size() - f));
   th.nchunks = (int)(th.ch_desc.size() / CH_STRIDE);
-  th.lds_bytes += 4 * th.ch_desc.size();
+  // contributions to every core column of A' t: partial sums of the dense chunks + products of the other rows
+  th.cent.assign(4 * ncp, -1);
+  th.use_part = th.npart > 0;
+  {
+    std::vector<int> fill(ncp, 0);
+    auto add = [&](int c, int v) { if (fill[c] < 4) th.cent[4 * c + fill[c]] = v; fill[c]++; };
+    for (int ch = 0; ch < th.nchunks; ch++) {
+      const int *dsc = &th.ch_desc[(size_t)ch * CH_STRIDE];
+      if (dsc[0] == 0) {
+        for (int k = 0; k < dsc[2]; k++) add(dsc[4] + k, dsc[14] + k);
+      } else {
+        for (int l = 0; l < dsc[1]; l++) {
+          const int *rec = &th.it[((size_t)ch * 64 + l) * 8];
+          for (int q = 2; q <= 3; q++) {
+            const int i = rec[q];
+            if (i < 0) continue;
+            for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
+              const int c = pl.core_of[pl.Rj[s]];
+              if (c >= 0) add(c, -(pl.Rpos[s] + 2));
+            }
+          }
+        }
+      }
+    }
+    for (size_t c = 0; c < ncp; c++) if (fill[c] > 4) th.use_part = false;
+  }
+  if (!th.use_part) th.npart = 0;
+  // factors; r/y, z/x~ (+ 64 zeros), x, q; partial sums; column metadata; chunk descriptors
+  th.lds_bytes = 8 * (th.blk_doubles + 4 * ncp + 64 + th.npart) + 4 * (4 * ncp + th.ch_desc.size());
   if (th.lds_bytes + 1024 > 160 * 1024) return false;
   th.ws_doubles = 3 * (size_t)m + pl.n_e + pl.n + pl.nnzA + 64;
   return true;
@@ -710,6 +738,7 @@ struct BtPtrs {
   const int *w;
   double *x, *y, *z, *sdy, *sdx, *ge, *prod;
   const double *s_xc;
+  double *s_part;       // partial column sums of the dense chunks (LDS) or null: products go to `prod`
   double alpha, sigma;
 };
 struct BtRow { double zc, ae, rh, w, z, y, l, u; };
@@ -723,30 +752,46 @@ __device__ __forceinline__ double bt_row_step(const BtRow &r, double alpha, doub
   yn = r.y + dy;
   return r.w * (r.rh * zn - yn);
 }
+// sum over the wavefront, valid in lane 63; fixed association order (16-lane rows by
+// row_shr 1,2,4,8, then row_bcast15 into rows 1 and 3, then row_bcast31 into rows 2 and 3)
+__device__ __forceinline__ double bt_wave_sum63(double v) {
+  int lo, hi, lo2, hi2;
+#define BT_DPP_STEP(ctrl, rmask)                                                             \
+  lo = __double2loint(v); hi = __double2hiint(v);                                            \
+  lo2 = __builtin_amdgcn_update_dpp(0, lo, ctrl, rmask, 0xf, true);                          \
+  hi2 = __builtin_amdgcn_update_dpp(0, hi, ctrl, rmask, 0xf, true);                          \
+  v += __hiloint2double(hi2, lo2);
+  BT_DPP_STEP(0x111, 0xf) BT_DPP_STEP(0x112, 0xf) BT_DPP_STEP(0x114, 0xf) BT_DPP_STEP(0x118, 0xf)
+  BT_DPP_STEP(0x142, 0xa) BT_DPP_STEP(0x143, 0xc)
+#undef BT_DPP_STEP
+  return v;
+}
 
 // Dense chunk: up to 64 consecutive rows r0 + lane with core entries in columns c0 .. c0 + ncols - 1
 // at CSC positions pos0 + k cs + lane; their eliminated variables e0 + lane (QP variable j0 + lane)
 // each with an optional second row r1 + lane that has no core entry.  Every address is a
-// descriptor scalar plus the lane and every load is unconditional (absent pieces re-read a valid
-// address and are masked afterwards), so a chunk costs one memory round trip; two chunks are
-// kept in flight per wavefront.
+// descriptor scalar plus the (clamped) lane and every load is unconditional, so a chunk costs one
+// memory round trip; two chunks are kept in flight per wavefront.  All 64 lanes run the arithmetic
+// (idle lanes repeat the last row and store nothing) so that A' t can be reduced across the wavefront.
 template <int NC>
 struct BtDenseRegs {
   double av[NC];
   BtRow p, s;
   double g, ki, xo, qj;
-  int r0, r1, e, j, ncols, pos0, cs, c0;
-  bool two;
+  int r0, r1, e, j, ncols, pos0, cs, c0, pbase, ln;
+  bool two, on;
 };
 template <int NC>
 __device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int lane, const BtPtrs &q, BtDenseRegs<NC> &R) {
-  R.ncols = dsc[2]; R.pos0 = dsc[5]; R.cs = dsc[6]; R.c0 = dsc[4];
-  R.r0 = dsc[3] + lane; R.e = dsc[7] + lane; R.j = dsc[8] + lane;
+  R.on = lane < dsc[1];
+  R.ln = R.on ? lane : dsc[1] - 1;
+  R.ncols = dsc[2]; R.pos0 = dsc[5]; R.cs = dsc[6]; R.c0 = dsc[4]; R.pbase = dsc[14];
+  R.r0 = dsc[3] + R.ln; R.e = dsc[7] + R.ln; R.j = dsc[8] + R.ln;
   R.two = dsc[9] >= 0;
-  R.r1 = R.two ? dsc[9] + lane : R.r0;
+  R.r1 = R.two ? dsc[9] + R.ln : R.r0;
 #pragma unroll
-  for (int k = 0; k < NC; k++) R.av[k] = q.As[R.pos0 + (k < R.ncols ? k : 0) * R.cs + lane];
-  const int ep0 = dsc[10] + dsc[11] * lane, ep1 = R.two ? dsc[12] + dsc[13] * lane : ep0;
+  for (int k = 0; k < NC; k++) R.av[k] = q.As[R.pos0 + (k < R.ncols ? k : 0) * R.cs + R.ln];
+  const int ep0 = dsc[10] + dsc[11] * R.ln, ep1 = R.two ? dsc[12] + dsc[13] * R.ln : ep0;
   R.p = BtRow{0.0, q.As[ep0], q.rho[R.r0], (double)q.w[R.r0], q.z[R.r0], q.y[R.r0], q.ls[R.r0], q.us[R.r0]};
   R.s = BtRow{0.0, q.As[ep1], q.rho[R.r1], (double)q.w[R.r1], q.z[R.r1], q.y[R.r1], q.ls[R.r1], q.us[R.r1]};
   R.g = q.ge[R.e]; R.ki = q.kinv[R.e]; R.xo = q.x[R.j]; R.qj = q.qs[R.j];
@@ -756,7 +801,7 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
   const double *xc = q.s_xc + R.c0;
   double xv[NC];
 #pragma unroll
-  for (int k = 0; k < NC; k++) xv[k] = xc[k];             // the slack behind s_xc is zero
+  for (int k = 0; k < NC; k++) xv[k] = xc[k];             // the slack behind x~_C is zero
   double z0 = 0.0, z1 = 0.0;
 #pragma unroll
   for (int k = 0; k < NC; k += 2) {
@@ -769,29 +814,37 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
   const double xte = R.g - R.ki * (rwp * R.p.ae * R.p.zc);         // the second row has no core entry
   double zn, yn, dy;
   const double tq0 = bt_row_step(R.p, q.alpha, xte, zn, yn, dy);
-  q.z[R.r0] = zn; q.y[R.r0] = yn; if (chk) q.sdy[R.r0] = dy;
+  if (R.on) { q.z[R.r0] = zn; q.y[R.r0] = yn; if (chk) q.sdy[R.r0] = dy; }
   double tq1 = 0.0;
-  if (R.two) { tq1 = bt_row_step(R.s, q.alpha, xte, zn, yn, dy); q.z[R.r1] = zn; q.y[R.r1] = yn; if (chk) q.sdy[R.r1] = dy; }
+  if (R.two) {
+    tq1 = bt_row_step(R.s, q.alpha, xte, zn, yn, dy);
+    if (R.on) { q.z[R.r1] = zn; q.y[R.r1] = yn; if (chk) q.sdy[R.r1] = dy; }
+  }
   const double xn = q.alpha * xte + (1.0 - q.alpha) * R.xo;
-  if (chk) q.sdx[R.j] = xn - R.xo;
-  q.x[R.j] = xn;
   const double gn = ((q.sigma * xn - R.qj) + R.p.ae * tq0 + R.s.ae * tq1) * R.ki;
-  q.ge[R.e] = gn;
-  const double t0 = tq0 - rwp * R.p.ae * gn;
+  if (R.on) { if (chk) q.sdx[R.j] = xn - R.xo; q.x[R.j] = xn; q.ge[R.e] = gn; }
+  const double t0 = R.on ? tq0 - rwp * R.p.ae * gn : 0.0;
+  if (q.s_part) {
 #pragma unroll
-  for (int k = 0; k < NC; k++)
-    if (k < R.ncols) q.prod[R.pos0 + k * R.cs + lane] = R.av[k] * t0;
+    for (int k = 0; k < NC; k++) {
+      const double tot = bt_wave_sum63(R.av[k] * t0);
+      if (lane == 63 && k < R.ncols) q.s_part[R.pbase + k] = tot;
+    }
+  } else if (R.on) {
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+      if (k < R.ncols) q.prod[R.pos0 + k * R.cs + lane] = R.av[k] * t0;
+  }
 }
-// chunks A (lanes < nA) and, if nB > 0, B: loads of both before the arithmetic of either
+// chunks A and, if hasB, B: loads of both before the arithmetic of either
 template <int NC>
-__device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const int (&dB)[CH_STRIDE], int nB, int lane, bool chk,
+__device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const int (&dB)[CH_STRIDE], bool hasB, int lane, bool chk,
                                               const BtPtrs &q) {
   BtDenseRegs<NC> RA, RB;
-  const bool onA = lane < dA[1], onB = lane < nB;
-  if (onA) bt_dense_load<NC>(dA, lane, q, RA);
-  if (onB) bt_dense_load<NC>(dB, lane, q, RB);
-  if (onA) bt_dense_compute<NC>(RA, lane, chk, q);
-  if (onB) bt_dense_compute<NC>(RB, lane, chk, q);
+  bt_dense_load<NC>(dA, lane, q, RA);
+  if (hasB) bt_dense_load<NC>(dB, lane, q, RB);
+  bt_dense_compute<NC>(RA, lane, chk, q);
+  if (hasB) bt_dense_compute<NC>(RB, lane, chk, q);
 }
 
 template <int BS>
@@ -802,15 +855,17 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   const int n = d.n, m = d.m, n_e = d.n_e, n_c = d.n_c, nb = a.bt_nb;
   constexpr int BB = BS * BS;
   const int ncp = nb * BS;
+  const bool use_part = a.use_part != 0;
   __shared__ double red[BTWV * 8];
   extern __shared__ double s_dyn[];
   double *s_blk = s_dyn;                       // [nb][2][BS][BS]: D_t^-1, E_t
-  double *s_r = s_blk + (size_t)nb * 2 * BB;   // core right-hand side, then z
-  double *s_y = s_r + ncp;                     // forward sweep result
-  double *s_x = s_y + ncp;                     // x_C (scaled iterate of the core variables)
+  double *s_r = s_blk + (size_t)nb * 2 * BB;   // core right-hand side r; the forward sweep turns it into y in place
+  double *s_xc = s_r + ncp;                    // z = D^-1 y; the backward sweep turns it into x~_C in place; then 64 zeros
+  double *s_x = s_xc + ncp + 64;               // x_C (scaled iterate of the core variables)
   double *s_q = s_x + ncp;                     // q_C
-  double *s_xc = s_q + ncp;                    // x~_C, followed by 64 zeros
-  int *s_cp0 = (int *)(s_xc + ncp + 64), *s_clen = s_cp0 + ncp, *s_cj = s_clen + ncp, *s_dsc = s_cj + ncp;
+  double *s_part = s_q + ncp;                  // partial column sums of the dense chunks
+  int *s_cent = (int *)(s_part + a.npart);     // use_part: [ncp][4] column contributions; else: segment start, length
+  int *s_dsc = s_cent + 4 * ncp;
   const double *As = d.As + (size_t)b * d.nnzA, *Ps = d.Ps + (size_t)b * d.nnzP;
   const double *qs = d.qs + (size_t)b * n, *ls = d.ls + (size_t)b * m, *us = d.us + (size_t)b * m;
   const double *rho = d.rho + (size_t)b * m, *kinv = d.kee_inv + (size_t)b * n_e;
@@ -820,23 +875,27 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   double *ws = a.ws + (size_t)b * a.ws_stride;
   double *z = ws, *tp = z + m, *sdy = tp + m, *ge = sdy + m, *sdx = ge + n_e, *prod = sdx + n;
   const double cscale = d.cscale[b], alpha = a.alpha, sigma = a.sigma;
-  const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, alpha, sigma};
+  const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, use_part ? s_part : nullptr, alpha, sigma};
 
   {
     const double *blk = a.bt_blk + (size_t)b * a.bt_stride;
     for (size_t t = tid; t < (size_t)nb * 2 * BB; t += BTT) s_blk[t] = blk[t];
-    for (int c = tid; c < 5 * ncp + 64; c += BTT) s_r[c] = 0.0;
-    for (int c = tid; c < ncp; c += BTT) {
-      int p0 = 0, len = 0, j = 0;
-      if (c < n_c) { j = d.core_var[c]; p0 = d.Ap[j]; len = d.Ap[j + 1] - p0; }
-      s_cp0[c] = p0; s_clen[c] = len; s_cj[c] = j;
+    for (int c = tid; c < 4 * ncp + 64 + a.npart; c += BTT) s_r[c] = 0.0;
+    if (use_part) {
+      for (int t = tid; t < 4 * ncp; t += BTT) s_cent[t] = a.cent[t];
+    } else {
+      for (int c = tid; c < ncp; c += BTT) {
+        int p0 = 0, len = 0;
+        if (c < n_c) { const int j = d.core_var[c]; p0 = d.Ap[j]; len = d.Ap[j + 1] - p0; }
+        s_cent[c] = p0; s_cent[ncp + c] = len;
+      }
     }
     for (int t = tid; t < a.nchunks * CH_STRIDE; t += BTT) s_dsc[t] = a.ch_desc[t];
   }
   for (int j = tid; j < n; j += BTT) { x[j] = 0.0; sdx[j] = 0.0; }
   for (int i = tid; i < m; i += BTT) { z[i] = 0.0; y[i] = 0.0; tp[i] = 0.0; sdy[i] = 0.0; }
   __syncthreads();
-  for (int c = tid; c < n_c; c += BTT) s_q[c] = qs[s_cj[c]];
+  for (int c = tid; c < n_c; c += BTT) s_q[c] = qs[d.core_var[c]];
   for (int e = tid; e < n_e; e += BTT) {
     const double g = -qs[d.elim_var[e]] * kinv[e];
     ge[e] = g;
@@ -848,6 +907,18 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   __syncthreads();
   for (int j = tid; j < n; j += BTT)
     for (int p = d.Ap[j]; p < d.Ap[j + 1]; p++) prod[p] = As[p] * tp[d.Ai[p]];
+  if (use_part) {
+    // partial sums of the start point: one dense chunk per wavefront pass
+    for (int ch = wave; ch < a.nchunks; ch += BTWV) {
+      const int *dsc = s_dsc + ch * CH_STRIDE;
+      if (dsc[0] != 0) continue;
+      for (int k = 0; k < dsc[2]; k++) {
+        const double v = lane < dsc[1] ? As[dsc[5] + k * dsc[6] + lane] * tp[dsc[3] + lane] : 0.0;
+        const double tot = bt_wave_sum63(v);
+        if (lane == 63) s_part[dsc[14] + k] = tot;
+      }
+    }
+  }
   __syncthreads();
 
   int status = 0, iter = 0;
@@ -862,44 +933,56 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   for (iter = 1; iter <= a.max_iter; iter++) {
     const bool chk = (a.check > 0 && iter % a.check == 0) || iter == a.max_iter;
     BSTAMP(11)
-    // (1) core right-hand side: 16 lanes per core column sum its CSC segment of products,
-    //     four columns in flight per lane group
-    for (int c4 = (tid >> 4) * 4; c4 < n_c; c4 += (BTT / 16) * 4) {
-      double pv[4][8];
-      int pp[4], ln[4];
+    // (1) core right-hand side r_c = sigma x_c - q_c + (A' t)_c
+    if (use_part) {
+      // at most four contributions per column: partial sums of dense chunks (LDS) and products of other rows
+      for (int c = tid; c < n_c; c += BTT) {
+        double v = 0.0;
 #pragma unroll
-      for (int u = 0; u < 4; u++) { pp[u] = s_cp0[c4 + u] + (tid & 15); ln[u] = s_clen[c4 + u] - (tid & 15); }
+        for (int u = 0; u < 4; u++) {
+          const int en = s_cent[4 * c + u];
+          if (en >= 0) v += s_part[en];
+          else if (en <= -2) v += prod[-(en + 2)];
+        }
+        s_r[c] = (sigma * s_x[c] - s_q[c]) + v;
+      }
+    } else {
+      // 16 lanes per core column sum its CSC segment of products, four columns in flight per lane group
+      for (int c4 = (tid >> 4) * 4; c4 < n_c; c4 += (BTT / 16) * 4) {
+        double pv[4][8];
+        int pp[4], ln[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+        for (int u = 0; u < 4; u++) { pp[u] = s_cent[c4 + u] + (tid & 15); ln[u] = s_cent[ncp + c4 + u] - (tid & 15); }
 #pragma unroll
-        for (int k = 0; k < 8; k++) pv[u][k] = prod[pp[u] + (16 * k < ln[u] ? 16 * k : 0)];     // unconditional loads
+        for (int u = 0; u < 4; u++)
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+          for (int k = 0; k < 8; k++) pv[u][k] = prod[pp[u] + (16 * k < ln[u] ? 16 * k : 0)];     // unconditional loads
 #pragma unroll
-        for (int k = 0; k < 8; k++) pv[u][k] = (16 * k < ln[u]) ? pv[u][k] : 0.0;
-        double v = ((pv[u][0] + pv[u][1]) + (pv[u][2] + pv[u][3])) + ((pv[u][4] + pv[u][5]) + (pv[u][6] + pv[u][7]));
-        for (int k = 128; k < ln[u]; k += 16) v += prod[pp[u] + k];
-        v = bt_row16_sum(v);
-        if ((tid & 15) == 15 && c4 + u < n_c) s_r[c4 + u] = (sigma * s_x[c4 + u] - s_q[c4 + u]) + v;
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) pv[u][k] = (16 * k < ln[u]) ? pv[u][k] : 0.0;
+          double v = ((pv[u][0] + pv[u][1]) + (pv[u][2] + pv[u][3])) + ((pv[u][4] + pv[u][5]) + (pv[u][6] + pv[u][7]));
+          for (int k = 128; k < ln[u]; k += 16) v += prod[pp[u] + k];
+          v = bt_row16_sum(v);
+          if ((tid & 15) == 15 && c4 + u < n_c) s_r[c4 + u] = (sigma * s_x[c4 + u] - s_q[c4 + u]) + v;
+        }
       }
     }
     BSTAMP(0)
     __syncthreads();
     BSTAMP(1)
-    // (3) block-tridiagonal solve.  Forward: lane i < BS owns row i of every block; the row of
-    // E_{t+1} is fetched while step t waits for y_{t-1}.
+    // (3) block-tridiagonal solve.  Forward, in place: lane i < BS owns row i of every block; the
+    // row of E_{t+1} is fetched while step t waits for y_{t-1}.
     if (wave == 0 && lane < BS) {
       const int i = lane;
-      s_y[i] = s_r[i];
       double e0[BS], e1[BS];
 #pragma unroll
       for (int k = 0; k < BS; k++) e0[k] = nb > 1 ? s_blk[2 * BB + BB + i * BS + k] : 0.0;
-      wave_lds_fence();
       auto fstep = [&](int t, const double (&ec)[BS], double (&en)[BS]) {
         double yv[BS];
         const double rt = s_r[t * BS + i];
 #pragma unroll
-        for (int k = 0; k < BS; k++) yv[k] = s_y[(t - 1) * BS + k];
+        for (int k = 0; k < BS; k++) yv[k] = s_r[(t - 1) * BS + k];
         if (t + 1 < nb) {
           const double *En = s_blk + (size_t)(t + 1) * 2 * BB + BB + i * BS;
 #pragma unroll
@@ -908,7 +991,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
         double a0 = rt, a1 = 0.0;
 #pragma unroll
         for (int k = 0; k < BS; k += 2) { a0 -= ec[k] * yv[k]; a1 -= ec[k + 1] * yv[k + 1]; }
-        s_y[t * BS + i] = a0 + a1;
+        s_r[t * BS + i] = a0 + a1;
         wave_lds_fence();
       };
       int t = 1;
@@ -923,21 +1006,19 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
       const double *Dv = s_blk + (size_t)t * 2 * BB + i * BS;
       double acc = 0.0;
 #pragma unroll
-      for (int k = 0; k < BS; k++) acc += Dv[k] * s_y[t * BS + k];
-      s_r[c] = acc;
+      for (int k = 0; k < BS; k++) acc += Dv[k] * s_r[t * BS + k];
+      s_xc[c] = acc;
     }
     __syncthreads();
     BSTAMP(4)
-    if (wave == 0 && lane < BS) {
+    if (wave == 0 && lane < BS) {                        // backward, in place on z
       const int i = lane;
-      s_xc[(nb - 1) * BS + i] = s_r[(nb - 1) * BS + i];
       double e0[BS], e1[BS];                             // column i of E_{t+1}
 #pragma unroll
       for (int k = 0; k < BS; k++) e0[k] = nb > 1 ? s_blk[(size_t)(nb - 1) * 2 * BB + BB + k * BS + i] : 0.0;
-      wave_lds_fence();
       auto bstep = [&](int t, const double (&ec)[BS], double (&en)[BS]) {
         double xv[BS];
-        const double zt = s_r[t * BS + i];
+        const double zt = s_xc[t * BS + i];
 #pragma unroll
         for (int k = 0; k < BS; k++) xv[k] = s_xc[(t + 1) * BS + k];
         if (t > 0) {
@@ -966,16 +1047,16 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
       const int kind = dsc[0], nact = dsc[1];
       if (kind == 0) {
         const int ncols = dsc[2], chb = ch + BTWV;
-        int nB = 0;
+        bool hasB = false;
         if (chb < a.nchunks) {
 #pragma unroll
           for (int k = 0; k < CH_STRIDE; k++) dsb[k] = __builtin_amdgcn_readfirstlane(s_dsc[chb * CH_STRIDE + k]);
-          if (dsb[0] == 0 && (dsb[2] + 3) / 4 == (ncols + 3) / 4) { nB = dsb[1]; ch = chb; }
+          if (dsb[0] == 0 && (dsb[2] + 3) / 4 == (ncols + 3) / 4) { hasB = true; ch = chb; }
         }
-        if (ncols <= 4) bt_dense_pair<4>(dsc, dsb, nB, lane, chk, bp);
-        else if (ncols <= 8) bt_dense_pair<8>(dsc, dsb, nB, lane, chk, bp);
-        else if (ncols <= 12) bt_dense_pair<12>(dsc, dsb, nB, lane, chk, bp);
-        else bt_dense_pair<16>(dsc, dsb, nB, lane, chk, bp);
+        if (ncols <= 4) bt_dense_pair<4>(dsc, dsb, hasB, lane, chk, bp);
+        else if (ncols <= 8) bt_dense_pair<8>(dsc, dsb, hasB, lane, chk, bp);
+        else if (ncols <= 12) bt_dense_pair<12>(dsc, dsb, hasB, lane, chk, bp);
+        else bt_dense_pair<16>(dsc, dsb, hasB, lane, chk, bp);
         continue;
       }
       if (lane >= nact) continue;
@@ -1033,7 +1114,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
     for (int c = tid; c < n_c; c += BTT) {
       const double xo = s_x[c], xn = alpha * s_xc[c] + (1.0 - alpha) * xo;
       s_x[c] = xn;
-      if (chk) { const int j = s_cj[c]; sdx[j] = xn - xo; x[j] = xn; }
+      if (chk) { const int j = d.core_var[c]; sdx[j] = xn - xo; x[j] = xn; }
     }
     BSTAMP(8)
     __syncthreads();
@@ -1110,6 +1191,7 @@ int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &t
   int rc;
   if ((rc = upb(allocs, th.ch_desc, &td.ch_desc))) return rc;
   if ((rc = upb(allocs, th.it, &td.it))) return rc;
+  if ((rc = upb(allocs, th.cent, &td.cent))) return rc;
   void *p = nullptr;
   SCO_HIP(hipMalloc(&p, (size_t)batch * th.blk_doubles * sizeof(double)));
   allocs.push_back(p);
@@ -1149,7 +1231,7 @@ int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, con
   }
 #endif
   ba.bt_bs = 0; ba.bt_nb = 0; ba.bt_blk = nullptr; ba.bt_stride = 0; ba.nchunks = 0;
-  ba.ch_desc = ba.it = nullptr;
+  ba.ch_desc = ba.it = ba.cent = nullptr; ba.npart = 0; ba.use_part = 0;
   ba.d = a.d; ba.Pp = Pp; ba.Pi = Pi;
   ba.row_elim = bd.row_elim; ba.row_epos = bd.row_epos; ba.er_ptr = bd.er_ptr; ba.er_row = bd.er_row;
   ba.free_rows = bd.free_rows; ba.pc_ptr = bd.pc_ptr; ba.pc_pos = bd.pc_pos; ba.pc_core = bd.pc_core;
@@ -1160,7 +1242,8 @@ int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, con
   ba.max_iter = a.max_iter; ba.check = a.check; ba.scaling = scaling;
   if (th) {
     ba.bt_bs = th->bs; ba.bt_nb = th->nb; ba.bt_blk = td->blk; ba.bt_stride = th->blk_doubles;
-    ba.ch_desc = td->ch_desc; ba.it = td->it; ba.nchunks = th->nchunks;
+    ba.ch_desc = td->ch_desc; ba.it = td->it; ba.cent = td->cent; ba.nchunks = th->nchunks;
+    ba.npart = th->npart; ba.use_part = th->use_part ? 1 : 0;
     ba.ws = td->ws; ba.ws_stride = th->ws_doubles;
   }
   hipLaunchKernelGGL(qp_setup_big_kernel, dim3(a.d.batch), dim3(BT), 0, st, ba);
