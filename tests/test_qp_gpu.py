@@ -226,3 +226,18 @@ def test_global_memory_tier_infeasible_status(gpu, monkeypatch, structured):
     prim = (np.array([[1.0]]), np.array([0.0]), A, np.array([1.0, -np.inf]), np.array([np.inf, 0.0]))
     _, _, st, _ = _check([prim])
     assert st[0] == -3
+
+
+def test_unconstrained_and_single_variable_qps(gpu):
+    """m = 0 (no rows at all) and n = 1: the degenerate ends of the ABI."""
+    P = np.array([[2.0, 0.5], [0.5, 1.0]]); q = np.array([-1.0, 1.0])
+    Pu = sp.triu(sp.csc_matrix(P), format="csc"); Pu.sort_indices()
+    Ap = np.zeros(3, dtype=np.int32); Ai = np.zeros(0, dtype=np.int32)
+    qp = _lib.BatchedQP(1, 2, 0, Pu.indptr.astype(np.int32), Pu.indices.astype(np.int32), Ap, Ai)
+    qp.load(Pu.data[None, :], q[None, :], np.zeros((1, 0)), np.zeros((1, 0)), np.zeros((1, 0)))
+    x, y, st, it, _ = qp.solve()
+    qp.close()
+    assert st[0] == 1 and np.abs(x[0] - np.linalg.solve(P, -q)).max() < 1e-5
+    one = (np.array([[4.0]]), np.array([-2.0]), np.array([[1.0]]), np.array([1.0]), np.array([1.0]))
+    _, x1, st1, _ = _check([one])
+    assert st1[0] == 1 and abs(x1[0, 0] - 1.0) < 1e-6

@@ -159,3 +159,23 @@ def test_12dof_50step_problem_against_stored_oracle_run(gpu):
     assert np.array_equal(tr[:, 6:8], g["trace"][:, 6:8])             # same QP status / iterations
     assert np.abs(res.x[0] - g["x"]).max() < TOL
     assert bool(res.success[0]) == bool(g["success"])
+
+
+@pytest.mark.parametrize("shape,B", [((1, 2, 1, 1), 1), ((2, 3, 1, 1), 3), ((1, 40, 1, 2), 2), ((5, 2, 3, 1), 5)])
+def test_minimal_and_odd_shapes(gpu, shape, B):
+    """Smallest legal descriptor (1 joint, 2 steps, 1 point, 1 obstacle, batch 1), odd batch sizes, a
+    long thin problem and a two-step one: same decisions and answers as the oracle."""
+    d, T, K, O = shape
+    arrays, probs = af.make_batch(B, d=d, T=T, K=K, O=O)
+    _compare(sb.solve_batch(arrays), probs, range(B))
+
+
+def test_longest_horizon_is_accepted_and_one_more_is_refused(gpu):
+    arrays, probs = af.make_batch(1, d=1, T=256, K=1, O=1)
+    res = sb.solve_batch(arrays)
+    assert np.all(np.isfinite(res.x)) and res.qp_solves[0] >= 2
+    x = res.x.reshape(1, 256, 1)
+    assert np.abs(x[:, 0, :] - arrays["start"]).max() < 1e-4 and np.abs(x[:, -1, :] - arrays["goal"]).max() < 1e-4
+    with pytest.raises(_lib.ScoHipError) as e:
+        sb.TrajOptBatch(1, 1, 257, 1, 1)
+    assert e.value.code == -1
