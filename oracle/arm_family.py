@@ -9,6 +9,7 @@ Problem i (``make_problem(i, ...)``):
   variables   joint angles theta[t][j], t < T, j < d, flattened time-major
   objective   sum_t || theta[t+1] - theta[t] ||^2            (QuadExpr)
   linear      theta[0] = start, theta[T-1] = goal            (EqExpr(AffExpr))
+              (reach variant: only the start pin; ee(theta[T-1]) = target as EqExpr(Expr))
   nonlinear   per timestep, K link points x O circular obstacles (LEqExpr, val = 0):
                 g[k*O + o](theta_t) = r_o - || p_k(theta_t) - c_o ||
               p_k = planar forward kinematics of a serial arm (cumulative angles)
@@ -66,6 +67,23 @@ def arm_dist_jac(theta, link_len, point_link, point_frac, obstacles):
     return J
 
 
+def ee_pos(theta, link_len):
+    """End-effector position (2,) of the arm."""
+    phi = np.cumsum(np.asarray(theta, dtype=np.float64).ravel())
+    return np.array([np.sum(link_len * np.cos(phi)), np.sum(link_len * np.sin(phi))])
+
+
+def ee_jac(theta, link_len):
+    """Analytic Jacobian (2, d) of ee_pos."""
+    phi = np.cumsum(np.asarray(theta, dtype=np.float64).ravel())
+    d = phi.shape[0]
+    J = np.zeros((2, d))
+    for j in range(d):
+        J[0, j] = -np.sum(link_len[j:] * np.sin(phi[j:]))
+        J[1, j] = np.sum(link_len[j:] * np.cos(phi[j:]))
+    return J
+
+
 def default_points(d, K):
     """K link points spread over the links: point k sits at the END of link
     (k * d) // K ... evenly, fraction 1.0 for the last point of a link."""
@@ -79,8 +97,11 @@ def default_points(d, K):
     return link, frac
 
 
-def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05):
-    """Seeded problem i of the batch."""
+def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False):
+    """Seeded problem i of the batch.  reach=True: the goal pin
+    theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
+    (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
+    is_reach = bool(reach)
     rng = np.random.default_rng(1000 + i)
     start = rng.uniform(-np.pi / 2, np.pi / 2, size=d)
     goal = rng.uniform(-np.pi / 2, np.pi / 2, size=d)
@@ -93,16 +114,20 @@ def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05):
     radius = rng.uniform(0.05, 0.15, size=O) * reach
     obstacles = np.stack([rad * np.cos(ang), rad * np.sin(ang), radius], axis=1)
     point_link, point_frac = default_points(d, K)
-    return dict(d=d, T=T, K=K, O=O, x0=x0.ravel(), start=start, goal=goal, link_len=link_len,
-                point_link=point_link, point_frac=point_frac, obstacles=obstacles)
+    out = dict(d=d, T=T, K=K, O=O, x0=x0.ravel(), start=start, goal=goal, link_len=link_len,
+               point_link=point_link, point_frac=point_frac, obstacles=obstacles, reach=is_reach)
+    if is_reach:
+        out["target"] = ee_pos(goal, link_len)
+    return out
 
 
 def make_batch(B, first=0, **kw):
     """Stacked arrays of problems first .. first+B-1 in the layout sco_sqp_load takes."""
     probs = [make_problem(first + i, **kw) for i in range(B)]
     p0 = probs[0]
+    extra = dict(reach=True, target=np.stack([p["target"] for p in probs])) if p0.get("reach") else {}
     return dict(
-        d=p0["d"], T=p0["T"], K=p0["K"], O=p0["O"], B=B,
+        d=p0["d"], T=p0["T"], K=p0["K"], O=p0["O"], B=B, **extra,
         x0=np.stack([p["x0"] for p in probs]),
         start=np.stack([p["start"] for p in probs]),
         goal=np.stack([p["goal"] for p in probs]),

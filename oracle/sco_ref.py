@@ -213,7 +213,8 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
         if b.kind == "leq":
             slack_of.append((np.arange(off, off + b.r), None)); off += b.r
         else:
-            slack_of.append((np.arange(off, off + b.r), np.arange(off + b.r, off + 2 * b.r))); off += 2 * b.r
+            # p_i, n_i side by side (the canonical column order of tests/trajopt_build.py)
+            slack_of.append((off + 2 * np.arange(b.r), off + 2 * np.arange(b.r) + 1)); off += 2 * b.r
     m_nl = sum(b.r for b in p.blocks)
     Pfull = sp.block_diag([Ptri, sp.csc_matrix((n_slack, n_slack))], format="csc") if n_slack else Ptri
     state = dict(slack_cost=1.0, k=0, masks=None)
@@ -344,11 +345,13 @@ def trajopt_flat(prob, analytic_jac=False):
         for j in range(d):
             a, b = t * d + j, (t + 1) * d + j
             Q[a, a] += 2.0; Q[b, b] += 2.0; Q[a, b] -= 2.0; Q[b, a] -= 2.0
-    lin = sp.lil_matrix((2 * d, n_x))
+    reach = bool(prob.get("reach"))
+    lin = sp.lil_matrix((d if reach else 2 * d, n_x))
     for j in range(d):
         lin[j, j] = 1.0
-        lin[d + j, (T - 1) * d + j] = 1.0
-    rhs = np.concatenate([prob["start"], prob["goal"]])
+        if not reach:
+            lin[d + j, (T - 1) * d + j] = 1.0
+    rhs = prob["start"].copy() if reach else np.concatenate([prob["start"], prob["goal"]])
     blocks = []
     R = prob["K"] * prob["O"]
     for t in range(T):
@@ -357,6 +360,10 @@ def trajopt_flat(prob, analytic_jac=False):
         if analytic_jac:
             jac = (lambda th, pr=prob: af.arm_dist_jac(th, pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"]))
         blocks.append(Block("leq", f, np.arange(t * d, (t + 1) * d), np.zeros(R), jac=jac))
+    if reach:
+        f = (lambda th, pr=prob: af.ee_pos(th, pr["link_len"]))
+        jac = (lambda th, pr=prob: af.ee_jac(th, pr["link_len"])) if analytic_jac else None
+        blocks.append(Block("eq", f, np.arange((T - 1) * d, T * d), prob["target"], jac=jac))
     # the object-API construction (tests/trajopt_build.py) binds every atom to two
     # Variables: the whole trajectory and its timestep block
     return FlatProblem(prob["x0"], Q.tocsc(), np.zeros(n_x), 0.0, lin.tocsr(), rhs, rhs, blocks,

@@ -128,3 +128,45 @@ def test_mirror_quirks_match_reference(oracle_qp_backend):
         _, _, Ae, _, _ = ct.expand_weighted_qp(rec)
         qs.append(np.sort(rec["q"])); shapes.append(list(Ae.shape))
     assert np.allclose(qs, g["q"]) and shapes == g["A_shapes"].tolist()
+
+
+@pytest.mark.parametrize("i", range(3))
+def test_flat_oracle_reproduces_reference_on_the_reach_variant(i):
+    """Non-linear equality (end-effector target) -> abs penalty with two slacks per row
+    (prob.py:280-315), recorded from the reference's own modules (make_golden_reach.py)."""
+    g = np.load(os.path.join(GOLD, "trajopt_reach.npz"))
+    pr = af.make_problem(i, d=3, T=6, K=2, O=2, reach=True)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr), record_qps=True)
+    gq = ct.load_golden_qps(g, "p%d_" % i)
+    assert gq[1]["A"].shape == (3 + 24 + 2 + 46, 18 + 24 + 4)
+    _compare_sequence(gq, out.qps, "reach%d" % i)
+    assert out.success == bool(g["p%d_success" % i])
+    assert np.abs(out.x - g["p%d_x" % i]).max() < 1e-9
+    assert abs(out.max_violation - float(g["p%d_max_violation" % i])) < 1e-9
+
+
+def test_flat_oracle_reach_variant_with_analytic_jacobian():
+    g = np.load(os.path.join(GOLD, "trajopt_reach.npz"))
+    pr = af.make_problem(1, d=3, T=6, K=2, O=2, reach=True)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr, analytic_jac=True), record_qps=True)
+    _compare_sequence(ct.load_golden_qps(g, "p1a_"), out.qps, "reach1a")
+    assert np.abs(out.x - g["p1a_x"]).max() < 1e-9
+
+
+def test_mirror_api_reproduces_reference_on_the_reach_variant(oracle_qp_backend):
+    g = np.load(os.path.join(GOLD, "trajopt_reach.npz"))
+    pr = af.make_problem(0, d=3, T=6, K=2, O=2, reach=True)
+    mods = ct.mirror_mods()
+    prob, traj, _, _ = tb.build_prob(mods, pr)
+    ok = mods.Solver().solve(prob, method="penalty_sqp")
+    gold = ct.load_golden_qps(g, "p0_")
+    assert len(gold) == len(oracle_qp_backend)
+    n_x = pr["d"] * pr["T"]
+    for k, (a, rec) in enumerate(zip(gold, oracle_qp_backend)):
+        _, _, Ae, le, ue = ct.expand_weighted_qp(rec)
+        P2, q2, A2, l2, u2, perm = tb.canonical_qp(rec["P"], rec["q"], Ae, le, ue, n_x)
+        ct.assert_qp_close(a, P2, q2, A2, l2, u2, ("mirror-reach", k))
+        assert a["status"] == rec["status"] and a["iters"] == rec["iters"]
+        assert np.abs(a["x"] - rec["x"][perm]).max() < 1e-9
+    assert ok == bool(g["p0_success"])
+    assert np.abs(traj.get_value().ravel() - g["p0_x"]).max() < 1e-9

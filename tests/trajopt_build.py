@@ -31,12 +31,15 @@ def build_prob(mods, pr, analytic_jac=False):
             Q[a, a] += 2.0; Q[b, b] += 2.0; Q[a, b] -= 2.0; Q[b, a] -= 2.0
     prob.add_obj_expr(mods.BoundExpr(mods.QuadExpr(Q, np.zeros((1, n_x)), np.zeros((1, 1))), traj))
 
-    pins = np.zeros((2 * d, n_x))
+    reach = bool(pr.get("reach"))
+    n_pin = d if reach else 2 * d
+    pins = np.zeros((n_pin, n_x))
     for j in range(d):
         pins[j, j] = 1.0
-        pins[d + j, (T - 1) * d + j] = 1.0
-    rhs = np.concatenate([pr["start"], pr["goal"]]).reshape(-1, 1)
-    prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(mods.AffExpr(pins, np.zeros((2 * d, 1))), rhs), traj))
+        if not reach:
+            pins[d + j, (T - 1) * d + j] = 1.0
+    rhs = (pr["start"] if reach else np.concatenate([pr["start"], pr["goal"]])).reshape(-1, 1)
+    prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(mods.AffExpr(pins, np.zeros((n_pin, 1))), rhs), traj))
 
     R = pr["K"] * pr["O"]
     step_vars = []
@@ -55,6 +58,15 @@ def build_prob(mods, pr, analytic_jac=False):
                                        pr["obstacles"])
         e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
         prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(e, np.zeros((R, 1))), sv))
+    if reach:
+        # end-effector target as a non-linear equality on the last timestep (abs penalty, prob.py:280-315)
+        def fe(x, pr=pr):
+            return af.ee_pos(x.ravel(), pr["link_len"]).reshape(-1, 1)
+
+        def ge(x, pr=pr):
+            return af.ee_jac(x.ravel(), pr["link_len"])
+        e = mods.Expr(fe, ge) if analytic_jac else mods.Expr(fe)
+        prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(e, pr["target"].reshape(-1, 1)), step_vars[-1]))
     return prob, traj, step_vars, atoms
 
 
