@@ -158,6 +158,10 @@ void sco_sqp_default_params(sco_sqp_params *p);
  * Python callables, expr.py:22-41; a GPU cannot). */
 #define SCO_FAM_ARM_CIRCLES 1  /* planar serial arm, link points vs circular obstacles:
                                   g[k*O + o](theta) = r_o - || p_k(theta) - c_o ||  <= 0 */
+#define SCO_FAM_ARM_REACH 2    /* the same, but the goal pin theta[horizon-1] = goal is replaced by the
+                                  NON-LINEAR EQUALITY ee(theta[horizon-1]) = target (2 rows, end-effector
+                                  position): EqExpr on an Expr, lowered to the abs penalty with two slack
+                                  variables per row (prob.py:280-315); target via sco_sqp_load_target */
 
 /* Structure of a batch of trajectory problems (shared by all `batch` problems):
  * variables theta[t][j], t < horizon, j < dof, flattened time-major (n_x = horizon*dof);
@@ -193,6 +197,9 @@ int sco_sqp_destroy(sco_sqp *h);
 int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, const double *goal,
                  const double *link_len, const int *point_link, const double *point_frac,
                  const double *obstacles);
+/* SCO_FAM_ARM_REACH only, after sco_sqp_load: target[batch][2] end-effector position the last
+ * timestep must reach (`goal` of sco_sqp_load is then unused and may repeat `start`). */
+int sco_sqp_load_target(sco_sqp *h, const double *target);
 
 /* Run Solver.solve(prob, method="penalty_sqp") for every problem of the batch
  * (solver.py:30-105) starting from the loaded state; blocks until all are done. */

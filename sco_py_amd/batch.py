@@ -16,6 +16,7 @@ import numpy as np
 from . import _lib
 
 SCO_FAM_ARM_CIRCLES = 1
+SCO_FAM_ARM_REACH = 2
 TRACE_W = 8
 
 
@@ -26,6 +27,8 @@ class TrajOptBatch(object):
         s.t. theta[0] = start, theta[T-1] = goal,
              r_o - ||p_k(theta[t]) - c_o|| <= 0   for all t, link points k, obstacles o
 
+    (``reach=True``: the goal pin is replaced by the non-linear equality
+    ee(theta[T-1]) = target, SCO_FAM_ARM_REACH)
     solved per problem exactly like ``Solver().solve(prob, method="penalty_sqp")``.
     ``prox_count`` says how many Variables hold each atom in the equivalent object-API
     construction (it scales the projection QP of find_closest_feasible_point,
@@ -34,12 +37,14 @@ class TrajOptBatch(object):
     """
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
-                 prox_count=2):
+                 prox_count=2, reach=False):
         self.B, self.d, self.T, self.K, self.O = int(batch), int(dof), int(horizon), int(n_points), int(n_obstacles)
         self.n_x = self.d * self.T
         self.device = int(device)
         self._h = C.c_void_p()
-        desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O, SCO_FAM_ARM_CIRCLES,
+        self.reach = bool(reach)
+        desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O,
+                                SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES,
                                 1 if analytic_jac else 0, int(prox_count))
         _lib.check(_lib.load().sco_sqp_create(self.device, C.byref(desc), C.byref(self._h)))
 
@@ -60,8 +65,9 @@ class TrajOptBatch(object):
     def __exit__(self, *exc):
         self.close()
 
-    def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles):
-        """Upload per-problem data (host arrays, copied)."""
+    def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles, target=None):
+        """Upload per-problem data (host arrays, copied).  ``target`` (B, 2): end-effector
+        position of the reach variant (``goal`` is then ignored by the device)."""
         B, d, K, O = self.B, self.d, self.K, self.O
 
         def arr(a, shape, dt=np.float64):
@@ -76,6 +82,11 @@ class TrajOptBatch(object):
         _lib.check(_lib.load().sco_sqp_load(self._h, _lib.dptr(x0), _lib.dptr(start), _lib.dptr(goal),
                                             _lib.dptr(link_len), _lib.iptr(point_link), _lib.dptr(point_frac),
                                             _lib.dptr(obstacles)))
+        if self.reach:
+            if target is None:
+                raise ValueError("the reach variant needs target (B, 2)")
+            target = arr(target, (B, 2))
+            _lib.check(_lib.load().sco_sqp_load_target(self._h, _lib.dptr(target)))
 
     def solve(self, params=None, qp_settings=None):
         """Run the penalty SQP for every problem; blocks until all are done.
@@ -117,8 +128,9 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
     generator) -> result namespace of :meth:`TrajOptBatch.fetch`."""
     a = batch_arrays
     with TrajOptBatch(a["B"], a["d"], a["T"], a["K"], a["O"], device=device, analytic_jac=analytic_jac,
-                      prox_count=prox_count) as tb:
-        tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"])
+                      prox_count=prox_count, reach=bool(a.get("reach"))) as tb:
+        tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
+                target=a.get("target"))
         tb.solve(params, qp_settings)
         res = tb.fetch()
         res.trace = tb.trace()

@@ -48,8 +48,11 @@ struct SqpScalars {
 
 struct SqpDev {
   int batch, d, T, K, O, R, n_x, n_slack, n, m_lin, m_nl, m, prox_count, analytic_jac, trace_cap;
+  // SCO_FAM_ARM_REACH: NE = 2 equality rows (end-effector x, y) on the last timestep, block index T;
+  // NB = number of constraint blocks (T or T + 1), RM = widest block (history strides)
+  int NE, NB, RM;
   // problem data
-  double *x0, *start, *goal, *link_len, *obstacles;   // [B][...]
+  double *x0, *start, *goal, *link_len, *obstacles, *target;   // [B][...]
   const int *point_link; const double *point_frac;    // [K]
   // SQP state
   double *x, *x_saved, *gsave, *J, *bmod, *trace;
@@ -57,13 +60,14 @@ struct SqpDev {
   SqpScalars *sc;
   int *active, *n_active;
   const int *jpos;   // [T*d] CSC position of J[t][0][j] in qp1's A values
+  const int *epos;   // [d]   CSC position of the first equality-row entry of column (T-1, j)
   const int *bpos;   // CSC positions are not needed for bounds: rows are contiguous
   // Q3 emulation: per timestep block, the points already seen (keys = rint(x * 1e6), the
   // reference's tuple(x.round(6))) with their f values, and the points already
   // convexified with their affine model
   int H, HC;
-  double *hkey, *hval, *ckey, *cJ, *cb;   // [B][T][H][d], [B][T][H][R], [B][T][HC][d], [B][T][HC][R*d], [B][T][HC][R]
-  int *hn, *cn;                            // [B][T]
+  double *hkey, *hval, *ckey, *cJ, *cb;   // [B][NB][H][d], [B][NB][H][RM], [B][NB][HC][d], [B][NB][HC][RM*d], [B][NB][HC][RM]
+  int *hn, *cn;                            // [B][NB]
 };
 
 struct sco_sqp {
@@ -74,7 +78,7 @@ struct sco_sqp {
   hipStream_t stream = nullptr;
   std::vector<void *> allocs;
   std::vector<hipEvent_t> events;
-  bool loaded = false, solved = false;
+  bool loaded = false, solved = false, target_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   int rounds = 0;
 };
@@ -154,6 +158,57 @@ __device__ __forceinline__ double arm_row_grad(const double *th, const double *l
   return -(dx * sx + dy * sy) / sqrt(dx * dx + dy * dy);
 }
 
+// SCO_FAM_ARM_REACH: component `comp` (0 = x, 1 = y) of the end-effector position
+__device__ __forceinline__ double arm_ee(const double *th, const double *len, int d, int comp, int pert, double h) {
+  double phi = 0.0, p = 0.0;
+  for (int i = 0; i < d; i++) {
+    double a = th[i];
+    if (i == pert) a += h;
+    phi += a;
+    double sn, cs;
+    sincos(phi, &sn, &cs);
+    p += len[i] * (comp == 0 ? cs : sn);
+  }
+  return p;
+}
+__device__ __forceinline__ double arm_ee_grad(const double *th, const double *len, int d, int comp, int j) {
+  double phi = 0.0, g = 0.0;
+  for (int i = 0; i < d; i++) {
+    phi += th[i];
+    double sn, cs;
+    sincos(phi, &sn, &cs);
+    if (i >= j) g += comp == 0 ? -(len[i] * sn) : len[i] * cs;
+  }
+  return g;
+}
+
+// Non-linear row e of a problem: hinge rows (timestep-major, R per timestep) first, then the NE
+// equality rows of the reach variant on the last timestep (constraint block index T).
+struct RowRef { int blk, t, r, eq; };
+__device__ __forceinline__ RowRef row_ref(int e, int T, int R) {
+  RowRef q;
+  if (e < T * R) { q.blk = e / R; q.t = q.blk; q.r = e % R; q.eq = 0; }
+  else { q.blk = T; q.t = T - 1; q.r = e - T * R; q.eq = 1; }
+  return q;
+}
+
+struct RowCtx { const double *len, *obs, *target; const int *point_link; const double *point_frac; int d, O; };
+// f of row q at th (the raw function value: the right-hand side val is 0 for hinge rows and
+// target[r] for equality rows and is applied by the callers, in the reference's order)
+__device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, const double *th, int pert, double h) {
+  if (q.eq) return arm_ee(th, c.len, c.d, q.r, pert, h);
+  const int kp = q.r / c.O, o = q.r % c.O;
+  return arm_row(th, c.len, c.point_link[kp], c.point_frac[kp], c.obs[3 * o], c.obs[3 * o + 1], c.obs[3 * o + 2], pert, h);
+}
+__device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, const double *th, int j) {
+  if (q.eq) return arm_ee_grad(th, c.len, c.d, q.r, j);
+  const int kp = q.r / c.O, o = q.r % c.O;
+  return arm_row_grad(th, c.len, c.point_link[kp], c.point_frac[kp], c.obs[3 * o], c.obs[3 * o + 1], j);
+}
+__device__ __forceinline__ double row_rhs(const RowCtx &c, const RowRef &q) { return q.eq ? c.target[q.r] : 0.0; }
+// violation of a row with value g = f - val: |g| for equality rows, max(g, 0) for hinge rows (prob.py:582-590)
+__device__ __forceinline__ double row_viol(const RowRef &q, double g) { return q.eq ? fabs(g) : fmax(g, 0.0); }
+
 // index of the stored point whose rounded key equals that of x (d coordinates), or -1
 __device__ __forceinline__ int memo_find(const double *keys, int count, int d, const double *x) {
   for (int h = 0; h < count; h++) {
@@ -193,7 +248,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
   for (int i = tid; i < m0; i += SCO_BLOCK) {
     double lo, hi;
     if (i < d) lo = hi = s.start[(size_t)b * d + i];
-    else if (i < 2 * d) lo = hi = s.goal[(size_t)b * d + (i - d)];
+    else if (i < s.m_lin) lo = hi = s.goal[(size_t)b * d + (i - d)];
     else { lo = -INFINITY; hi = INFINITY; }
     q0.l[(size_t)b * m0 + i] = lo; q0.u[(size_t)b * m0 + i] = hi;
     q0.w[(size_t)b * m0 + i] = 1;
@@ -205,7 +260,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
     sc.slack_cost = 1.0; sc.merit = 0.0; sc.merit_viol = 0.0;
     s.active[b] = 1;
   }
-  for (int t = tid; t < s.T; t += SCO_BLOCK) { s.hn[(size_t)b * s.T + t] = 0; s.cn[(size_t)b * s.T + t] = 0; }
+  for (int t = tid; t < s.NB; t += SCO_BLOCK) { s.hn[(size_t)b * s.NB + t] = 0; s.cn[(size_t)b * s.NB + t] = 0; }
 }
 
 struct SqpParamsDev {
@@ -246,25 +301,30 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
     double *qv = q1.q + (size_t)b * n;
     for (int i = tid; i < n; i += SCO_BLOCK) qv[i] = 0.0;
     double *Av = q1.Aval + (size_t)b * q1.nnzA;
-    // x columns: [pin 1.0]? [R hinge entries (written by convexify)] [bound 1.0]
+    // x columns: [pin 1.0]? [R hinge entries (written by convexify)] [NE equality entries]? [bound 1.0]
+    const bool goal_pin = s.m_lin == 2 * d;
     for (int col = tid; col < n_x; col += SCO_BLOCK) {
       const int t = col / d;
       int pz = q1.Ap[col];
-      if (t == 0 || t == s.T - 1) Av[pz++] = 1.0;
+      if (t == 0 || (t == s.T - 1 && goal_pin)) Av[pz++] = 1.0;
       for (int r = 0; r < s.R; r++) Av[pz++] = 0.0;
+      if (t == s.T - 1) for (int r = 0; r < s.NE; r++) Av[pz++] = 0.0;
       Av[pz] = 1.0;
     }
+    // slack columns: hinge t_i (-1 in its row); equality rows p_i (-1) then n_i (+1) (prob.py:303-312)
     for (int sidx = tid; sidx < s.n_slack; sidx += SCO_BLOCK) {
       const int pz = q1.Ap[n_x + sidx];
-      Av[pz] = -1.0; Av[pz + 1] = 1.0;
+      const int ke = sidx - s.T * s.R;
+      Av[pz] = (ke >= 0 && (ke & 1)) ? 1.0 : -1.0; Av[pz + 1] = 1.0;
     }
     double *l = q1.l + (size_t)b * m, *u = q1.u + (size_t)b * m;
     int *w = q1.w + (size_t)b * m;
     for (int i = tid; i < m; i += SCO_BLOCK) {
       double lo, hi;
       if (i < d) lo = hi = s.start[(size_t)b * d + i];
-      else if (i < 2 * d) lo = hi = s.goal[(size_t)b * d + (i - d)];
-      else if (i < s.m_lin + s.m_nl) { lo = -INFINITY; hi = 0.0; }
+      else if (i < s.m_lin) lo = hi = s.goal[(size_t)b * d + (i - d)];
+      else if (i < s.m_lin + s.T * s.R) { lo = -INFINITY; hi = 0.0; }
+      else if (i < s.m_lin + s.m_nl) { lo = 0.0; hi = 0.0; }              // equality rows: set by convexify
       else if (i < s.m_lin + s.m_nl + n_x) { lo = -INFINITY; hi = INFINITY; }
       else { lo = 0.0; hi = INFINITY; }
       l[i] = lo; u[i] = hi; w[i] = 1;
@@ -303,39 +363,40 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
 
   if (state == ST_CONVEXIFY) {
     // Q3: which blocks sit on an already-seen / already-convexified rounded point
-    __shared__ int ev_hit[256], cv_hit[256];
-    const int H = s.H, HC = s.HC;
-    double *hkey = s.hkey + (size_t)b * T * H * d, *hval = s.hval + (size_t)b * T * H * R;
-    double *ckey = s.ckey + (size_t)b * T * HC * d, *cJ = s.cJ + (size_t)b * T * HC * R * d, *cb = s.cb + (size_t)b * T * HC * R;
-    int *hn = s.hn + (size_t)b * T, *cn = s.cn + (size_t)b * T;
-    for (int t = tid; t < T; t += SCO_BLOCK) {
-      ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * d, hn[t], d, x + t * d) : -1;
-      cv_hit[t] = p.memo ? memo_find(ckey + (size_t)t * HC * d, cn[t], d, x + t * d) : -1;
+    __shared__ int ev_hit[260], cv_hit[260];
+    const int H = s.H, HC = s.HC, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
+    const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O};
+    double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
+    double *ckey = s.ckey + (size_t)b * NB * HC * d, *cJ = s.cJ + (size_t)b * NB * HC * RM * d, *cb = s.cb + (size_t)b * NB * HC * RM;
+    int *hn = s.hn + (size_t)b * NB, *cn = s.cn + (size_t)b * NB;
+    for (int t = tid; t < NB; t += SCO_BLOCK) {
+      const double *xb = x + (t < T ? t : T - 1) * d;      // block T (equality rows) lives on the last timestep
+      ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * d, hn[t], d, xb) : -1;
+      cv_hit[t] = p.memo ? memo_find(ckey + (size_t)t * HC * d, cn[t], d, xb) : -1;
     }
     __syncthreads();
     // S1: f(x) per row, memoised on the rounded point (expr.py:34-41)
-    for (int e = tid; e < T * R; e += SCO_BLOCK) {
-      const int t = e / R, r = e % R, kp = r / O, o = r % O;
+    for (int e = tid; e < m_nl; e += SCO_BLOCK) {
+      const RowRef q = row_ref(e, T, R);
       double g;
-      if (ev_hit[t] >= 0) g = hval[((size_t)t * H + ev_hit[t]) * R + r];
+      if (ev_hit[q.blk] >= 0) g = hval[((size_t)q.blk * H + ev_hit[q.blk]) * RM + q.r];
       else {
-        g = arm_row(x + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
-        if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * R + r] = g;
+        g = row_value(rc, q, x + q.t * d, -1, 0.0);
+        if (p.memo && hn[q.blk] < H) hval[((size_t)q.blk * H + hn[q.blk]) * RM + q.r] = g;
       }
       gs[e] = g;
     }
     // S1/S2: Jacobian entry per thread (expr.py:61-69 numeric / :88 analytic); a block whose
-    // rounded point was convexified before reuses that affine model (expr.py:362-365)
-    for (int e = tid; e < T * R * d; e += SCO_BLOCK) {
-      const int j = e % d, r = (e / d) % R, t = e / (d * R), kp = r / O, o = r % O;
-      const double *th = x + t * d;
-      const int lk = s.point_link[kp];
-      const double fr = s.point_frac[kp], cx = obs[3 * o], cy = obs[3 * o + 1], rad = obs[3 * o + 2];
+    // rounded point was convexified before reuses that affine model (expr.py:362-365, 323-332)
+    for (int e = tid; e < m_nl * d; e += SCO_BLOCK) {
+      const int j = e % d;
+      const RowRef q = row_ref(e / d, T, R);
+      const double *th = x + q.t * d;
       double val;
-      if (cv_hit[t] >= 0) {
-        val = cJ[(((size_t)t * HC + cv_hit[t]) * R + r) * d + j];
+      if (cv_hit[q.blk] >= 0) {
+        val = cJ[(((size_t)q.blk * HC + cv_hit[q.blk]) * RM + q.r) * d + j];
       } else if (s.analytic_jac) {
-        val = arm_row_grad(th, len, lk, fr, cx, cy, j);
+        val = row_grad(rc, q, th, j);
       } else {
         // central differences on a halving ladder + Richardson extrapolation
         const double h0 = FD_BASE * fmax(1.0, fabs(th[j]));
@@ -343,8 +404,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
 #pragma unroll
         for (int lv = 0; lv < FD_LEVELS; lv++) {
           const double h = h0 / (double)(1 << lv);
-          const double fp = arm_row(th, len, lk, fr, cx, cy, rad, j, h);
-          const double fm = arm_row(th, len, lk, fr, cx, cy, rad, j, -h);
+          const double fp = row_value(rc, q, th, j, h);
+          const double fm = row_value(rc, q, th, j, -h);
           tab[lv] = (fp - fm) / (2.0 * h);
         }
         double p4 = 4.0;
@@ -358,48 +419,54 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         val = tab[FD_LEVELS - 1];
       }
       J[e] = val;
-      if (p.memo && cv_hit[t] < 0 && cn[t] < HC) cJ[(((size_t)t * HC + cn[t]) * R + r) * d + j] = val;
+      if (p.memo && cv_hit[q.blk] < 0 && cn[q.blk] < HC) cJ[(((size_t)q.blk * HC + cn[q.blk]) * RM + q.r) * d + j] = val;
       if (!spawned) mask[e] = (val != 0.0) ? 1 : 0;   // creation-time pattern (prob.py:264, 440)
     }
     __syncthreads();
-    // S2: affine model b = f - J x - val (expr.py:141, 367), val = 0;  S3: rows
+    // S2: affine model b = f - J x - val (expr.py:141, 367 / 328);  S3: rows
     if (p.duplicate_rows) k_rows += 1; else k_rows = 1;
     slack_cost = p.compound_penalty ? slack_cost * penalty : penalty;
     double *Av = q1.Aval + (size_t)b * q1.nnzA;
-    double *u = q1.u + (size_t)b * m;
+    double *l = q1.l + (size_t)b * m, *u = q1.u + (size_t)b * m;
     int *w = q1.w + (size_t)b * m;
-    for (int e = tid; e < T * R; e += SCO_BLOCK) {
-      const int t = e / R;
+    for (int e = tid; e < m_nl; e += SCO_BLOCK) {
+      const RowRef q = row_ref(e, T, R);
       double acc = 0.0;
-      for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * x[t * d + j];
-      double bb = gs[e] - acc;
-      const int r_ = e % R;
-      if (cv_hit[t] >= 0) bb = cb[((size_t)t * HC + cv_hit[t]) * R + r_];
-      else if (p.memo && cn[t] < HC) cb[((size_t)t * HC + cn[t]) * R + r_] = bb;
+      for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * x[q.t * d + j];
+      double bb = (gs[e] - acc) - row_rhs(rc, q);
+      if (cv_hit[q.blk] >= 0) bb = cb[((size_t)q.blk * HC + cv_hit[q.blk]) * RM + q.r];
+      else if (p.memo && cn[q.blk] < HC) cb[((size_t)q.blk * HC + cn[q.blk]) * RM + q.r] = bb;
       bm[e] = bb;
-      u[s.m_lin + e] = -bb;            // -inf <= a x - t <= -b  (prob.py:265-275, 486)
+      u[s.m_lin + e] = -bb;            // hinge: -inf <= a x - t <= -b  (prob.py:265-275, 486)
+      if (q.eq) l[s.m_lin + e] = -bb;  // abs:   a x - p + n = -b        (prob.py:303-312, 480-484)
       w[s.m_lin + e] = k_rows;         // row present k times (prob.py:508-509)
     }
-    for (int e = tid; e < T * R * d; e += SCO_BLOCK) {
-      const int j = e % d, r = (e / d) % R, t = e / (d * R);
-      Av[s.jpos[t * d + j] + r] = mask[e] ? J[e] : 0.0;   // prob.py:493-504
+    for (int e = tid; e < m_nl * d; e += SCO_BLOCK) {
+      const int j = e % d;
+      const RowRef q = row_ref(e / d, T, R);
+      const int pos = q.eq ? s.epos[j] + q.r : s.jpos[q.t * d + j] + q.r;
+      Av[pos] = mask[e] ? J[e] : 0.0;   // prob.py:493-504
     }
     double *qv = q1.q + (size_t)b * n;
     for (int i = tid; i < s.n_slack; i += SCO_BLOCK) qv[n_x + i] = slack_cost;   // prob.py:424-426
     // S7: merit at the convexification point (prob.py:571-579), S4 prerequisite: save
     double v[2] = {traj_obj_partial(x, d, T, tid), 0.0};
-    for (int e = tid; e < T * R; e += SCO_BLOCK) v[1] += fmax(gs[e], 0.0);
+    for (int e = tid; e < m_nl; e += SCO_BLOCK) {
+      const RowRef q = row_ref(e, T, R);
+      v[1] += row_viol(q, gs[e] - row_rhs(rc, q));
+    }
     block_reduce_sm<2, 0>(v, red);
     for (int i = tid; i < n_x; i += SCO_BLOCK) xs[i] = x[i];
     // commit the new history entries (keys last, after every value has been written)
     if (p.memo)
-      for (int t = tid; t < T; t += SCO_BLOCK) {
+      for (int t = tid; t < NB; t += SCO_BLOCK) {
+        const double *xb = x + (t < T ? t : T - 1) * d;
         if (ev_hit[t] < 0 && hn[t] < H) {
-          for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(x[t * d + j] * 1e6);
+          for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(xb[j] * 1e6);
           hn[t] += 1;
         }
         if (cv_hit[t] < 0 && cn[t] < HC) {
-          for (int j = 0; j < d; j++) ckey[((size_t)t * HC + cn[t]) * d + j] = rint(x[t * d + j] * 1e6);
+          for (int j = 0; j < d; j++) ckey[((size_t)t * HC + cn[t]) * d + j] = rint(xb[j] * 1e6);
           cn[t] += 1;
         }
       }
@@ -440,34 +507,37 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   const bool ok = (status == 1 || status == 2);                 // prob.py:197
   const double *xq = ok ? (q1.x + (size_t)b * n) : xs;          // failed QP leaves the variables alone
   // Q3: blocks of the trial point that round onto an already-seen point reuse its f values
-  __shared__ int ev_hit[256];
-  const int H = s.H;
-  double *hkey = s.hkey + (size_t)b * T * H * d, *hval = s.hval + (size_t)b * T * H * R;
-  int *hn = s.hn + (size_t)b * T;
-  for (int t = tid; t < T; t += SCO_BLOCK)
-    ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * d, hn[t], d, xq + t * d) : -1;
+  __shared__ int ev_hit[260];
+  const int H = s.H, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
+  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O};
+  double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
+  int *hn = s.hn + (size_t)b * NB;
+  for (int t = tid; t < NB; t += SCO_BLOCK)
+    ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * d, hn[t], d, xq + (t < T ? t : T - 1) * d) : -1;
   __syncthreads();
   // model violation uses the FULL Jacobian (prob.py:627-628), new violation f at the new point (prob.py:575-577)
   double v[4] = {traj_obj_partial(xq, d, T, tid), 0.0, 0.0, 0.0};
-  for (int e = tid; e < T * R; e += SCO_BLOCK) {
-    const int t = e / R, r = e % R, kp = r / O, o = r % O;
+  for (int e = tid; e < m_nl; e += SCO_BLOCK) {
+    const RowRef q = row_ref(e, T, R);
+    const double rhs = row_rhs(rc, q);
     double acc = 0.0;
-    for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * xq[t * d + j];
-    v[1] += fmax(acc + bm[e], 0.0);
+    for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * xq[q.t * d + j];
+    v[1] += row_viol(q, acc + bm[e]);
     double g;
-    if (ev_hit[t] >= 0) g = hval[((size_t)t * H + ev_hit[t]) * R + r];
+    if (ev_hit[q.blk] >= 0) g = hval[((size_t)q.blk * H + ev_hit[q.blk]) * RM + q.r];
     else {
-      g = arm_row(xq + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
-      if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * R + r] = g;
+      g = row_value(rc, q, xq + q.t * d, -1, 0.0);
+      if (p.memo && hn[q.blk] < H) hval[((size_t)q.blk * H + hn[q.blk]) * RM + q.r] = g;
     }
-    v[2] += fmax(g, 0.0);
-    v[3] = fmax(v[3], fmax(gs[e], 0.0));                        // max violation at the SAVED point
+    v[2] += row_viol(q, g - rhs);
+    v[3] = fmax(v[3], row_viol(q, gs[e] - rhs));                 // max violation at the SAVED point
   }
   __syncthreads();
   if (p.memo)
-    for (int t = tid; t < T; t += SCO_BLOCK)
+    for (int t = tid; t < NB; t += SCO_BLOCK)
       if (ev_hit[t] < 0 && hn[t] < H) {
-        for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(xq[t * d + j] * 1e6);
+        const double *xb = xq + (t < T ? t : T - 1) * d;
+        for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(xb[j] * 1e6);
         hn[t] += 1;
       }
   block_reduce_sm<3, 1>(v, red);
@@ -523,11 +593,12 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *
   const double *x = s.x + (size_t)b * n_x;
   const double *len = s.link_len + (size_t)b * d;
   const double *obs = s.obstacles + (size_t)b * O * 3;
+  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O};
   double v[3] = {traj_obj_partial(x, d, T, tid), 0.0, 0.0};
-  for (int e = tid; e < T * R; e += SCO_BLOCK) {
-    const int t = e / R, r = e % R, kp = r / O, o = r % O;
-    const double g = arm_row(x + t * d, len, s.point_link[kp], s.point_frac[kp], obs[3 * o], obs[3 * o + 1], obs[3 * o + 2], -1, 0.0);
-    v[1] += fmax(g, 0.0); v[2] = fmax(v[2], fmax(g, 0.0));
+  for (int e = tid; e < s.m_nl; e += SCO_BLOCK) {
+    const RowRef q = row_ref(e, T, R);
+    const double g = row_viol(q, row_value(rc, q, x + q.t * d, -1, 0.0) - row_rhs(rc, q));
+    v[1] += g; v[2] = fmax(v[2], g);
   }
   block_reduce_sm<2, 1>(v, red);
   if (tid == 0) { merit_out[b] = v[0] + s.sc[b].penalty * v[1]; viol_out[b] = v[2]; }
@@ -559,7 +630,7 @@ static int sq_alloc(sco_sqp *h, size_t count, T **out) {
 extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
   if (!desc || !out) { sco_set_error("sco_sqp_create: null pointer"); return SCO_ERR_ARG; }
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
-      desc->horizon > 256 || desc->family != SCO_FAM_ARM_CIRCLES) {
+      desc->horizon > 256 || (desc->family != SCO_FAM_ARM_CIRCLES && desc->family != SCO_FAM_ARM_REACH)) {
     sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
   }
   int ndev = 0;
@@ -574,7 +645,10 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
   h->device = device; h->desc = *desc;
   SCO_HIP(hipStreamCreate(&h->stream));
   const int B = desc->batch, d = desc->dof, T = desc->horizon, K = desc->n_points, O = desc->n_obstacles;
-  const int R = K * O, n_x = d * T, n_slack = T * R, n = n_x + n_slack, m_lin = 2 * d, m_nl = T * R, m = m_lin + m_nl + n;
+  const bool reach = desc->family == SCO_FAM_ARM_REACH;
+  const int NE = reach ? 2 : 0;                  // equality rows (end-effector x, y) on the last timestep
+  const int R = K * O, n_x = d * T, n_slack = T * R + 2 * NE, n = n_x + n_slack, m_lin = reach ? d : 2 * d;
+  const int m_nl = T * R + NE, m = m_lin + m_nl + n;
   // ---- projection QP pattern: P = diag, A = [pins ; I]
   {
     std::vector<int> Pp(n_x + 1), Pi(n_x), Ap(n_x + 1), Ai;
@@ -584,7 +658,7 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
       Ap[col] = (int)Ai.size();
       const int t = col / d, j = col % d;
       if (t == 0) Ai.push_back(j);
-      if (t == T - 1) Ai.push_back(d + j);
+      if (t == T - 1 && !reach) Ai.push_back(d + j);
       Ai.push_back(m_lin + col);
     }
     Ap[n_x] = (int)Ai.size();
@@ -592,7 +666,7 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
     if (rc) { delete h; return rc; }
   }
   // ---- penalty QP pattern (prob.py:251-278 rows, osqp_utils.py:185-189 bound rows)
-  std::vector<int> jpos(n_x);
+  std::vector<int> jpos(n_x), epos(d, 0);
   {
     std::vector<int> Pp(n + 1), Pi, Ap(n + 1), Ai;
     for (int col = 0; col < n; col++) {
@@ -608,13 +682,18 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
       if (col < n_x) {
         const int t = col / d, j = col % d;
         if (t == 0) Ai.push_back(j);
-        if (t == T - 1) Ai.push_back(d + j);
+        if (t == T - 1 && !reach) Ai.push_back(d + j);
         jpos[col] = (int)Ai.size();
         for (int r = 0; r < R; r++) Ai.push_back(m_lin + t * R + r);
+        if (t == T - 1 && reach) {
+          epos[j] = (int)Ai.size();
+          for (int r = 0; r < NE; r++) Ai.push_back(m_lin + T * R + r);
+        }
         Ai.push_back(m_lin + m_nl + col);
       } else {
+        // hinge slack i sits in hinge row i; equality row r has p_r (slack T R + 2 r) and n_r (+ 1)
         const int sidx = col - n_x;
-        Ai.push_back(m_lin + sidx);
+        Ai.push_back(m_lin + (sidx < T * R ? sidx : T * R + (sidx - T * R) / 2));
         Ai.push_back(m_lin + m_nl + col);
       }
     }
@@ -626,21 +705,25 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
   s.batch = B; s.d = d; s.T = T; s.K = K; s.O = O; s.R = R; s.n_x = n_x; s.n_slack = n_slack; s.n = n;
   s.m_lin = m_lin; s.m_nl = m_nl; s.m = m; s.prox_count = desc->prox_count > 0 ? desc->prox_count : 1;
   s.analytic_jac = desc->analytic_jac; s.trace_cap = 64;
+  s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE);
   int rc = 0;
 #define AL(f, cnt) if ((rc = sq_alloc(h, (cnt), &s.f))) return rc;
   AL(x0, (size_t)B * n_x) AL(start, (size_t)B * d) AL(goal, (size_t)B * d) AL(link_len, (size_t)B * d)
-  AL(obstacles, (size_t)B * O * 3)
+  AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2)
   AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
   AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
   AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, 1)
   s.H = 40; s.HC = 24;
-  AL(hkey, (size_t)B * T * s.H * d) AL(hval, (size_t)B * T * s.H * R) AL(ckey, (size_t)B * T * s.HC * d)
-  AL(cJ, (size_t)B * T * s.HC * R * d) AL(cb, (size_t)B * T * s.HC * R) AL(hn, (size_t)B * T) AL(cn, (size_t)B * T)
+  AL(hkey, (size_t)B * s.NB * s.H * d) AL(hval, (size_t)B * s.NB * s.H * s.RM) AL(ckey, (size_t)B * s.NB * s.HC * d)
+  AL(cJ, (size_t)B * s.NB * s.HC * s.RM * d) AL(cb, (size_t)B * s.NB * s.HC * s.RM) AL(hn, (size_t)B * s.NB)
+  AL(cn, (size_t)B * s.NB)
 #undef AL
   { int *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_link = p; }
   { double *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_frac = p; }
   { int *p; if ((rc = sq_alloc(h, (size_t)n_x, &p))) return rc; s.jpos = p;
     SCO_HIP(hipMemcpy(p, jpos.data(), n_x * sizeof(int), hipMemcpyHostToDevice)); }
+  { int *p; if ((rc = sq_alloc(h, (size_t)d, &p))) return rc; s.epos = p;
+    SCO_HIP(hipMemcpy(p, epos.data(), d * sizeof(int), hipMemcpyHostToDevice)); }
   s.bpos = nullptr;
   *out = h;
   return SCO_OK;
@@ -682,6 +765,17 @@ extern "C" int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, c
   return SCO_OK;
 }
 
+extern "C" int sco_sqp_load_target(sco_sqp *h, const double *target) {
+  if (!h || !target) { sco_set_error("sco_sqp_load_target: null pointer"); return SCO_ERR_ARG; }
+  if (h->desc.family != SCO_FAM_ARM_REACH) { sco_set_error("sco_sqp_load_target: family has no target"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_load_target: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  SCO_HIP(hipSetDevice(h->device));
+  SCO_HIP(hipMemcpyAsync(h->d.target, target, (size_t)h->d.batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipStreamSynchronize(h->stream));
+  h->target_loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
 static hipEvent_t next_event(sco_sqp *h, size_t &cursor) {
   if (cursor == h->events.size()) {
     hipEvent_t e; (void)hipEventCreate(&e); h->events.push_back(e);
@@ -692,6 +786,9 @@ static hipEvent_t next_event(sco_sqp *h, size_t &cursor) {
 extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco_qp_settings *qs) {
   if (!h || !params || !qs) { sco_set_error("sco_sqp_solve: null pointer"); return SCO_ERR_ARG; }
   if (!h->loaded) { sco_set_error("sco_sqp_solve: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  if (h->desc.family == SCO_FAM_ARM_REACH && !h->target_loaded) {
+    sco_set_error("sco_sqp_solve: call sco_sqp_load_target first"); return SCO_ERR_STATE;
+  }
   SCO_HIP(hipSetDevice(h->device));
   SqpDev &s = h->d;
   SqpParamsDev p{params->improve_ratio_threshold, params->min_trust_region_size, params->min_approx_improve,
