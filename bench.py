@@ -45,6 +45,49 @@ def cpu_baseline(n_problems, first, dims):
     return iters / dt, dt, iters
 
 
+_CPU_WORKER = """
+import sys
+sys.path.insert(0, sys.argv[1])
+from oracle import arm_family as af
+from oracle import sco_ref as sr
+dims = dict(d=int(sys.argv[2]), T=int(sys.argv[3]), K=int(sys.argv[4]), O=int(sys.argv[5]))
+it = 0
+for i in sys.argv[6:]:
+    it += sr.penalty_sqp(sr.trajopt_flat(af.make_problem(int(i), **dims)), emulate_memo=True).sqp_iters
+print(it)
+"""
+
+
+def cpu_baseline_all_cores(dims, per_core=2, timeout=240):
+    """One oracle process per host core of this box, each solving `per_core` problems (the generous
+    CPU baseline of SURVEY 8(d); the reference itself is single-threaded).  Plain child processes,
+    started before anything touches the GPU; returns None if a worker fails or overruns."""
+    import subprocess
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    t0 = time.perf_counter()
+    procs = []
+    for c in range(cores):
+        ids = [str(c * per_core + k) for k in range(per_core)]
+        procs.append(subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT] +
+                                      [str(dims[k]) for k in ("d", "T", "K", "O")] + ids,
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
+    iters, ok = 0, True
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=max(1.0, timeout - (time.perf_counter() - t0)))
+            iters += int(out.decode().strip())
+        except Exception:
+            ok = False
+            pr.kill()
+    dt = time.perf_counter() - t0
+    if not ok:
+        return None
+    return {"value": iters / dt, "unit": "sco_iters/s", "cores": cores, "kind": "port",
+            "sample": "problems 0..%d of the same batch, one oracle process per core, %.1f s incl. start-up"
+                      % (cores * per_core - 1, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +104,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu_all = None
+    if world == 1 and args.cpu_problems > 0 and args.workload == "7x20":
+        cpu_all = cpu_baseline_all_cores(dict(d=7, T=20, K=5, O=2))
     import torch
     import torch.distributed as dist
     # rehearsal on a 1-GPU box: SCO_BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo
@@ -193,6 +239,8 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "sco_iters/s", "cores": 1, "kind": "port",
                                    "sample": "problems 0..%d of the same batch, oracle/sco_ref.py + "
                                              "oracle/osqp_ref.c, %.1f s" % (args.cpu_problems - 1, dt)}
+        if cpu_all is not None:
+            out["aux"]["cpu_baseline_all_cores"] = cpu_all
         print(json.dumps(out))
     tb.close()
     if world > 1:

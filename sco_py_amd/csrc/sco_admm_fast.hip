@@ -453,11 +453,15 @@ int fast_upload(const FastHost &fh, std::vector<void *> &allocs, FastDev &fd) {
 
 template <int TR, int TC, int CW, int RW, int PA, int PE>
 static int launch_one(const AdmmArgs &a, const FastDev &fd, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  // hipFuncSetAttribute applies to the current device only
+  static bool attr_done[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  dev_ &= 63;
+  if (!attr_done[dev_]) {
     SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_fast_kernel<TR, TC, CW, RW, PA, PE>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done[dev_] = true;
   }
   hipLaunchKernelGGL((qp_admm_fast_kernel<TR, TC, CW, RW, PA, PE>), dim3(a.d.batch), dim3(FT), lds, st, a, fd);
   SCO_HIP(hipGetLastError());

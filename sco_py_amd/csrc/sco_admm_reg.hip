@@ -505,11 +505,15 @@ int reg_upload(const RegHost &rh, std::vector<void *> &allocs, RegDev &rd) {
 
 template <int TR, int TC, int CW, int RW, int PX>
 static int reg_launch_one(const RegArgs &ra, int batch, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  // hipFuncSetAttribute applies to the current device only
+  static bool attr_done[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  dev_ &= 63;
+  if (!attr_done[dev_]) {
     SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_reg_kernel<TR, TC, CW, RW, PX>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 44032));
-    attr_done = true;
+    attr_done[dev_] = true;
   }
   hipLaunchKernelGGL((qp_admm_reg_kernel<TR, TC, CW, RW, PX>), dim3(batch), dim3(RT), lds, st, ra);
   SCO_HIP(hipGetLastError());

@@ -661,11 +661,15 @@ int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd) {
 
 template <int TR, int TC>
 static int rl_launch_one(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  // hipFuncSetAttribute applies to the current device only
+  static bool attr_done[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  dev_ &= 63;
+  if (!attr_done[dev_]) {
     SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 108 * 1024));
-    attr_done = true;
+    attr_done[dev_] = true;
   }
   hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC>), dim3(batch), dim3(LT), lds, st, ra);
   SCO_HIP(hipGetLastError());

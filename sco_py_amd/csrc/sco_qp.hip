@@ -563,6 +563,9 @@ static size_t setup_lds_doubles(const QpPlan &pl) {
          (size_t)pl.n_c * (pl.n_c + 1) / 2;
 }
 
+static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const int *Pp, const int *Pi,
+                          const int *Ap, const int *Ai, hipStream_t stream);
+
 int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, const int *Pi,
                             const int *Ap, const int *Ai, hipStream_t stream, sco_qp **out) {
   if (!out || batch <= 0 || n <= 0 || m < 0 || !Pp || !Ap) { sco_set_error("sco_qp_create: bad argument"); return SCO_ERR_ARG; }
@@ -576,9 +579,17 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
   SCO_HIP(hipSetDevice(device));
   sco_qp *qp = new sco_qp();
   qp->device = device;
+  const int rc = qp_create_impl(qp, device, batch, n, m, Pp, Pi, Ap, Ai, stream);
+  if (rc) { sco_qp_destroy(qp); return rc; }      // frees whatever had been allocated
+  *out = qp;
+  return SCO_OK;
+}
+
+static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const int *Pp, const int *Pi,
+                          const int *Ap, const int *Ai, hipStream_t stream) {
   const char *no_elim = getenv("SCO_QP_NO_ELIM");
   int rc = qp_plan_build(n, m, Pp, Pi, Ap, Ai, (no_elim && no_elim[0] == '1') ? 0 : 1, qp->plan);
-  if (rc != 0) { delete qp; sco_set_error("sco_qp_create: malformed sparsity pattern"); return SCO_ERR_ARG; }
+  if (rc != 0) { sco_set_error("sco_qp_create: malformed sparsity pattern"); return SCO_ERR_ARG; }
   const QpPlan &pl = qp->plan;
   qp->lds_setup = setup_lds_doubles(pl) * sizeof(double);
   qp->lds_admm = admm_lds_doubles(n, m, pl.nnzA, pl.n_e, pl.n_c, pl.ncpl) * sizeof(double) + (size_t)m * sizeof(int);
@@ -590,7 +601,7 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
       char buf[256];
       snprintf(buf, sizeof buf, "sco_qp_create: pattern not supported (setup %zu B, admm %zu B of LDS, core %d)",
                qp->lds_setup, qp->lds_admm, pl.n_c);
-      delete qp; sco_set_error(buf); return SCO_ERR_CAPACITY;
+      sco_set_error(buf); return SCO_ERR_CAPACITY;
     }
     qp->use_big = true;
     const char *no_bt = getenv("SCO_QP_NO_BT");
@@ -626,7 +637,6 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
     int r_ = big_upload(qp->big, qp->use_bt ? 1 : batch, qp->allocs, qp->bigd);   // dense workspace unused by bt
     if (r_) return r_;
     if (qp->use_bt && (r_ = bt_upload(qp->bt, batch, qp->allocs, qp->btd))) return r_;
-    *out = qp;
     return SCO_OK;
   }
   {
@@ -654,7 +664,6 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
       qp->use_fast = true;
     }
   }
-  *out = qp;
   return SCO_OK;
 }
 

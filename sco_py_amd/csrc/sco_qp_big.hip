@@ -1205,10 +1205,14 @@ int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &t
 
 template <int BS>
 static int bt_launch_bs(const BigArgs &ba, int batch, size_t lds, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  // hipFuncSetAttribute applies to the current device only
+  static bool attr_done[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  dev_ &= 63;
+  if (!attr_done[dev_]) {
     SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_bt_kernel<BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-    attr_done = true;
+    attr_done[dev_] = true;
   }
   hipLaunchKernelGGL(qp_bt_factor_kernel<BS>, dim3(batch), dim3(256), 0, st, ba);
   SCO_HIP(hipGetLastError());

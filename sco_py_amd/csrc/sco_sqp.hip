@@ -627,6 +627,8 @@ static int sq_alloc(sco_sqp *h, size_t count, T **out) {
   return SCO_OK;
 }
 
+static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc);
+
 extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
   if (!desc || !out) { sco_set_error("sco_sqp_create: null pointer"); return SCO_ERR_ARG; }
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
@@ -643,6 +645,13 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
   SCO_HIP(hipSetDevice(device));
   sco_sqp *h = new sco_sqp();
   h->device = device; h->desc = *desc;
+  const int rc = sqp_create_impl(h, device, desc);
+  if (rc) { sco_sqp_destroy(h); return rc; }       // frees whatever had been allocated
+  *out = h;
+  return SCO_OK;
+}
+
+static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc) {
   SCO_HIP(hipStreamCreate(&h->stream));
   const int B = desc->batch, d = desc->dof, T = desc->horizon, K = desc->n_points, O = desc->n_obstacles;
   const bool reach = desc->family == SCO_FAM_ARM_REACH;
@@ -663,7 +672,7 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
     }
     Ap[n_x] = (int)Ai.size();
     int rc = sco_qp_create_on_stream(device, B, n_x, m_lin + n_x, Pp.data(), Pi.data(), Ap.data(), Ai.data(), h->stream, &h->qp0);
-    if (rc) { delete h; return rc; }
+    if (rc) return rc;
   }
   // ---- penalty QP pattern (prob.py:251-278 rows, osqp_utils.py:185-189 bound rows)
   std::vector<int> jpos(n_x), epos(d, 0);
@@ -699,7 +708,7 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
     }
     Ap[n] = (int)Ai.size();
     int rc = sco_qp_create_on_stream(device, B, n, m, Pp.data(), Pi.data(), Ap.data(), Ai.data(), h->stream, &h->qp1);
-    if (rc) { sco_qp_destroy(h->qp0); delete h; return rc; }
+    if (rc) return rc;
   }
   SqpDev &s = h->d;
   s.batch = B; s.d = d; s.T = T; s.K = K; s.O = O; s.R = R; s.n_x = n_x; s.n_slack = n_slack; s.n = n;
@@ -725,7 +734,6 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
   { int *p; if ((rc = sq_alloc(h, (size_t)d, &p))) return rc; s.epos = p;
     SCO_HIP(hipMemcpy(p, epos.data(), d * sizeof(int), hipMemcpyHostToDevice)); }
   s.bpos = nullptr;
-  *out = h;
   return SCO_OK;
 }
 
