@@ -65,13 +65,16 @@ def cpu_baseline_all_cores(dims, per_core=2, timeout=240):
     import subprocess
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
+    # children never touch the GPU: drop any profiler preload / tool hooks from their environment
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER"))}
     t0 = time.perf_counter()
     procs = []
     for c in range(cores):
         ids = [str(c * per_core + k) for k in range(per_core)]
         procs.append(subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT] +
                                       [str(dims[k]) for k in ("d", "T", "K", "O")] + ids,
-                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env))
     iters, ok = 0, True
     for pr in procs:
         try:
