@@ -97,7 +97,23 @@ def default_points(d, K):
     return link, frac
 
 
-def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False):
+def block_groups(T, reach, scheme):
+    """Constraint-group ids per non-linear block (T timestep blocks, then the reach block):
+    scheme "halves" puts every block in "all" and the first / second half of the horizon in
+    "head" / "tail" (so "all" overlaps both), the reach block in "all" and "reach"; scheme
+    "split" uses the disjoint groups "head", "tail" (and "reach") only."""
+    if scheme is None:
+        return None
+    assert scheme in ("halves", "split")
+    if scheme == "split":            # disjoint groups, no "all": one stalled half ends the minimisation
+        return [["head"] if t < T // 2 else ["tail"] for t in range(T)] + ([["reach"]] if reach else [])
+    g = [["all", "head"] if t < T // 2 else ["all", "tail"] for t in range(T)]
+    if reach:
+        g.append(["all", "reach"])
+    return g
+
+
+def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None):
     """Seeded problem i of the batch.  reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
@@ -118,6 +134,8 @@ def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False):
                point_link=point_link, point_frac=point_frac, obstacles=obstacles, reach=is_reach)
     if is_reach:
         out["target"] = ee_pos(goal, link_len)
+    if groups is not None:
+        out["groups"] = block_groups(T, is_reach, groups)      # prob.add_cnt_expr(..., group_ids=...)
     return out
 
 
@@ -126,6 +144,8 @@ def make_batch(B, first=0, **kw):
     probs = [make_problem(first + i, **kw) for i in range(B)]
     p0 = probs[0]
     extra = dict(reach=True, target=np.stack([p["target"] for p in probs])) if p0.get("reach") else {}
+    if p0.get("groups") is not None:
+        extra["groups"] = p0["groups"]
     return dict(
         d=p0["d"], T=p0["T"], K=p0["K"], O=p0["O"], B=B, **extra,
         x0=np.stack([p["x0"] for p in probs]),

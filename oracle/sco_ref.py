@@ -58,9 +58,10 @@ class Block(object):
     """One non-linear constraint BoundExpr: kind 'leq' | 'eq', callable f on the
     block's own variables x[idx], optional analytic jac, right-hand side val."""
 
-    def __init__(self, kind, f, idx, val, jac=None):
+    def __init__(self, kind, f, idx, val, jac=None, groups=None):
         assert kind in ("leq", "eq")
         self.kind, self.f, self.jac = kind, f, jac
+        self.groups = list(groups) if groups is not None else ["all"]      # prob.py:135-142
         self.idx = np.asarray(idx, dtype=np.int64)
         self.val = np.asarray(val, dtype=np.float64).ravel()
         self.r = self.val.shape[0]
@@ -219,6 +220,16 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
     Pfull = sp.block_diag([Ptri, sp.csc_matrix((n_slack, n_slack))], format="csc") if n_slack else Ptri
     state = dict(slack_cost=1.0, k=0, masks=None)
 
+    # constraint groups (prob.py:81-86, 135-142): sorted ids, member blocks, overlap graph
+    gids = sorted(set(g for b in p.blocks for g in b.groups))
+    gind = {g: i for i, g in enumerate(gids)}
+    members = [[k for k, b in enumerate(p.blocks) if g in b.groups] for g in gids]
+    overlap = [sorted(set(gind[h] for b in p.blocks if g in b.groups for h in b.groups if h != g)) for g in gids]
+    st.nonconverged = []
+
+    def group_vec(per_block):
+        return np.array([sum(per_block[k] for k in mem) for mem in members])
+
     def max_violation():
         worst = 0.0
         for b in p.blocks:
@@ -257,9 +268,10 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
             lo_top = np.concatenate([p.lin_lo] + lo) if lo else p.lin_lo
             hi_top = np.concatenate([p.lin_hi] + hi) if hi else p.lin_hi
             # merit at the convexification point (prob.py:571-579)
-            viol = sum(float(np.sum(b.violation(st.x[b.idx]))) for b in p.blocks)
+            bviol = [float(np.sum(b.violation(st.x[b.idx]))) for b in p.blocks]
+            viol = sum(bviol)
             merit = quad_obj(st.x) + penalty * viol
-            merit_vec = viol
+            merit_vec = group_vec(bviol)                      # get_value(vectorize=True), prob.py:558-570
             st.x_saved = st.x.copy()
             while True:
                 # trust region on x, slacks in [0, inf) (variable.py:43-45, prob.py:454)
@@ -272,11 +284,13 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
                 if res.info.status_val in (1, 2):                 # prob.py:197-203
                     st.x = res.x[:n_x].copy()
                 # model merit (prob.py:605-630): full Jacobian, not the masked rows
-                mviol = 0.0
+                bmviol = []
                 for b, (Am, bm) in zip(p.blocks, models):
                     v = Am.dot(st.x[b.idx]) + bm
-                    mviol += float(np.sum(np.abs(v) if b.kind == "eq" else np.maximum(v, 0.0)))
+                    bmviol.append(float(np.sum(np.abs(v) if b.kind == "eq" else np.maximum(v, 0.0))))
+                mviol = sum(bmviol)
                 model_merit = quad_obj(st.x) + penalty * mviol
+                model_vec = group_vec(bmviol)                 # get_approx_value(vectorize=True), prob.py:617-622
                 nviol = sum(float(np.sum(b.violation(st.x[b.idx]))) for b in p.blocks)
                 new_merit = quad_obj(st.x) + penalty * nviol
 
@@ -285,17 +299,25 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
                     approx += 1e-12
                 exact = merit - new_merit
                 ratio = exact / approx
-                if p.blocks:      # single group "all" (prob.py:135-136)
-                    approx_vec, violated = merit_vec - mviol, merit_vec > P_.cnt_tolerance
-                else:
-                    approx_vec, violated = approx, True
+                approx_vec, violated = merit_vec - model_vec, merit_vec > P_.cnt_tolerance
                 rec = (merit, model_merit, new_merit, trust, penalty, res)
                 if approx < -1e-5:                                # _bad_model
                     st.x = st.x_saved.copy(); record(STEP_BAD, *rec); return False, trust
                 if approx < P_.min_approx_improve:                # _y_converged
                     st.x = st.x_saved.copy(); record(STEP_YCONV, *rec); return True, trust
-                if p.blocks and violated and approx_vec < P_.min_approx_improve:
-                    st.x = st.x_saved.copy(); record(STEP_GROUP, *rec); return True, trust
+                # a violated group that no longer improves, and none of whose overlapping groups
+                # does either, ends the merit minimisation (solver.py:209-235)
+                stalled = []
+                for g in range(len(gids)):
+                    if violated[g] and approx_vec[g] < P_.min_approx_improve:
+                        if not any(approx_vec[h] > P_.min_approx_improve for h in overlap[g]):
+                            stalled.append(g)
+                if stalled:
+                    st.x = st.x_saved.copy(); record(STEP_GROUP, *rec)
+                    st.nonconverged = sorted(set(stalled) | set(
+                        g for g in range(len(gids)) if violated[g] and approx_vec[g] < P_.min_approx_improve))
+                    return True, trust
+                st.nonconverged = []
                 if exact < 0 or ratio < P_.improve_ratio_threshold:
                     st.x = st.x_saved.copy(); record(STEP_SHRINK, *rec)
                     trust = trust * P_.trust_shrink_ratio
@@ -328,6 +350,8 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
     out.qps = st.qps
     out.sqp_iters, out.qp_solves, out.admm_iters = st.sqp_iters, st.qp_solves, st.admm_iters
     out.max_violation = max_violation() if p.blocks else 0.0
+    out.group_ids = gids
+    out.nonconverged_groups = [gids[g] for g in st.nonconverged]
     out.merit = quad_obj(st.x) + penalty * sum(float(np.sum(b.violation(st.x[b.idx]))) for b in p.blocks)
     return out
 
@@ -359,11 +383,13 @@ def trajopt_flat(prob, analytic_jac=False):
         jac = None
         if analytic_jac:
             jac = (lambda th, pr=prob: af.arm_dist_jac(th, pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"]))
-        blocks.append(Block("leq", f, np.arange(t * d, (t + 1) * d), np.zeros(R), jac=jac))
+        blocks.append(Block("leq", f, np.arange(t * d, (t + 1) * d), np.zeros(R), jac=jac,
+                            groups=prob["groups"][t] if prob.get("groups") is not None else None))
     if reach:
         f = (lambda th, pr=prob: af.ee_pos(th, pr["link_len"]))
         jac = (lambda th, pr=prob: af.ee_jac(th, pr["link_len"])) if analytic_jac else None
-        blocks.append(Block("eq", f, np.arange((T - 1) * d, T * d), prob["target"], jac=jac))
+        blocks.append(Block("eq", f, np.arange((T - 1) * d, T * d), prob["target"], jac=jac,
+                            groups=prob["groups"][T] if prob.get("groups") is not None else None))
     # the object-API construction (tests/trajopt_build.py) binds every atom to two
     # Variables: the whole trajectory and its timestep block
     return FlatProblem(prob["x0"], Q.tocsc(), np.zeros(n_x), 0.0, lin.tocsr(), rhs, rhs, blocks,

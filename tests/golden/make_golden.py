@@ -108,7 +108,7 @@ def run_reference_tests():
     return int(rc)
 
 
-def run_trajopt(mods, pr, analytic_jac=False):
+def run_trajopt(mods, pr, analytic_jac=False, solver_attrs=None):
     import trajopt_build as tb
     del QP_LOG[:]
     prob, traj, step_vars, atoms = tb.build_prob(mods, pr, analytic_jac=analytic_jac)
@@ -127,6 +127,9 @@ def run_trajopt(mods, pr, analytic_jac=False):
 
     prob.get_value, prob.get_approx_value = get_value, get_approx_value
     solver = mods.Solver()
+    for k, v in (solver_attrs or {}).items():      # public attributes of Solver (solver.py:17-28)
+        assert hasattr(solver, k), k
+        setattr(solver, k, v)
     ok = solver.solve(prob, method="penalty_sqp")
     n_x = pr["d"] * pr["T"]
     qps = []
@@ -137,7 +140,8 @@ def run_trajopt(mods, pr, analytic_jac=False):
             P2, q2, A2, l2, u2, perm = tb.canonical_qp(rec["P"], rec["q"], rec["A"], rec["l"], rec["u"], n_x)
         qps.append(dict(P=P2, q=q2, A=A2, l=l2, u=u2, x=rec["x"][perm], status=rec["status"], iters=rec["iters"]))
     return dict(success=bool(ok), x=traj.get_value().ravel(), qps=qps, merit_log=np.array(merit_log),
-                max_violation=float(prob.get_max_cnt_violation()))
+                max_violation=float(prob.get_max_cnt_violation()),
+                nonconverged=sorted(set(prob.nonconverged_groups)))
 
 
 def pack(prefix, res, out, sparse=False):
@@ -146,6 +150,7 @@ def pack(prefix, res, out, sparse=False):
     out[prefix + "merit_log"] = res["merit_log"]
     out[prefix + "max_violation"] = np.array(res["max_violation"])
     out[prefix + "n_qp"] = np.array(len(res["qps"]))
+    out[prefix + "nonconverged"] = np.array(res.get("nonconverged", []), dtype="U16")
     for k, qp in enumerate(res["qps"]):
         base = "%sqp%d_" % (prefix, k)
         for name in ("q", "l", "u", "x"):

@@ -170,3 +170,42 @@ def test_mirror_api_reproduces_reference_on_the_reach_variant(oracle_qp_backend)
         assert np.abs(a["x"] - rec["x"][perm]).max() < 1e-9
     assert ok == bool(g["p0_success"])
     assert np.abs(traj.get_value().ravel() - g["p0_x"]).max() < 1e-9
+
+
+def _group_cases():
+    sys_path = os.path.join(GOLD)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_groups_cases", os.path.join(sys_path, "make_golden_groups.py"))
+    src = open(spec.origin).read()
+    ns = {}
+    exec(src[src.index("SMALL ="):src.index("def main")], ns)     # the CASES table only (no reference import)
+    return ns["CASES"]
+
+
+@pytest.mark.parametrize("case", _group_cases(), ids=lambda c: c[0])
+def test_flat_oracle_reproduces_reference_with_constraint_groups(case):
+    """prob.add_cnt_expr(..., group_ids=...): per-group merit vectors, overlap graph and
+    nonconverged_groups (prob.py:81-86, 135-142, 558-570, 617-622; solver.py:155-161, 209-235),
+    recorded from the reference's own modules (make_golden_groups.py)."""
+    prefix, kw, i, knobs = case
+    g = np.load(os.path.join(GOLD, "trajopt_groups.npz"))
+    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i, **kw)), sr.SolverParams(**(knobs or {})), record_qps=True)
+    _compare_sequence(ct.load_golden_qps(g, prefix), out.qps, prefix)
+    assert out.success == bool(g[prefix + "success"])
+    assert np.abs(out.x - g[prefix + "x"]).max() < 1e-9
+    assert sorted(out.nonconverged_groups) == sorted(str(s) for s in g[prefix + "nonconverged"])
+
+
+@pytest.mark.parametrize("prefix,i", [("s22_", 22), ("s58_", 58)])
+def test_mirror_api_reproduces_reference_with_constraint_groups(prefix, i, oracle_qp_backend):
+    g = np.load(os.path.join(GOLD, "trajopt_groups.npz"))
+    pr = af.make_problem(i, d=3, T=6, K=2, O=2, groups="split", reach=True)
+    mods = ct.mirror_mods()
+    prob, traj, _, _ = tb.build_prob(mods, pr)
+    ok = mods.Solver().solve(prob, method="penalty_sqp")
+    gold = ct.load_golden_qps(g, prefix)
+    assert len(gold) == len(oracle_qp_backend)
+    assert [a["iters"] for a in gold] == [r["iters"] for r in oracle_qp_backend]
+    assert ok == bool(g[prefix + "success"])
+    assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 1e-9
+    assert sorted(set(prob.nonconverged_groups)) == sorted(str(s) for s in g[prefix + "nonconverged"])

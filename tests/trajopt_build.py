@@ -57,7 +57,8 @@ def build_prob(mods, pr, analytic_jac=False):
                 return af.arm_dist_jac(x.ravel(), pr["link_len"], pr["point_link"], pr["point_frac"],
                                        pr["obstacles"])
         e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
-        prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(e, np.zeros((R, 1))), sv))
+        gids = pr["groups"][t] if pr.get("groups") is not None else None
+        prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(e, np.zeros((R, 1))), sv), gids)
     if reach:
         # end-effector target as a non-linear equality on the last timestep (abs penalty, prob.py:280-315)
         def fe(x, pr=pr):
@@ -66,7 +67,8 @@ def build_prob(mods, pr, analytic_jac=False):
         def ge(x, pr=pr):
             return af.ee_jac(x.ravel(), pr["link_len"])
         e = mods.Expr(fe, ge) if analytic_jac else mods.Expr(fe)
-        prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(e, pr["target"].reshape(-1, 1)), step_vars[-1]))
+        gids = pr["groups"][T] if pr.get("groups") is not None else None
+        prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(e, pr["target"].reshape(-1, 1)), step_vars[-1]), gids)
     return prob, traj, step_vars, atoms
 
 
