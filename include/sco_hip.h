@@ -201,6 +201,16 @@ int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, const double
  * timestep must reach (`goal` of sco_sqp_load is then unused and may repeat `start`). */
 int sco_sqp_load_target(sco_sqp *h, const double *target);
 
+/* Constraint groups (prob.add_cnt_expr(bound_expr, group_ids), prob.py:112-142): n_groups <= 32 group ids
+ * in SORTED order (the reference sorts them, prob.py:538, 559); block_mask[n_blocks], n_blocks = horizon
+ * (+ 1 for the equality block of SCO_FAM_ARM_REACH, last): bit g set = that constraint block belongs to
+ * group g.  Groups sharing a block overlap (prob.py:139-142).  Never called = one group "all" holding
+ * every block (prob.py:135-136).  Shared by the batch; call before sco_sqp_solve. */
+int sco_sqp_set_groups(sco_sqp *h, int n_groups, const unsigned int *block_mask);
+/* nonconverged[batch]: bit g set = group g is in prob.nonconverged_groups after the last solve
+ * (violated and no longer improving when _min_merit_fn last returned, solver.py:209-235). */
+int sco_sqp_fetch_groups(sco_sqp *h, unsigned int *nonconverged);
+
 /* Run Solver.solve(prob, method="penalty_sqp") for every problem of the batch
  * (solver.py:30-105) starting from the loaded state; blocks until all are done. */
 int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco_qp_settings *qp_settings);

@@ -88,6 +88,20 @@ class TrajOptBatch(object):
             target = arr(target, (B, 2))
             _lib.check(_lib.load().sco_sqp_load_target(self._h, _lib.dptr(target)))
 
+    def set_groups(self, block_groups):
+        """Constraint groups (``prob.add_cnt_expr(bound_expr, group_ids)``): one list of group ids
+        per constraint block (T timestep blocks, then the reach block).  Ids are sorted like the
+        reference sorts them; ``fetch().nonconverged_groups`` reports them by name."""
+        nb = self.T + (1 if self.reach else 0)
+        if len(block_groups) != nb:
+            raise ValueError("expected %d blocks, got %d" % (nb, len(block_groups)))
+        gids = sorted(set(g for blk in block_groups for g in blk))
+        if not 1 <= len(gids) <= 32 or any(len(blk) == 0 for blk in block_groups):
+            raise ValueError("1..32 group ids, every block in at least one group")
+        mask = np.array([sum(1 << gids.index(g) for g in set(blk)) for blk in block_groups], dtype=np.uint32)
+        _lib.check(_lib.load().sco_sqp_set_groups(self._h, len(gids), mask.ctypes.data_as(C.POINTER(C.c_uint))))
+        self.group_ids = gids
+
     def solve(self, params=None, qp_settings=None):
         """Run the penalty SQP for every problem; blocks until all are done.
         May be called repeatedly: every call restarts from the loaded state."""
@@ -105,8 +119,12 @@ class TrajOptBatch(object):
         _lib.check(_lib.load().sco_sqp_fetch(
             self._h, _lib.dptr(x), _lib.iptr(success), _lib.iptr(sqp_iters), _lib.iptr(qp_solves),
             admm.ctypes.data_as(C.POINTER(C.c_longlong)), _lib.dptr(merit), _lib.dptr(viol)))
+        nc = np.zeros(B, dtype=np.uint32)
+        _lib.check(_lib.load().sco_sqp_fetch_groups(self._h, nc.ctypes.data_as(C.POINTER(C.c_uint))))
+        gids = getattr(self, "group_ids", ["all"])
+        groups = [[g for k, g in enumerate(gids) if (int(m) >> k) & 1] for m in nc]
         return SimpleNamespace(x=x, success=success.astype(bool), sqp_iters=sqp_iters, qp_solves=qp_solves,
-                               admm_iters=admm, merit=merit, max_violation=viol)
+                               admm_iters=admm, merit=merit, max_violation=viol, nonconverged_groups=groups)
 
     def trace(self, cap=64):
         """Per-problem decision trace: list of (n_rows, 8) arrays with columns
@@ -131,6 +149,8 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
                       prox_count=prox_count, reach=bool(a.get("reach"))) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                 target=a.get("target"))
+        if a.get("groups") is not None:
+            tb.set_groups(a["groups"])
         tb.solve(params, qp_settings)
         res = tb.fetch()
         res.trace = tb.trace()

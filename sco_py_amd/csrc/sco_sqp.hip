@@ -61,6 +61,12 @@ struct SqpDev {
   int *active, *n_active;
   const int *jpos;   // [T*d] CSC position of J[t][0][j] in qp1's A values
   const int *epos;   // [d]   CSC position of the first equality-row entry of column (T-1, j)
+  // constraint groups (prob.py:81-86, 135-142): G = 0 means the default single group "all"
+  int G;
+  const unsigned int *gmask;      // [NB] groups of every constraint block
+  const unsigned int *goverlap;   // [32] groups sharing a block with group g
+  double *mvec;                   // [B][32] per-group violation at the convexification point
+  unsigned int *nonconv;          // [B] prob.nonconverged_groups
   const int *bpos;   // CSC positions are not needed for bounds: rows are contiguous
   // Q3 emulation: per timestep block, the points already seen (keys = rint(x * 1e6), the
   // reference's tuple(x.round(6))) with their f values, and the points already
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
     sc.state = ST_PROJECT; sc.k = 0; sc.sqp_iters = 0; sc.qp_solves = 0; sc.success = 0;
     sc.escalations = 0; sc.n_trace = 0; sc.spawned = 0; sc.admm_iters = 0;
     sc.slack_cost = 1.0; sc.merit = 0.0; sc.merit_viol = 0.0;
-    s.active[b] = 1;
+    s.active[b] = 1; s.nonconv[b] = 0u;
   }
   for (int t = tid; t < s.NB; t += SCO_BLOCK) { s.hn[(size_t)b * s.NB + t] = 0; s.cn[(size_t)b * s.NB + t] = 0; }
 }
@@ -456,6 +462,23 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
       v[1] += row_viol(q, gs[e] - row_rhs(rc, q));
     }
     block_reduce_sm<2, 0>(v, red);
+    if (s.G > 0) {
+      // get_value(vectorize=True): per-block sums, then per-group sums in block order (prob.py:558-570)
+      __shared__ double bsum[260];
+      for (int blk = tid; blk < NB; blk += SCO_BLOCK) {
+        const int e0 = blk < T ? blk * R : T * R, cnt = blk < T ? R : s.NE;
+        double acc = 0.0;
+        for (int e = e0; e < e0 + cnt; e++) { const RowRef q = row_ref(e, T, R); acc += row_viol(q, gs[e] - row_rhs(rc, q)); }
+        bsum[blk] = acc;
+      }
+      __syncthreads();
+      for (int g = tid; g < s.G; g += SCO_BLOCK) {
+        double acc = 0.0;
+        for (int blk = 0; blk < NB; blk++) if ((s.gmask[blk] >> g) & 1u) acc += bsum[blk];
+        s.mvec[(size_t)b * 32 + g] = acc;
+      }
+      __syncthreads();
+    }
     for (int i = tid; i < n_x; i += SCO_BLOCK) xs[i] = x[i];
     // commit the new history entries (keys last, after every value has been written)
     if (p.memo)
@@ -541,6 +564,44 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
         hn[t] += 1;
       }
   block_reduce_sm<3, 1>(v, red);
+  // constraint groups: which violated groups stopped improving, and do their overlapping groups too
+  // (solver.py:155-161, 209-235)
+  __shared__ unsigned int g_stalled, g_report;
+  if (s.G > 0) {
+    __shared__ double bsum[260], gimp[32];
+    for (int blk = tid; blk < NB; blk += SCO_BLOCK) {
+      const int e0 = blk < T ? blk * R : T * R, cnt = blk < T ? R : s.NE;
+      double acc = 0.0;
+      for (int e = e0; e < e0 + cnt; e++) {
+        const RowRef q = row_ref(e, T, R);
+        double ax = 0.0;
+        for (int j = 0; j < d; j++) ax += J[(size_t)e * d + j] * xq[q.t * d + j];
+        acc += row_viol(q, ax + bm[e]);
+      }
+      bsum[blk] = acc;
+    }
+    __syncthreads();
+    for (int g = tid; g < s.G; g += SCO_BLOCK) {
+      double acc = 0.0;
+      for (int blk = 0; blk < NB; blk++) if ((s.gmask[blk] >> g) & 1u) acc += bsum[blk];
+      gimp[g] = s.mvec[(size_t)b * 32 + g] - acc;         // approx_improve_vec
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int stalled = 0, report = 0;
+      for (int g = 0; g < s.G; g++) {
+        const bool viol_g = s.mvec[(size_t)b * 32 + g] > p.cnt_tolerance;
+        if (!(viol_g && gimp[g] < p.min_approx_improve)) continue;
+        report |= 1u << g;
+        bool overlap_improve = false;
+        for (int h = 0; h < s.G; h++)
+          if (((s.goverlap[g] >> h) & 1u) && gimp[h] > p.min_approx_improve) overlap_improve = true;
+        if (!overlap_improve) stalled |= 1u << g;
+      }
+      g_stalled = stalled; g_report = report;
+    }
+    __syncthreads();
+  }
   const double model_merit = v[0] + pen * v[1], new_merit = v[0] + pen * v[2];
   double approx = merit - model_merit;
   if (approx == 0.0) approx += 1e-12;                           // solver.py:152-153
@@ -552,7 +613,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   double new_trust = trust;
   if (approx < -1e-5) { kind = STEP_BAD; ret = 0; }                               // solver.py:185-198
   else if (approx < p.min_approx_improve) { kind = STEP_YCONV; ret = 1; }         // solver.py:200-204
-  else if (violated && approx_vec < p.min_approx_improve) { kind = STEP_GROUP; ret = 1; }   // solver.py:209-235
+  else if (s.G > 0 ? g_stalled != 0u : (violated && approx_vec < p.min_approx_improve)) { kind = STEP_GROUP; ret = 1; }   // solver.py:209-235
   else if (exact < 0.0 || ratio < p.improve_ratio_threshold) {                   // solver.py:237-241
     kind = STEP_SHRINK; new_trust = trust * p.trust_shrink_ratio;
     if (new_trust < p.min_trust_region_size) { kind = STEP_XCONV; ret = 1; }      // solver.py:248-251
@@ -562,6 +623,10 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   if (kind == STEP_ACCEPT) for (int i = tid; i < n_x; i += SCO_BLOCK) x[i] = xq[i];
   // every other outcome restores the saved point (solver.py:197, 203, 229, 238); x == xs already
   if (tid == 0) {
+    // prob.nonconverged_groups is rewritten by every trust-region trial that gets past the
+    // y-convergence test (solver.py:209, 233-235)
+    if (kind != STEP_BAD && kind != STEP_YCONV)
+      s.nonconv[b] = (kind == STEP_GROUP) ? (s.G > 0 ? g_report : 1u) : 0u;
     sc.qp_solves = qp_solves; sc.admm_iters += iters;
     trace_row(s, b, sc, kind, merit, model_merit, new_merit, trust, pen, status, iters);
     sc.trust = new_trust;
@@ -731,6 +796,11 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   { double *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_frac = p; }
   { int *p; if ((rc = sq_alloc(h, (size_t)n_x, &p))) return rc; s.jpos = p;
     SCO_HIP(hipMemcpy(p, jpos.data(), n_x * sizeof(int), hipMemcpyHostToDevice)); }
+  { unsigned int *p; if ((rc = sq_alloc(h, (size_t)s.NB, &p))) return rc; s.gmask = p; }
+  { unsigned int *p; if ((rc = sq_alloc(h, (size_t)32, &p))) return rc; s.goverlap = p; }
+  if ((rc = sq_alloc(h, (size_t)B * 32, &s.mvec))) return rc;
+  if ((rc = sq_alloc(h, (size_t)B, &s.nonconv))) return rc;
+  s.G = 0;
   { int *p; if ((rc = sq_alloc(h, (size_t)d, &p))) return rc; s.epos = p;
     SCO_HIP(hipMemcpy(p, epos.data(), d * sizeof(int), hipMemcpyHostToDevice)); }
   s.bpos = nullptr;
@@ -781,6 +851,33 @@ extern "C" int sco_sqp_load_target(sco_sqp *h, const double *target) {
   SCO_HIP(hipMemcpyAsync(h->d.target, target, (size_t)h->d.batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   SCO_HIP(hipStreamSynchronize(h->stream));
   h->target_loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_set_groups(sco_sqp *h, int n_groups, const unsigned int *block_mask) {
+  if (!h || !block_mask) { sco_set_error("sco_sqp_set_groups: null pointer"); return SCO_ERR_ARG; }
+  if (n_groups < 1 || n_groups > 32) { sco_set_error("sco_sqp_set_groups: 1..32 groups"); return SCO_ERR_ARG; }
+  SqpDev &s = h->d;
+  const unsigned int all = n_groups == 32 ? 0xffffffffu : ((1u << n_groups) - 1u);
+  unsigned int overlap[32] = {0};
+  for (int blk = 0; blk < s.NB; blk++) {
+    const unsigned int mk = block_mask[blk];
+    if (mk == 0u || (mk & ~all)) { sco_set_error("sco_sqp_set_groups: every block needs a group < n_groups"); return SCO_ERR_ARG; }
+    for (int g = 0; g < n_groups; g++) if ((mk >> g) & 1u) overlap[g] |= mk & ~(1u << g);    // prob.py:139-142
+  }
+  SCO_HIP(hipSetDevice(h->device));
+  SCO_HIP(hipMemcpy((void *)s.gmask, block_mask, (size_t)s.NB * sizeof(unsigned int), hipMemcpyHostToDevice));
+  SCO_HIP(hipMemcpy((void *)s.goverlap, overlap, sizeof overlap, hipMemcpyHostToDevice));
+  s.G = n_groups;
+  h->solved = false;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_fetch_groups(sco_sqp *h, unsigned int *nonconverged) {
+  if (!h || !nonconverged) return SCO_ERR_ARG;
+  if (!h->solved) { sco_set_error("sco_sqp_fetch_groups: call sco_sqp_solve first"); return SCO_ERR_STATE; }
+  SCO_HIP(hipSetDevice(h->device));
+  SCO_HIP(hipMemcpy(nonconverged, h->d.nonconv, (size_t)h->d.batch * sizeof(unsigned int), hipMemcpyDeviceToHost));
   return SCO_OK;
 }
 

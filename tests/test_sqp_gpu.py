@@ -232,3 +232,42 @@ def test_reach_family_needs_its_target(gpu):
         with pytest.raises(ValueError):
             tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
                     arrays["point_frac"], arrays["obstacles"])
+
+
+def _compare_groups(res, probs, which, oracle_params=None):
+    _compare(res, probs, which, oracle_params)
+    for b in which:
+        ref = sr.penalty_sqp(sr.trajopt_flat(probs[b]), oracle_params, emulate_memo=True)
+        assert sorted(res.nonconverged_groups[b]) == sorted(ref.nonconverged_groups), (b, res.nonconverged_groups[b])
+
+
+@pytest.mark.parametrize("scheme,reach", [("halves", False), ("split", True), ("split", False)])
+def test_constraint_groups_on_device(gpu, scheme, reach):
+    """prob.add_cnt_expr(..., group_ids): per-group merit vectors, overlap graph, nonconverged groups
+    (solver.py:155-161, 209-235) in the device loop, against the oracle (itself pinned to reference
+    runs with groups, tests/test_golden.py)."""
+    kw = dict(d=3, T=6, K=2, O=2, groups=scheme, reach=reach)
+    arrays, probs = af.make_batch(12, first=8, **kw)      # problems 10, 13 stall a group
+    res = sb.solve_batch(arrays)
+    _compare_groups(res, probs, range(12))
+    knobs = dict(initial_penalty_coeff=10.0, max_merit_coeff_increases=3)
+    _compare_groups(sb.solve_batch(arrays, params=_lib.default_sqp_params(**knobs)), probs, range(12), sr.SolverParams(**knobs))
+
+
+def test_constraint_groups_match_reference_golden_runs(gpu):
+    g = np.load(os.path.join(GOLD, "trajopt_groups.npz"))
+    for prefix, i in (("s22_", 22), ("s35_", 35), ("s38_", 38), ("s58_", 58)):
+        arrays, _ = af.make_batch(1, first=i, d=3, T=6, K=2, O=2, groups="split", reach=True)
+        res = sb.solve_batch(arrays)
+        assert np.abs(res.x[0] - g[prefix + "x"]).max() < TOL
+        assert bool(res.success[0]) == bool(g[prefix + "success"])
+        assert sorted(res.nonconverged_groups[0]) == sorted(str(s) for s in g[prefix + "nonconverged"])
+        assert [int(v) for v in res.trace[0][:, 7]] == [int(g["%sqp%d_iters" % (prefix, k)]) for k in range(int(g[prefix + "n_qp"]))]
+
+
+def test_default_group_is_all(gpu):
+    arrays, probs = af.make_batch(3, first=10, d=3, T=6, K=2, O=2)
+    res = sb.solve_batch(arrays)
+    for b in range(3):
+        ref = sr.penalty_sqp(sr.trajopt_flat(probs[b]), emulate_memo=True)
+        assert res.nonconverged_groups[b] == ref.nonconverged_groups
