@@ -767,6 +767,41 @@ __device__ __forceinline__ double bt_wave_sum63(double v) {
   return v;
 }
 
+// Column totals of NC per-lane values over the wavefront with the gfx950 lane-swap instructions:
+// v_permlane32_swap folds the two 32-lane halves of two columns into one register, v_permlane16_swap
+// folds the 16-lane rows of two such registers, and a row_shr scan finishes inside the rows: 63
+// instructions for 12 columns instead of 12 full wavefront reductions.  Fixed association order.
+typedef unsigned int bt_uint2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double bt_fold32(double a, double b) {
+  const bt_uint2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const bt_uint2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double bt_fold16(double a, double b) {
+  const bt_uint2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const bt_uint2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+// v[k] = value of column k in this lane (0 for idle lanes / unused columns); dst[k] <- sum over the wavefront
+template <int NC>
+__device__ __forceinline__ void bt_reduce_cols(const double (&v)[NC], double *dst, int ncols, int lane) {
+  static_assert(NC % 4 == 0, "columns are processed four at a time");
+  double u[NC / 2], t[NC / 4];
+#pragma unroll
+  for (int m = 0; m < NC / 2; m++) u[m] = bt_fold32(v[2 * m], v[2 * m + 1]);     // halves: column 2m | 2m+1
+#pragma unroll
+  for (int n = 0; n < NC / 4; n++) t[n] = bt_fold16(u[2 * n], u[2 * n + 1]);     // rows: columns 4n, 4n+2, 4n+1, 4n+3
+#pragma unroll
+  for (int n = 0; n < NC / 4; n++) t[n] = bt_row16_sum(t[n]);                    // lane 15 of every row: the total
+  if ((lane & 15) == 15) {
+    const int row = lane >> 4;
+    const int off = row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
+#pragma unroll
+    for (int n = 0; n < NC / 4; n++)
+      if (4 * n + off < ncols) dst[4 * n + off] = t[n];
+  }
+}
+
 // Dense chunk: up to 64 consecutive rows r0 + lane with core entries in columns c0 .. c0 + ncols - 1
 // at CSC positions pos0 + k cs + lane; their eliminated variables e0 + lane (QP variable j0 + lane)
 // each with an optional second row r1 + lane that has no core entry.  Every address is a
@@ -825,11 +860,10 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
   if (R.on) { if (chk) q.sdx[R.j] = xn - R.xo; q.x[R.j] = xn; q.ge[R.e] = gn; }
   const double t0 = R.on ? tq0 - rwp * R.p.ae * gn : 0.0;
   if (q.s_part) {
+    double pv[NC];
 #pragma unroll
-    for (int k = 0; k < NC; k++) {
-      const double tot = bt_wave_sum63(R.av[k] * t0);
-      if (lane == 63 && k < R.ncols) q.s_part[R.pbase + k] = tot;
-    }
+    for (int k = 0; k < NC; k++) pv[k] = (k < R.ncols ? R.av[k] : 0.0) * t0;
+    bt_reduce_cols<NC>(pv, q.s_part + R.pbase, R.ncols, lane);
   } else if (R.on) {
 #pragma unroll
     for (int k = 0; k < NC; k++)
@@ -845,6 +879,80 @@ __device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const 
   if (hasB) bt_dense_load<NC>(dB, lane, q, RB);
   bt_dense_compute<NC>(RA, lane, chk, q);
   if (hasB) bt_dense_compute<NC>(RB, lane, chk, q);
+}
+
+// One generic chunk (kind 1: rows walk the CSR arrays; kind 2: at most one core entry per item).
+__device__ __forceinline__ void bt_generic_chunk(const BigArgs &a, const QpDev &d, const int (&dsc)[CH_STRIDE], int ch, int lane, bool chk,
+                                                 const BtPtrs &bp, const double *As, const double *rho, const int *w, double *z, double *y,
+                                                 const double *ls, const double *us, double *ge, const double *kinv, double *x,
+                                                 const double *qs, double *sdy, double *sdx, double *prod, const double *s_xc,
+                                                 double alpha, double sigma) {
+  if (lane >= dsc[1]) return;
+  const int kind = dsc[0];
+      const int *rec = a.it + ((size_t)ch * 64 + lane) * 8;
+      if (kind == 2) {
+        // rows with at most one core entry (bound rows, pins): direct indices; every load is
+        // unconditional on a clamped index so the chunk costs two memory round trips
+        typedef int int4v __attribute__((ext_vector_type(4)));
+        const int4v ra4 = *(const int4v *)rec, rb4 = *(const int4v *)(rec + 4);
+        const int e = ra4.x, j = ra4.y, r0 = ra4.z, r1 = ra4.w, ep0 = rb4.x, ep1 = rb4.y, cc = rb4.z, cp = rb4.w;
+        const int r0c = r0 >= 0 ? r0 : 0, r1c = r1 >= 0 ? r1 : r0c, ec = e >= 0 ? e : 0, jc = j >= 0 ? j : 0;
+        const double a0 = As[cp >= 0 ? cp : 0];
+        BtRow p{0.0, As[ep0 >= 0 ? ep0 : 0], rho[r0c], (double)w[r0c], z[r0c], y[r0c], ls[r0c], us[r0c]};
+        BtRow q{0.0, As[ep1 >= 0 ? ep1 : 0], rho[r1c], (double)w[r1c], z[r1c], y[r1c], ls[r1c], us[r1c]};
+        const double g = ge[ec], ki = e >= 0 ? kinv[ec] : 0.0, xo = x[jc], qj = qs[jc];
+        if (cp >= 0) p.zc = a0 * s_xc[cc];
+        if (r0 < 0 || e < 0) p.ae = 0.0;
+        if (r1 < 0 || e < 0) q.ae = 0.0;
+        if (r0 < 0) p.w = 0.0;
+        if (r1 < 0) q.w = 0.0;
+        const double rwp = p.w * p.rh, rwq = q.w * q.rh;
+        const double xte = e >= 0 ? g - ki * (rwp * p.ae * p.zc + rwq * q.ae * q.zc) : 0.0;
+        double zn, yn, dy, tq0 = 0.0, tq1 = 0.0;
+        if (r0 >= 0) { tq0 = bt_row_step(p, alpha, xte, zn, yn, dy); z[r0] = zn; y[r0] = yn; if (chk) sdy[r0] = dy; }
+        if (r1 >= 0) { tq1 = bt_row_step(q, alpha, xte, zn, yn, dy); z[r1] = zn; y[r1] = yn; if (chk) sdy[r1] = dy; }
+        double gn = 0.0;
+        if (e >= 0) {
+          const double xn = alpha * xte + (1.0 - alpha) * xo;
+          if (chk) sdx[j] = xn - xo;
+          x[j] = xn;
+          gn = ((sigma * xn - qj) + p.ae * tq0 + q.ae * tq1) * ki;
+          ge[e] = gn;
+        }
+        if (cp >= 0) prod[cp] = a0 * (tq0 - rwp * p.ae * gn);
+        return;
+      }
+      const int e = rec[0], r0 = rec[2], r1 = rec[3];
+      BtRow p{0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0}, q = p;
+      if (r0 >= 0) p = BtRow{big_row_core_dot(d, As, s_xc, r0), 0.0, rho[r0], (double)w[r0], z[r0], y[r0], ls[r0], us[r0]};
+      if (r1 >= 0) q = BtRow{big_row_core_dot(d, As, s_xc, r1), 0.0, rho[r1], (double)w[r1], z[r1], y[r1], ls[r1], us[r1]};
+      double g = 0.0, ki = 0.0, xte = 0.0;
+      const double rwp = p.w * p.rh, rwq = q.w * q.rh;
+      if (e >= 0) {
+        if (r0 >= 0) p.ae = As[rec[4]];
+        if (r1 >= 0) q.ae = As[rec[5]];
+        g = ge[e]; ki = kinv[e];
+        xte = g - ki * (rwp * p.ae * p.zc + rwq * q.ae * q.zc);
+      }
+      double zn, yn, dy, tq0 = 0.0, tq1 = 0.0;
+      if (r0 >= 0) { tq0 = bt_row_step(p, alpha, xte, zn, yn, dy); z[r0] = zn; y[r0] = yn; if (chk) sdy[r0] = dy; }
+      if (r1 >= 0) { tq1 = bt_row_step(q, alpha, xte, zn, yn, dy); z[r1] = zn; y[r1] = yn; if (chk) sdy[r1] = dy; }
+      double gn = 0.0;
+      if (e >= 0) {
+        const int j = rec[1];
+        const double xo = x[j], xn = alpha * xte + (1.0 - alpha) * xo;
+        if (chk) sdx[j] = xn - xo;
+        x[j] = xn;
+        gn = ((sigma * xn - qs[j]) + p.ae * tq0 + q.ae * tq1) * ki;
+        ge[e] = gn;
+      }
+      const double t0 = tq0 - rwp * p.ae * gn, t1 = tq1 - rwq * q.ae * gn;
+      if (r0 >= 0)
+        for (int s = d.Rp[r0]; s < d.Rp[r0 + 1]; s++)
+          if (d.core_of[d.Rj[s]] >= 0) prod[d.Rpos[s]] = As[d.Rpos[s]] * t0;
+      if (r1 >= 0)
+        for (int s = d.Rp[r1]; s < d.Rp[r1 + 1]; s++)
+          if (d.core_of[d.Rj[s]] >= 0) prod[d.Rpos[s]] = As[d.Rpos[s]] * t1;
 }
 
 template <int BS>
@@ -925,7 +1033,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   double pri = 0.0, dua = 0.0;
 #ifdef SCO_STAMP
   // diagnostic build only: cycles per phase per wavefront (never compiled into the product)
-  long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
+  long long st_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
 #define BSTAMP(k) { const long long now_ = __builtin_readcyclecounter(); st_acc[k] += now_ - st_t; st_t = now_; }
 #else
 #define BSTAMP(k)
@@ -1044,8 +1152,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
       int dsc[CH_STRIDE], dsb[CH_STRIDE];          // wave-uniform: descriptor words in SGPRs
 #pragma unroll
       for (int k = 0; k < CH_STRIDE; k++) dsc[k] = __builtin_amdgcn_readfirstlane(s_dsc[ch * CH_STRIDE + k]);
-      const int kind = dsc[0], nact = dsc[1];
-      if (kind == 0) {
+      if (dsc[0] == 0) {
         const int ncols = dsc[2], chb = ch + BTWV;
         bool hasB = false;
         if (chb < a.nchunks) {
@@ -1057,58 +1164,12 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
         else if (ncols <= 8) bt_dense_pair<8>(dsc, dsb, hasB, lane, chk, bp);
         else if (ncols <= 12) bt_dense_pair<12>(dsc, dsb, hasB, lane, chk, bp);
         else bt_dense_pair<16>(dsc, dsb, hasB, lane, chk, bp);
+        BSTAMP(7)
         continue;
       }
-      if (lane >= nact) continue;
-      const int *rec = a.it + ((size_t)ch * 64 + lane) * 8;
-      const int e = rec[0], r0 = rec[2], r1 = rec[3];
-      BtRow p{0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0}, q = p;
-      int cp = -1;
-      if (kind == 2) {
-        // at most one core entry, in the first row: direct indices, loads issued together
-        const int cc = rec[6];
-        cp = rec[7];
-        const int ra = r0 >= 0 ? r0 : 0, rb = r1 >= 0 ? r1 : ra;
-        const double a0 = As[cp >= 0 ? cp : 0];
-        BtRow pl{0.0, 0.0, rho[ra], (double)w[ra], z[ra], y[ra], ls[ra], us[ra]};
-        BtRow ql{0.0, 0.0, rho[rb], (double)w[rb], z[rb], y[rb], ls[rb], us[rb]};
-        if (r0 >= 0) { p = pl; if (cp >= 0) p.zc = a0 * s_xc[cc]; }
-        if (r1 >= 0) q = ql;
-      } else {
-        if (r0 >= 0) p = BtRow{big_row_core_dot(d, As, s_xc, r0), 0.0, rho[r0], (double)w[r0], z[r0], y[r0], ls[r0], us[r0]};
-        if (r1 >= 0) q = BtRow{big_row_core_dot(d, As, s_xc, r1), 0.0, rho[r1], (double)w[r1], z[r1], y[r1], ls[r1], us[r1]};
-      }
-      double g = 0.0, ki = 0.0, xte = 0.0;
-      const double rwp = p.w * p.rh, rwq = q.w * q.rh;
-      if (e >= 0) {
-        if (r0 >= 0) p.ae = As[rec[4]];
-        if (r1 >= 0) q.ae = As[rec[5]];
-        g = ge[e]; ki = kinv[e];
-        xte = g - ki * (rwp * p.ae * p.zc + rwq * q.ae * q.zc);
-      }
-      double zn, yn, dy, tq0 = 0.0, tq1 = 0.0;
-      if (r0 >= 0) { tq0 = bt_row_step(p, alpha, xte, zn, yn, dy); z[r0] = zn; y[r0] = yn; if (chk) sdy[r0] = dy; }
-      if (r1 >= 0) { tq1 = bt_row_step(q, alpha, xte, zn, yn, dy); z[r1] = zn; y[r1] = yn; if (chk) sdy[r1] = dy; }
-      double gn = 0.0;
-      if (e >= 0) {
-        const int j = rec[1];
-        const double xo = x[j], xn = alpha * xte + (1.0 - alpha) * xo;
-        if (chk) sdx[j] = xn - xo;
-        x[j] = xn;
-        gn = ((sigma * xn - qs[j]) + p.ae * tq0 + q.ae * tq1) * ki;
-        ge[e] = gn;
-      }
-      const double t0 = tq0 - rwp * p.ae * gn, t1 = tq1 - rwq * q.ae * gn;
-      if (kind == 2) {
-        if (cp >= 0) prod[cp] = As[cp] * t0;
-      } else {
-        if (r0 >= 0)
-          for (int s = d.Rp[r0]; s < d.Rp[r0 + 1]; s++)
-            if (d.core_of[d.Rj[s]] >= 0) prod[d.Rpos[s]] = As[d.Rpos[s]] * t0;
-        if (r1 >= 0)
-          for (int s = d.Rp[r1]; s < d.Rp[r1 + 1]; s++)
-            if (d.core_of[d.Rj[s]] >= 0) prod[d.Rpos[s]] = As[d.Rpos[s]] * t1;
-      }
+      BSTAMP(7)
+      bt_generic_chunk(a, d, dsc, ch, lane, chk, bp, As, rho, w, z, y, ls, us, ge, kinv, x, qs, sdy, sdx, prod, s_xc, alpha, sigma);
+      BSTAMP(12)
     }
     BSTAMP(7)
     for (int c = tid; c < n_c; c += BTT) {
@@ -1132,7 +1193,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   if (iter > a.max_iter) iter = a.max_iter;
 #ifdef SCO_STAMP
   if (lane == 0 && b == 0 && a.stamp) {
-    for (int k = 0; k < 12; k++) a.stamp[wave * 16 + k] = (double)st_acc[k];
+    for (int k = 0; k < 14; k++) a.stamp[wave * 16 + k] = (double)st_acc[k];
     a.stamp[wave * 16 + 15] = (double)iter;
   }
 #endif

@@ -13,10 +13,10 @@ with sb.TrajOptBatch(B, 12, 50, 10, 10) as tb:
     lib = _lib.load(); lib.sco_debug_stamps_bt.argtypes = [C.POINTER(C.c_double)]
     out = np.zeros(256); print("rc", lib.sco_debug_stamps_bt(out.ctypes.data_as(C.POINTER(C.c_double))))
     st = out.reshape(16, 16)
-    names = ["(1) colsum", "bar", "fwd", "bar", "mid+bar", "bwd", "bar", "(Y) rows", "x upd", "bar", "check", "top"]
+    names = ["(1) colsum", "bar", "fwd", "bar", "mid+bar", "bwd", "bar", "(Y) dense", "x upd", "bar", "check", "top", "(Y) generic", "-"]
     it = st[0, 15]
     print("problem 0, last launch: iterations", it, " timing:", tb.last_timing())
     print("cycles per iteration by wave (rows) and segment (cols):", names)
     np.set_printoptions(linewidth=220, precision=0, suppress=True)
-    print(st[:, :12] / it)
-    print("sum per wave", (st[:, :12].sum(axis=1) / it))
+    print(st[:8, :14] / it)
+    print("sum per wave", (st[:8, :14].sum(axis=1) / it))
