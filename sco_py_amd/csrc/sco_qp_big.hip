@@ -96,7 +96,7 @@ struct BigArgs {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   int max_iter, check, scaling;
   // block-tridiagonal core (bt_bs > 0): S goes to block storage instead of the dense array
-  int bt_bs, bt_nb;
+  int bt_bs, bt_nb, bt_mid;
   double *bt_blk; size_t bt_stride;
   const int *ch_desc, *it, *cent;
   int nchunks, npart, use_part;
@@ -662,42 +662,82 @@ bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th) {
   return true;
 }
 
-// ---- block LDL' of S in place: [t][0] <- D_t^-1, [t][1] <- E_t ------------------------
+// ---- twisted block LDL' of S in place ---------------------------------------------------
+// Blocks 0 .. mid-1 are eliminated top-down, blocks nb-1 .. mid+1 bottom-up, block `mid` last, so a
+// solve is two independent chains of about nb/2 dependent steps (one wavefront each) instead of one
+// chain of nb:
+//   top     D_t = S_tt - E_t S_{t,t-1}',      E_t = S_{t,t-1} D_{t-1}^-1          (t = 1 .. mid)
+//   bottom  D_t = S_tt - G_t S_{t+1,t},       G_t = S_{t+1,t}' D_{t+1}^-1         (t = nb-2 .. mid)
+//   middle  D_mid = S_mm - E_mid S_{mid,mid-1}' - G_mid S_{mid+1,mid},   H = D_mid^-1 G_mid
+// Storage: [t][0] <- D_t^-1;  [t][1] <- E_t for 1 <= t <= mid, G_{t-1} for t > mid (the slot of
+// S_{t,t-1}, which both use up);  [0][1] <- H.
+template <int BS>
+__device__ __forceinline__ void bt_invert_spd(double *M, double *rowk, double *colk, int tid) {
+  // Gauss-Jordan inversion of a symmetric positive definite block (no pivoting needed)
+  const int i = tid / BS, j = tid % BS;
+  const bool on = tid < BS * BS;
+  for (int k = 0; k < BS; k++) {
+    if (tid < BS) {
+      const double piv = M[k * BS + k];
+      rowk[tid] = (tid == k ? 1.0 : M[k * BS + tid]) / piv;
+      colk[tid] = M[tid * BS + k];
+    }
+    __syncthreads();
+    if (on) {
+      const double v = (j == k) ? 0.0 : M[tid];
+      M[tid] = (i == k) ? rowk[j] : v - colk[i] * rowk[j];
+    }
+    __syncthreads();
+  }
+}
+
 template <int BS>
 __global__ __launch_bounds__(256) void qp_bt_factor_kernel(BigArgs a) {
   const QpDev &d = a.d;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (d.active && !d.active[b]) return;
   constexpr int BB = BS * BS;
-  __shared__ double M[BB], Sub[BB], Ev[BB], rowk[BS], colk[BS];
+  __shared__ double M[BB], Sub[BB], Ev[BB], Cb[BB], rowk[BS], colk[BS];
   double *blk = a.bt_blk + (size_t)b * a.bt_stride;
-  const int i = tid / BS, j = tid % BS;
+  const int i = tid / BS, j = tid % BS, nb = a.bt_nb, mid = a.bt_mid;
   const bool on = tid < BB;
-  if (on) M[tid] = blk[tid];
+  // ---- bottom chain: t = nb-1 .. mid+1; leaves Cb = G_mid S_{mid+1,mid} for the middle block
+  if (on) { Cb[tid] = 0.0; if (nb - 1 > mid) M[tid] = blk[(size_t)(nb - 1) * 2 * BB + tid]; }
   __syncthreads();
-  for (int t = 0; t < a.bt_nb; t++) {
-    // Gauss-Jordan inversion of the symmetric positive definite D_t (no pivoting needed)
-    for (int k = 0; k < BS; k++) {
-      if (tid < BS) {
-        const double piv = M[k * BS + k];
-        rowk[tid] = (tid == k ? 1.0 : M[k * BS + tid]) / piv;
-        colk[tid] = M[tid * BS + k];
-      }
-      __syncthreads();
-      if (on) {
-        const double v = (j == k) ? 0.0 : M[tid];
-        M[tid] = (i == k) ? rowk[j] : v - colk[i] * rowk[j];
-      }
-      __syncthreads();
+  for (int t = nb - 1; t > mid; t--) {
+    bt_invert_spd<BS>(M, rowk, colk, tid);
+    double *cur = blk + (size_t)t * 2 * BB;
+    if (on) { cur[tid] = M[tid]; Sub[tid] = cur[BB + tid]; }            // Sub = S_{t,t-1}
+    __syncthreads();
+    if (on) {
+      double g = 0.0;                                                    // G_{t-1} = S_{t,t-1}' D_t^-1
+#pragma unroll
+      for (int k = 0; k < BS; k++) g += Sub[k * BS + i] * M[k * BS + j];
+      Ev[tid] = g; cur[BB + tid] = g;
     }
+    __syncthreads();
+    if (on) {
+      double v = 0.0;                                                    // G_{t-1} S_{t,t-1}
+#pragma unroll
+      for (int k = 0; k < BS; k++) v += Ev[i * BS + k] * Sub[k * BS + j];
+      if (t - 1 > mid) M[tid] = blk[(size_t)(t - 1) * 2 * BB + tid] - v;
+      else Cb[tid] = v;
+    }
+    __syncthreads();
+  }
+  // ---- top chain: t = 0 .. mid
+  if (on) M[tid] = blk[tid] - (mid == 0 ? Cb[tid] : 0.0);
+  __syncthreads();
+  for (int t = 0; t <= mid; t++) {
+    bt_invert_spd<BS>(M, rowk, colk, tid);
     double *cur = blk + (size_t)t * 2 * BB;
     if (on) cur[tid] = M[tid];
-    if (t + 1 < a.bt_nb) {
+    if (t < mid) {
       double *nxt = cur + 2 * BB;
-      if (on) Sub[tid] = nxt[BB + tid];
+      if (on) Sub[tid] = nxt[BB + tid];                                  // S_{t+1,t}
       __syncthreads();
       if (on) {
-        double e = 0.0;
+        double e = 0.0;                                                  // E_{t+1} = S_{t+1,t} D_t^-1
 #pragma unroll
         for (int k = 0; k < BS; k++) e += Sub[i * BS + k] * M[k * BS + j];
         Ev[tid] = e; nxt[BB + tid] = e;
@@ -707,9 +747,21 @@ __global__ __launch_bounds__(256) void qp_bt_factor_kernel(BigArgs a) {
         double v = nxt[tid];
 #pragma unroll
         for (int k = 0; k < BS; k++) v -= Ev[i * BS + k] * Sub[j * BS + k];
+        if (t + 1 == mid) v -= Cb[tid];
         M[tid] = v;
       }
       __syncthreads();
+    }
+  }
+  // ---- H = D_mid^-1 G_mid (G_mid sits in slot [mid+1][1]) -> slot [0][1]
+  if (nb - 1 > mid) {
+    if (on) Sub[tid] = blk[(size_t)(mid + 1) * 2 * BB + BB + tid];
+    __syncthreads();
+    if (on) {
+      double h = 0.0;
+#pragma unroll
+      for (int k = 0; k < BS; k++) h += M[i * BS + k] * Sub[k * BS + j];
+      blk[BB + tid] = h;
     }
   }
 }
@@ -881,6 +933,40 @@ __device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const 
   if (hasB) bt_dense_compute<NC>(RB, lane, chk, q);
 }
 
+// One chain of the twisted block solve, in place on `vec`: for s = 0 .. nsteps-1, t = t0 + s dt:
+//     vec_t -= B_{t + boff} vec_{t - dt}        (COL: B' instead of B)
+// B_u = second matrix of block slot u.  Lane i < BS owns entry i of every block; the next block's
+// row (column) is fetched while the current step waits for vec_{t - dt} (LDS, same wavefront).
+template <int BS, bool COL>
+__device__ __forceinline__ void bt_chain(double *vec, const double *s_blk, int i, int t0, int dt, int nsteps, int boff) {
+  constexpr int BB = BS * BS;
+  if (nsteps <= 0) return;
+  auto fetch = [&](int t, double (&e)[BS]) {
+    const double *B = s_blk + (size_t)(t + boff) * 2 * BB + BB;
+#pragma unroll
+    for (int k = 0; k < BS; k++) e[k] = COL ? B[k * BS + i] : B[i * BS + k];
+  };
+  double e0[BS], e1[BS];
+  fetch(t0, e0);
+  wave_lds_fence();
+  auto step = [&](int sidx, const double (&ec)[BS], double (&en)[BS]) {
+    const int t = t0 + sidx * dt;
+    double pv[BS];
+    const double own = vec[t * BS + i];
+#pragma unroll
+    for (int k = 0; k < BS; k++) pv[k] = vec[(t - dt) * BS + k];
+    if (sidx + 1 < nsteps) fetch(t + dt, en);
+    double a0 = own, a1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < BS; k += 2) { a0 -= ec[k] * pv[k]; a1 -= ec[k + 1] * pv[k + 1]; }
+    vec[t * BS + i] = a0 + a1;
+    wave_lds_fence();
+  };
+  int sidx = 0;
+  for (; sidx + 1 < nsteps; sidx += 2) { step(sidx, e0, e1); step(sidx + 1, e1, e0); }
+  if (sidx < nsteps) step(sidx, e0, e1);
+}
+
 // One generic chunk (kind 1: rows walk the CSR arrays; kind 2: at most one core entry per item).
 __device__ __forceinline__ void bt_generic_chunk(const BigArgs &a, const QpDev &d, const int (&dsc)[CH_STRIDE], int ch, int lane, bool chk,
                                                  const BtPtrs &bp, const double *As, const double *rho, const int *w, double *z, double *y,
@@ -960,7 +1046,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   const QpDev &d = a.d;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (d.active && !d.active[b]) return;
-  const int n = d.n, m = d.m, n_e = d.n_e, n_c = d.n_c, nb = a.bt_nb;
+  const int n = d.n, m = d.m, n_e = d.n_e, n_c = d.n_c, nb = a.bt_nb, mid = a.bt_mid;
   constexpr int BB = BS * BS;
   const int ncp = nb * BS;
   const bool use_part = a.use_part != 0;
@@ -1079,33 +1165,10 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
     BSTAMP(0)
     __syncthreads();
     BSTAMP(1)
-    // (3) block-tridiagonal solve.  Forward, in place: lane i < BS owns row i of every block; the
-    // row of E_{t+1} is fetched while step t waits for y_{t-1}.
-    if (wave == 0 && lane < BS) {
-      const int i = lane;
-      double e0[BS], e1[BS];
-#pragma unroll
-      for (int k = 0; k < BS; k++) e0[k] = nb > 1 ? s_blk[2 * BB + BB + i * BS + k] : 0.0;
-      auto fstep = [&](int t, const double (&ec)[BS], double (&en)[BS]) {
-        double yv[BS];
-        const double rt = s_r[t * BS + i];
-#pragma unroll
-        for (int k = 0; k < BS; k++) yv[k] = s_r[(t - 1) * BS + k];
-        if (t + 1 < nb) {
-          const double *En = s_blk + (size_t)(t + 1) * 2 * BB + BB + i * BS;
-#pragma unroll
-          for (int k = 0; k < BS; k++) en[k] = En[k];
-        }
-        double a0 = rt, a1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < BS; k += 2) { a0 -= ec[k] * yv[k]; a1 -= ec[k + 1] * yv[k + 1]; }
-        s_r[t * BS + i] = a0 + a1;
-        wave_lds_fence();
-      };
-      int t = 1;
-      for (; t + 1 < nb; t += 2) { fstep(t, e0, e1); fstep(t + 1, e1, e0); }
-      if (t < nb) fstep(t, e0, e1);
-    }
+    // (3) twisted block solve, in place.  Forward: wavefront 0 runs the top chain y_t = r_t - E_t y_{t-1}
+    // (t = 1 .. mid), wavefront 1 the bottom chain y_t = r_t - G_t y_{t+1} (t = nb-2 .. mid+1)
+    if (wave == 0 && lane < BS) bt_chain<BS, false>(s_r, s_blk, lane, 1, 1, mid, 0);
+    if (wave == 1 && lane < BS) bt_chain<BS, false>(s_r, s_blk, lane, nb - 2, -1, nb - 2 - mid, 1);
     BSTAMP(2)
     __syncthreads();
     BSTAMP(3)
@@ -1115,35 +1178,19 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
       double acc = 0.0;
 #pragma unroll
       for (int k = 0; k < BS; k++) acc += Dv[k] * s_r[t * BS + k];
+      if (t == mid && mid + 1 < nb) {            // the middle block also takes the bottom chain: - H y_{mid+1}
+        const double *Hv = s_blk + BB + i * BS;
+#pragma unroll
+        for (int k = 0; k < BS; k++) acc -= Hv[k] * s_r[(mid + 1) * BS + k];
+      }
       s_xc[c] = acc;
     }
     __syncthreads();
     BSTAMP(4)
-    if (wave == 0 && lane < BS) {                        // backward, in place on z
-      const int i = lane;
-      double e0[BS], e1[BS];                             // column i of E_{t+1}
-#pragma unroll
-      for (int k = 0; k < BS; k++) e0[k] = nb > 1 ? s_blk[(size_t)(nb - 1) * 2 * BB + BB + k * BS + i] : 0.0;
-      auto bstep = [&](int t, const double (&ec)[BS], double (&en)[BS]) {
-        double xv[BS];
-        const double zt = s_xc[t * BS + i];
-#pragma unroll
-        for (int k = 0; k < BS; k++) xv[k] = s_xc[(t + 1) * BS + k];
-        if (t > 0) {
-          const double *En = s_blk + (size_t)t * 2 * BB + BB + i;
-#pragma unroll
-          for (int k = 0; k < BS; k++) en[k] = En[k * BS];
-        }
-        double a0 = zt, a1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < BS; k += 2) { a0 -= ec[k] * xv[k]; a1 -= ec[k + 1] * xv[k + 1]; }
-        s_xc[t * BS + i] = a0 + a1;
-        wave_lds_fence();
-      };
-      int t = nb - 2;
-      for (; t >= 1; t -= 2) { bstep(t, e0, e1); bstep(t - 1, e1, e0); }
-      if (t >= 0) bstep(t, e0, e1);
-    }
+    // backward from the middle block outwards: x_t = z_t - E_{t+1}' x_{t+1} (t = mid-1 .. 0) and
+    // x_t = z_t - G_{t-1}' x_{t-1} (t = mid+1 .. nb-1)
+    if (wave == 0 && lane < BS) bt_chain<BS, true>(s_xc, s_blk, lane, mid - 1, -1, mid, 1);
+    if (wave == 1 && lane < BS) bt_chain<BS, true>(s_xc, s_blk, lane, mid + 1, 1, nb - 1 - mid, 0);
     BSTAMP(5)
     __syncthreads();
     BSTAMP(6)
@@ -1295,7 +1342,7 @@ int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, con
     ba.stamp = g_stamp; sco_debug_stamp_bt_ptr = g_stamp;
   }
 #endif
-  ba.bt_bs = 0; ba.bt_nb = 0; ba.bt_blk = nullptr; ba.bt_stride = 0; ba.nchunks = 0;
+  ba.bt_bs = 0; ba.bt_nb = 0; ba.bt_mid = 0; ba.bt_blk = nullptr; ba.bt_stride = 0; ba.nchunks = 0;
   ba.ch_desc = ba.it = ba.cent = nullptr; ba.npart = 0; ba.use_part = 0;
   ba.d = a.d; ba.Pp = Pp; ba.Pi = Pi;
   ba.row_elim = bd.row_elim; ba.row_epos = bd.row_epos; ba.er_ptr = bd.er_ptr; ba.er_row = bd.er_row;
@@ -1306,7 +1353,7 @@ int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, con
   ba.eps_prim_inf = a.eps_prim_inf; ba.eps_dual_inf = a.eps_dual_inf;
   ba.max_iter = a.max_iter; ba.check = a.check; ba.scaling = scaling;
   if (th) {
-    ba.bt_bs = th->bs; ba.bt_nb = th->nb; ba.bt_blk = td->blk; ba.bt_stride = th->blk_doubles;
+    ba.bt_bs = th->bs; ba.bt_nb = th->nb; ba.bt_mid = th->nb >= 4 ? th->nb / 2 : th->nb - 1; ba.bt_blk = td->blk; ba.bt_stride = th->blk_doubles;
     ba.ch_desc = td->ch_desc; ba.it = td->it; ba.cent = td->cent; ba.nchunks = th->nchunks;
     ba.npart = th->npart; ba.use_part = th->use_part ? 1 : 0;
     ba.ws = td->ws; ba.ws_stride = th->ws_doubles;
