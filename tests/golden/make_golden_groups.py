@@ -12,13 +12,7 @@ sys.path.insert(0, HERE)
 import make_golden as mg                      # noqa: E402
 from oracle import arm_family as af           # noqa: E402
 
-SMALL = dict(d=3, T=6, K=2, O=2)
-KNOBS = dict(initial_penalty_coeff=10.0, max_merit_coeff_increases=3)
-# (prefix, problem kwargs, problem index, Solver attribute overrides)
-CASES = [("h%d_" % i, dict(SMALL, groups="halves"), i, None) for i in (0, 10, 13)] + \
-        [("hk%d_" % i, dict(SMALL, groups="halves"), i, KNOBS) for i in (0, 10)] + \
-        [("s%d_" % i, dict(SMALL, groups="split", reach=True), i, None) for i in (22, 35, 38, 58)] + \
-        [("sk%d_" % i, dict(SMALL, groups="split", reach=True), i, KNOBS) for i in (0, 58)]
+from group_cases import CASES            # noqa: E402
 
 
 def main():

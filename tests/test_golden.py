@@ -173,13 +173,10 @@ def test_mirror_api_reproduces_reference_on_the_reach_variant(oracle_qp_backend)
 
 
 def _group_cases():
-    sys_path = os.path.join(GOLD)
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("make_golden_groups_cases", os.path.join(sys_path, "make_golden_groups.py"))
-    src = open(spec.origin).read()
-    ns = {}
-    exec(src[src.index("SMALL ="):src.index("def main")], ns)     # the CASES table only (no reference import)
-    return ns["CASES"]
+    import sys
+    sys.path.insert(0, GOLD)
+    from group_cases import CASES
+    return CASES
 
 
 @pytest.mark.parametrize("case", _group_cases(), ids=lambda c: c[0])
