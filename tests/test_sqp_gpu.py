@@ -271,3 +271,15 @@ def test_default_group_is_all(gpu):
     for b in range(3):
         ref = sr.penalty_sqp(sr.trajopt_flat(probs[b]), emulate_memo=True)
         assert res.nonconverged_groups[b] == ref.nonconverged_groups
+
+
+@pytest.mark.parametrize("structured", ["0", "1"])
+def test_reach_family_and_groups_through_the_global_memory_tier(gpu, monkeypatch, structured):
+    """The equality rows put one abs slack of every pair into the dense core and add rows that are neither
+    dense chunks nor single-entry rows: both forms of the global-memory tier must handle them."""
+    monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    monkeypatch.setenv("SCO_QP_NO_BT", "0" if structured == "1" else "1")
+    arrays, probs = af.make_batch(3, d=3, T=6, K=2, O=2, reach=True, groups="split")
+    _compare_groups(sb.solve_batch(arrays), probs, range(3))
+    arrays, probs = af.make_batch(2, d=4, T=5, K=5, O=4, reach=True)       # 20 rows per block: dense chunks
+    _compare(sb.solve_batch(arrays), probs, range(2))
