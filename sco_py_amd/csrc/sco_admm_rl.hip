@@ -34,7 +34,8 @@
 #define LGI (LT / LGJ)
 #define LCAP_M 1024
 #define LCAP_NC 160
-#define LCW 12          // entries of a core variable's column
+#define LCW 12          // entries of a core variable's column (default; 16 for the widest instantiation)
+#define LCW_MAX 16
 #define LRW 8           // core entries of a row
 
 // Paired sliced-ELL: slices of 64 items (one wavefront); entries 2h and 2h+1 of lane l
@@ -102,7 +103,8 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
       const int c = LT - 1 - t;
       if (c < pl.n_c) {
         const int j = pl.core_var[c];
-        if (pl.Ap[j + 1] - pl.Ap[j] > LCW) return false;
+        if (pl.Ap[j + 1] - pl.Ap[j] > LCW_MAX) return false;
+        if (pl.Ap[j + 1] - pl.Ap[j] > LCW) rh.CW = LCW_MAX;
         for (int p = pl.Ap[j]; p < pl.Ap[j + 1]; p++) { idx.push_back(pl.Ai[p]); src.push_back(p); }
       }
       ptr[t + 1] = (int)idx.size();
@@ -127,12 +129,13 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
   }
   rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rh.Ar0.total + rh.Ar1.total + 64 * 16);
   // ---- per-thread tables: packed gather offsets and roles
-  const int slots = LCW + 2 * LRW;
+  const int CWv = rh.CW;
+  const int slots = CWv + 2 * LRW;
   rh.off.assign((size_t)slots * LT, 0);
   rh.role.assign((size_t)16 * LT, -1);
   for (int t = 0; t < LT; t++) {
-    for (int k = 0; k < LCW; k++) rh.off[(size_t)k * LT + t] = (unsigned short)(8 * m);             // zero of t'
-    for (int k = 0; k < 2 * LRW; k++) rh.off[(size_t)(LCW + k) * LT + t] = (unsigned short)(8 * pl.n_c);   // zero of x_C
+    for (int k = 0; k < CWv; k++) rh.off[(size_t)k * LT + t] = (unsigned short)(8 * m);             // zero of t'
+    for (int k = 0; k < 2 * LRW; k++) rh.off[(size_t)(CWv + k) * LT + t] = (unsigned short)(8 * pl.n_c);   // zero of x_C
     // role table: 0 core idx, 1 core var, 2 elim idx, 3 elim var, 4/5 row of slot 0/1,
     //             6/7 CSC position of the row's eliminated coefficient, 8 col base, 9/10 row bases,
     //             11/12 position of P_jj for the core / eliminated variable
@@ -164,7 +167,7 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
       int k = 0;
       for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
         const int c2 = pl.core_of[pl.Rj[s]];
-        if (c2 >= 0) { rh.off[(size_t)(LCW + q * LRW + k) * LT + t] = (unsigned short)(8 * c2); k++; }
+        if (c2 >= 0) { rh.off[(size_t)(CWv + q * LRW + k) * LT + t] = (unsigned short)(8 * c2); k++; }
       }
     }
   }
@@ -182,6 +185,7 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
   rh.TR = std::max(1, (pl.n_c + LGI - 1) / LGI);
   rh.TC = 2 * rh.TR;
   if (rh.TR == 5 && pl.n_c <= LGJ * 9) rh.TC = 9;
+  if (rh.CW > LCW && rh.TR != 5) return false;        // the wide-column variant exists for the 5-row tiles only
   return rh.lds_bytes + 32 * 1024 <= 160 * 1024;   // + 30.2 KB of static LDS
 }
 
@@ -258,11 +262,13 @@ __device__ __forceinline__ double rl_dot(const double *V, unsigned int *o, const
 }
 
 // dispatch on the wave-uniform trip count so padded slots cost nothing
+template <int CW>
 __device__ __forceinline__ double rl_dot_col(int w, const double *V, unsigned int *o, const double *vec) {
   if (w <= 0) return 0.0;
   if (w <= 4) return rl_dot<4>(V, o, vec);
   if (w <= 8) return rl_dot<8>(V, o, vec);
-  return rl_dot<LCW>(V, o, vec);
+  if constexpr (CW > 12) { if (w <= 12) return rl_dot<12>(V, o, vec); }
+  return rl_dot<CW>(V, o, vec);
 }
 __device__ __forceinline__ double rl_dot_row(int w, const double *V, unsigned int *o, const double *vec) {
   if (w <= 0) return 0.0;
@@ -291,7 +297,7 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
-template <int TR, int TC>
+template <int TR, int TC, int CW>
 __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (a.active && !a.active[b]) return;
@@ -320,13 +326,13 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   auto pack = [&](int slot) -> unsigned int {
     return (unsigned int)a.off[(size_t)slot * LT + tid] | ((unsigned int)a.off[(size_t)(slot + 1) * LT + tid] << 16);
   };
-  unsigned int co[LCW / 2], ro[2][LRW / 2];
+  unsigned int co[CW / 2], ro[2][LRW / 2];
 #pragma unroll
-  for (int k = 0; k < LCW / 2; k++) co[k] = pack(2 * k);
+  for (int k = 0; k < CW / 2; k++) co[k] = pack(2 * k);
 #pragma unroll
   for (int q = 0; q < 2; q++)
 #pragma unroll
-    for (int k = 0; k < LRW / 2; k++) ro[q][k] = pack(LCW + q * LRW + 2 * k);
+    for (int k = 0; k < LRW / 2; k++) ro[q][k] = pack(CW + q * LRW + 2 * k);
   const double *vcol = s_val + a.role[(size_t)8 * LT + tid];
   const double *vr0 = s_val + a.role[(size_t)9 * LT + tid];
   const double *vr1 = s_val + a.role[(size_t)10 * LT + tid];
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     STAMP(6)
     // (1) core right-hand side
     {
-      const double dv = rl_dot_col(wcol, vcol, co, s_tv);
+      const double dv = rl_dot_col<CW>(wcol, vcol, co, s_tv);
       if (cown >= 0) s_rv[cown] = (sigma * xcv - qc) + dv;
     }
     STAMP(0)
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               v[2] = fmax(v[2], fabs(ei * ax));
             }
         }
-        const double aty_c = rl_dot_col(wcol, vcol, co, swy);     // whole wave: the trip count is wave-uniform
+        const double aty_c = rl_dot_col<CW>(wcol, vcol, co, swy);     // whole wave: the trip count is wave-uniform
         if (cown >= 0) {
           const double aty = aty_c;
           double px = 0.0;
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               __syncthreads();
               double nat[1] = {0.0};
               {
-                const double dv = rl_dot_col(wcol, vcol, co, swy);
+                const double dv = rl_dot_col<CW>(wcol, vcol, co, swy);
                 if (cown >= 0) nat[0] = fabs(dv / Dg[cvar]);
               }
               if (eown >= 0) nat[0] = fmax(nat[0], fabs((r_ae[0] * (r_w[0] * dyp[0]) + r_ae[1] * (r_w[1] * dyp[1])) / Dg[evar]));
@@ -659,7 +665,7 @@ int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd) {
   return SCO_OK;
 }
 
-template <int TR, int TC>
+template <int TR, int TC, int CW = LCW>
 static int rl_launch_one(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
   // hipFuncSetAttribute applies to the current device only
   static bool attr_done[64] = {};
@@ -667,11 +673,11 @@ static int rl_launch_one(const RlArgs &ra, int batch, size_t lds, hipStream_t st
   (void)hipGetDevice(&dev_);
   dev_ &= 63;
   if (!attr_done[dev_]) {
-    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC, CW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 108 * 1024));
     attr_done[dev_] = true;
   }
-  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC>), dim3(batch), dim3(LT), lds, st, ra);
+  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC, CW>), dim3(batch), dim3(LT), lds, st, ra);
   SCO_HIP(hipGetLastError());
   return SCO_OK;
 }
@@ -698,6 +704,12 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
     extern double *sco_debug_stamp_ptr; sco_debug_stamp_ptr = g_stamp;
   }
 #endif
+  if (rh.CW > LCW) {
+    if (rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW_MAX>(ra, d.batch, rh.lds_bytes, st);
+    if (rh.TR == 5 && rh.TC == 10) return rl_launch_one<5, 10, LCW_MAX>(ra, d.batch, rh.lds_bytes, st);
+    sco_set_error("rl_launch: unsupported tile");
+    return SCO_ERR_CAPACITY;
+  }
   switch (rh.TR * 100 + rh.TC) {
     case 102: return rl_launch_one<1, 2>(ra, d.batch, rh.lds_bytes, st);
     case 204: return rl_launch_one<2, 4>(ra, d.batch, rh.lds_bytes, st);
