@@ -241,3 +241,19 @@ def test_unconstrained_and_single_variable_qps(gpu):
     one = (np.array([[4.0]]), np.array([-2.0]), np.array([[1.0]]), np.array([1.0]), np.array([1.0]))
     _, x1, st1, _ = _check([one])
     assert st1[0] == 1 and abs(x1[0, 0] - 1.0) < 1e-6
+
+
+def test_structured_tier_is_run_to_run_deterministic(gpu, monkeypatch):
+    """Partial sums are reduced in a fixed order inside the wavefront and chunks write disjoint data,
+    so two runs give bit-identical answers."""
+    monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    rng = np.random.default_rng(77)
+    probs = [penalty_qp(rng, 4, 12, 70) for _ in range(3)]
+    n, m, Pp, Pi, Ap, Ai, Pval, q, Aval, l, u = _stack(probs)
+    outs = []
+    for _ in range(2):
+        qp = _lib.BatchedQP(3, n, m, Pp, Pi, Ap, Ai)
+        qp.load(Pval, q, Aval, l, u)
+        outs.append(qp.solve()); qp.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][3], outs[1][3])

@@ -283,3 +283,26 @@ def test_reach_family_and_groups_through_the_global_memory_tier(gpu, monkeypatch
     _compare_groups(sb.solve_batch(arrays), probs, range(3))
     arrays, probs = af.make_batch(2, d=4, T=5, K=5, O=4, reach=True)       # 20 rows per block: dense chunks
     _compare(sb.solve_batch(arrays), probs, range(2))
+
+
+def test_family_specific_calls_are_validated(gpu):
+    arrays, _ = af.make_batch(1, d=3, T=6, K=2, O=2)
+    with sb.TrajOptBatch(1, 3, 6, 2, 2) as tb:
+        tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                arrays["point_frac"], arrays["obstacles"])
+        with pytest.raises(_lib.ScoHipError) as e:       # a target only exists in the reach family
+            _lib.check(_lib.load().sco_sqp_load_target(tb._h, _lib.dptr(np.zeros((1, 2)))))
+        assert e.value.code == -1
+        with pytest.raises(ValueError):
+            tb.set_groups([["all"]] * 5)                  # one entry per constraint block (6 here)
+        with pytest.raises(ValueError):
+            tb.set_groups([["g%d" % k for k in range(40)]] * 6)     # at most 32 groups
+        tb.set_groups([["a"], ["a"], ["a", "b"], ["b"], ["b"], ["b"]])
+        tb.solve()
+        assert tb.fetch().nonconverged_groups[0] in ([], ["a"], ["b"], ["a", "b"])
+    with sb.TrajOptBatch(1, 3, 6, 2, 2, reach=True) as tb:
+        r = af.make_batch(1, d=3, T=6, K=2, O=2, reach=True)[0]
+        tb.load(r["x0"], r["start"], r["goal"], r["link_len"], r["point_link"], r["point_frac"], r["obstacles"],
+                target=r["target"])
+        with pytest.raises(ValueError):
+            tb.set_groups([["all"]] * 6)                  # the reach block is a seventh block
