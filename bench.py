@@ -205,6 +205,10 @@ def main():
         if os.path.exists(tpath) and B == 1024 and not args.intended and not big:
             with open(tpath) as fh:
                 traffic = json.load(fh)["hbm_bytes_per_launch"]
+        tpath_big = os.path.join(ROOT, "profiles", "r01_traffic_12x50.json")
+        if big and os.path.exists(tpath_big) and not args.intended:
+            with open(tpath_big) as fh:      # measured per problem-iteration at B = 64; scaled to this run's launches
+                traffic = json.load(fh)["hbm_bytes_per_problem_iteration"] * admm_iters_total / max(qp_launches, 1)
         out = {
             "metric": "SCO iters/sec (batch of N trajopt QPs)",
             "value": sco_iters / elapsed,
