@@ -1,11 +1,16 @@
 // sco_qp_big.hip -- QP layer tier for problems whose working set does not fit a
-// CU's LDS (BASELINE config 5: 12-DOF x 50 steps, n = 5600, m = 10 624, dense core
-// of order 600).  Same algorithm as the LDS tiers (OSQP's ADMM, the third-party call
-// behind /root/reference/sco_py/sco_osqp/osqp_utils.py:195-216, with the two-level
-// reduced solve of qp_plan.h and the row-local rewrite of sco_admm_rl.hip); every
-// array lives in HBM/L2, one workgroup of 1024 threads per problem.  This tier is
-// about coverage, not speed: it is latency/L2-bound (W alone is n_c^2 * 8 = 2.9 MB
-// per problem and is streamed every iteration).
+// CU's LDS (BASELINE config 5: 12-DOF x 50 steps, n = 5600, m = 10 624, core of order
+// 600).  Same algorithm as the LDS tiers (OSQP's ADMM, the third-party call behind
+// /root/reference/sco_py/sco_osqp/osqp_utils.py:195-216, with the two-level reduced
+// solve of qp_plan.h and the row-local rewrite of sco_admm_rl.hip); one workgroup per
+// problem, values and row state in HBM/L2.  Two forms:
+//   * structured (qp_bt_factor_kernel + qp_admm_bt_kernel, second half of this file):
+//     for a banded core -- twisted block LDL' of the block-tridiagonal Schur
+//     complement (factors resident in LDS), dense row chunks addressed without index
+//     arrays, A't reduced inside the wavefront.  This is what 12 x 50 runs on.
+//   * dense (qp_setup_big_kernel's Cholesky + qp_admm_big_kernel): explicit inverse W
+//     of the core streamed from L2 every iteration (n_c^2 * 8 = 2.9 MB at 12 x 50);
+//     the fall-back for cores that are not banded and the cross-check of the above.
 #include "sco_internal.h"
 
 #include <algorithm>
