@@ -84,6 +84,16 @@ def ee_jac(theta, link_len):
     return J
 
 
+def velocity_rows(d, T):
+    """V (2 d (T-1), d T): rows theta[t+1][j] - theta[t][j] (t-major), then their negatives."""
+    D = np.zeros((d * (T - 1), d * T))
+    for t in range(T - 1):
+        for j in range(d):
+            D[t * d + j, t * d + j] = -1.0
+            D[t * d + j, (t + 1) * d + j] = 1.0
+    return np.vstack([D, -D])
+
+
 def default_points(d, K):
     """K link points spread over the links: point k sits at the END of link
     (k * d) // K ... evenly, fraction 1.0 for the last point of a link."""
@@ -113,7 +123,7 @@ def block_groups(T, reach, scheme):
     return g
 
 
-def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None):
+def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None):
     """Seeded problem i of the batch.  reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
@@ -136,6 +146,10 @@ def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None):
         out["target"] = ee_pos(goal, link_len)
     if groups is not None:
         out["groups"] = block_groups(T, is_reach, groups)      # prob.add_cnt_expr(..., group_ids=...)
+    if vel_limit is not None:
+        # joint-velocity limits |theta[t+1][j] - theta[t][j]| <= vmax: LINEAR inequalities, i.e.
+        # LEqExpr(AffExpr) rows that go straight into every QP (prob.py:126-131, 317-346)
+        out["vmax"] = float(vel_limit)
     return out
 
 
@@ -146,6 +160,8 @@ def make_batch(B, first=0, **kw):
     extra = dict(reach=True, target=np.stack([p["target"] for p in probs])) if p0.get("reach") else {}
     if p0.get("groups") is not None:
         extra["groups"] = p0["groups"]
+    if p0.get("vmax") is not None:
+        extra["vmax"] = np.array([p["vmax"] for p in probs])
     return dict(
         d=p0["d"], T=p0["T"], K=p0["K"], O=p0["O"], B=B, **extra,
         x0=np.stack([p["x0"] for p in probs]),

@@ -197,10 +197,14 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
     u0 = np.concatenate([p.lin_hi, np.full(n_x, np.inf)])
     res = run_qp(Pp, qp, A0, l0, u0, None, {})
     out = _State()
-    if res.info.status_val not in (1, 2):
+    if res.info.status_val not in (1, 2):                    # solver.py:81-82: give up, variables untouched
+        record(STEP_PROJECT, 0.0, 0.0, 0.0, P_.initial_trust_region_size, P_.initial_penalty_coeff, res)
         out.x, out.success = st.x, False
-        out.trace, out.qps = np.array(st.trace), st.qps
+        out.trace, out.qps = np.array(st.trace, dtype=np.float64).reshape(-1, 8), st.qps
         out.sqp_iters, out.qp_solves, out.admm_iters = 0, st.qp_solves, st.admm_iters
+        out.max_violation = max([float(np.max(b.violation(st.x[b.idx]))) for b in p.blocks] + [0.0])
+        out.merit = 0.0
+        out.group_ids, out.nonconverged_groups = sorted(set(g for b in p.blocks for g in b.groups)), []
         return out
     st.x = res.x.copy()
     record(STEP_PROJECT, 0.0, 0.0, 0.0, P_.initial_trust_region_size, P_.initial_penalty_coeff, res)
@@ -376,6 +380,12 @@ def trajopt_flat(prob, analytic_jac=False):
         if not reach:
             lin[d + j, (T - 1) * d + j] = 1.0
     rhs = prob["start"].copy() if reach else np.concatenate([prob["start"], prob["goal"]])
+    lin_lo, lin_hi = rhs, rhs
+    if prob.get("vmax") is not None:               # linear inequality rows (prob.py:329-338: lb = -inf, ub = val - b)
+        V = af.velocity_rows(d, T)
+        lin = sp.vstack([lin.tocsr(), sp.csr_matrix(V)]).tolil()
+        lin_lo = np.concatenate([rhs, np.full(V.shape[0], -np.inf)])
+        lin_hi = np.concatenate([rhs, np.full(V.shape[0], prob["vmax"])])
     blocks = []
     R = prob["K"] * prob["O"]
     for t in range(T):
@@ -392,5 +402,5 @@ def trajopt_flat(prob, analytic_jac=False):
                             groups=prob["groups"][T] if prob.get("groups") is not None else None))
     # the object-API construction (tests/trajopt_build.py) binds every atom to two
     # Variables: the whole trajectory and its timestep block
-    return FlatProblem(prob["x0"], Q.tocsc(), np.zeros(n_x), 0.0, lin.tocsr(), rhs, rhs, blocks,
+    return FlatProblem(prob["x0"], Q.tocsc(), np.zeros(n_x), 0.0, lin.tocsr(), lin_lo, lin_hi, blocks,
                        prox_count=np.full(n_x, 2.0))

@@ -206,3 +206,38 @@ def test_mirror_api_reproduces_reference_with_constraint_groups(prefix, i, oracl
     assert ok == bool(g[prefix + "success"])
     assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 1e-9
     assert sorted(set(prob.nonconverged_groups)) == sorted(str(s) for s in g[prefix + "nonconverged"])
+
+
+def _vel_cases():
+    import sys
+    sys.path.insert(0, GOLD)
+    from vel_cases import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("case", _vel_cases(), ids=lambda c: c[0])
+def test_flat_oracle_reproduces_reference_with_linear_inequality_rows(case):
+    """Joint-velocity limits: LEqExpr(AffExpr) rows go straight into every QP (prob.py:126-131, 317-346),
+    including the projection QP, which the pins can make infeasible (Solver.solve then returns False,
+    solver.py:81-82)."""
+    prefix, kw, i = case
+    g = np.load(os.path.join(GOLD, "trajopt_vel.npz"))
+    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i, **kw)), record_qps=True)
+    _compare_sequence(ct.load_golden_qps(g, prefix), out.qps, prefix)
+    assert out.success == bool(g[prefix + "success"])
+    assert np.abs(out.x - g[prefix + "x"]).max() < 1e-9
+    assert abs(out.max_violation - float(g[prefix + "max_violation"])) < 1e-9
+
+
+def test_mirror_api_reproduces_reference_with_linear_inequality_rows(oracle_qp_backend):
+    g = np.load(os.path.join(GOLD, "trajopt_vel.npz"))
+    for prefix, kw, i in _vel_cases()[:2] + _vel_cases()[-1:]:
+        del oracle_qp_backend[:]
+        mods = ct.mirror_mods()
+        prob, traj, _, _ = tb.build_prob(mods, af.make_problem(i, **kw))
+        ok = mods.Solver().solve(prob, method="penalty_sqp")
+        gold = ct.load_golden_qps(g, prefix)
+        assert [a["iters"] for a in gold] == [r["iters"] for r in oracle_qp_backend]
+        assert [a["status"] for a in gold] == [r["status"] for r in oracle_qp_backend]
+        assert ok == bool(g[prefix + "success"])
+        assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 1e-9

@@ -41,6 +41,11 @@ def build_prob(mods, pr, analytic_jac=False):
     rhs = (pr["start"] if reach else np.concatenate([pr["start"], pr["goal"]])).reshape(-1, 1)
     prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(mods.AffExpr(pins, np.zeros((n_pin, 1))), rhs), traj))
 
+    if pr.get("vmax") is not None:
+        V = af.velocity_rows(d, T)
+        prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(mods.AffExpr(V, np.zeros((V.shape[0], 1))),
+                                                      np.full((V.shape[0], 1), pr["vmax"])), traj))
+
     R = pr["K"] * pr["O"]
     step_vars = []
     for t in range(T):
