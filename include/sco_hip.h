@@ -169,6 +169,11 @@ void sco_sqp_default_params(sco_sqp_params *p);
  * linear      theta[0] = start, theta[horizon-1] = goal (EqExpr(AffExpr), prob.py:126-128)
  * nonlinear   one LEqExpr block of n_points*n_obstacles rows per timestep (family above),
  *             Jacobians by central finite differences on device. */
+#define SCO_FAM_FLAG_VEL_LIMITS 16 /* OR-ed into `family`: joint-velocity limits
+                                  |theta[t+1][j] - theta[t][j]| <= vmax as LINEAR inequality rows
+                                  (LEqExpr on an AffExpr: they go straight into every QP, the projection
+                                  QP included, prob.py:126-131, 317-346); vmax via sco_sqp_load_vel_limit */
+
 typedef struct sco_trajopt_desc {
   int batch;
   int dof;
@@ -200,6 +205,8 @@ int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, const double
 /* SCO_FAM_ARM_REACH only, after sco_sqp_load: target[batch][2] end-effector position the last
  * timestep must reach (`goal` of sco_sqp_load is then unused and may repeat `start`). */
 int sco_sqp_load_target(sco_sqp *h, const double *target);
+/* SCO_FAM_FLAG_VEL_LIMITS only, after sco_sqp_load: vmax[batch] > 0, one limit per problem. */
+int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax);
 
 /* Constraint groups (prob.add_cnt_expr(bound_expr, group_ids), prob.py:112-142): n_groups <= 32 group ids
  * in SORTED order (the reference sorts them, prob.py:538, 559); block_mask[n_blocks], n_blocks = horizon

@@ -17,6 +17,7 @@ from . import _lib
 
 SCO_FAM_ARM_CIRCLES = 1
 SCO_FAM_ARM_REACH = 2
+SCO_FAM_FLAG_VEL_LIMITS = 16
 TRACE_W = 8
 
 
@@ -28,7 +29,8 @@ class TrajOptBatch(object):
              r_o - ||p_k(theta[t]) - c_o|| <= 0   for all t, link points k, obstacles o
 
     (``reach=True``: the goal pin is replaced by the non-linear equality
-    ee(theta[T-1]) = target, SCO_FAM_ARM_REACH)
+    ee(theta[T-1]) = target, SCO_FAM_ARM_REACH; ``vel_limits=True``: linear rows
+    |theta[t+1] - theta[t]| <= vmax in every QP, SCO_FAM_FLAG_VEL_LIMITS)
     solved per problem exactly like ``Solver().solve(prob, method="penalty_sqp")``.
     ``prox_count`` says how many Variables hold each atom in the equivalent object-API
     construction (it scales the projection QP of find_closest_feasible_point,
@@ -37,14 +39,16 @@ class TrajOptBatch(object):
     """
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
-                 prox_count=2, reach=False):
+                 prox_count=2, reach=False, vel_limits=False):
         self.B, self.d, self.T, self.K, self.O = int(batch), int(dof), int(horizon), int(n_points), int(n_obstacles)
         self.n_x = self.d * self.T
         self.device = int(device)
         self._h = C.c_void_p()
         self.reach = bool(reach)
+        self.vel_limits = bool(vel_limits)
         desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O,
-                                SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES,
+                                (SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES) |
+                                (SCO_FAM_FLAG_VEL_LIMITS if self.vel_limits else 0),
                                 1 if analytic_jac else 0, int(prox_count))
         _lib.check(_lib.load().sco_sqp_create(self.device, C.byref(desc), C.byref(self._h)))
 
@@ -65,7 +69,7 @@ class TrajOptBatch(object):
     def __exit__(self, *exc):
         self.close()
 
-    def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles, target=None):
+    def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles, target=None, vmax=None):
         """Upload per-problem data (host arrays, copied).  ``target`` (B, 2): end-effector
         position of the reach variant (``goal`` is then ignored by the device)."""
         B, d, K, O = self.B, self.d, self.K, self.O
@@ -87,6 +91,11 @@ class TrajOptBatch(object):
                 raise ValueError("the reach variant needs target (B, 2)")
             target = arr(target, (B, 2))
             _lib.check(_lib.load().sco_sqp_load_target(self._h, _lib.dptr(target)))
+        if self.vel_limits:
+            if vmax is None:
+                raise ValueError("velocity limits need vmax (B,)")
+            vmax = arr(np.broadcast_to(np.asarray(vmax, dtype=np.float64), (B,)), (B,))
+            _lib.check(_lib.load().sco_sqp_load_vel_limit(self._h, _lib.dptr(vmax)))
 
     def set_groups(self, block_groups):
         """Constraint groups (``prob.add_cnt_expr(bound_expr, group_ids)``): one list of group ids
@@ -146,9 +155,9 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
     generator) -> result namespace of :meth:`TrajOptBatch.fetch`."""
     a = batch_arrays
     with TrajOptBatch(a["B"], a["d"], a["T"], a["K"], a["O"], device=device, analytic_jac=analytic_jac,
-                      prox_count=prox_count, reach=bool(a.get("reach"))) as tb:
+                      prox_count=prox_count, reach=bool(a.get("reach")), vel_limits=a.get("vmax") is not None) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
-                target=a.get("target"))
+                target=a.get("target"), vmax=a.get("vmax"))
         if a.get("groups") is not None:
             tb.set_groups(a["groups"])
         tb.solve(params, qp_settings)

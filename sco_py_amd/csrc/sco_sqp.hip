@@ -51,6 +51,10 @@ struct SqpDev {
   // SCO_FAM_ARM_REACH: NE = 2 equality rows (end-effector x, y) on the last timestep, block index T;
   // NB = number of constraint blocks (T or T + 1), RM = widest block (history strides)
   int NE, NB, RM;
+  // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows
+  int m_pin, m_vel;
+  const double *a0c, *a1c;      // constant parts of the A values of the projection / penalty QP (shared)
+  double *vmax;                 // [B]
   // problem data
   double *x0, *start, *goal, *link_len, *obstacles, *target;   // [B][...]
   const int *point_link; const double *point_frac;    // [K]
@@ -84,7 +88,7 @@ struct sco_sqp {
   hipStream_t stream = nullptr;
   std::vector<void *> allocs;
   std::vector<hipEvent_t> events;
-  bool loaded = false, solved = false, target_loaded = false;
+  bool loaded = false, solved = false, target_loaded = false, vel_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   int rounds = 0;
 };
@@ -250,11 +254,12 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
     q0.q[(size_t)b * n_x + i] = (-2.0 * x0[i]) * c;
     s.x[(size_t)b * n_x + i] = x0[i];
   }
-  for (int t = tid; t < q0.nnzA; t += SCO_BLOCK) q0.Aval[(size_t)b * q0.nnzA + t] = 1.0;
+  for (int t = tid; t < q0.nnzA; t += SCO_BLOCK) q0.Aval[(size_t)b * q0.nnzA + t] = s.a0c[t];
   for (int i = tid; i < m0; i += SCO_BLOCK) {
     double lo, hi;
     if (i < d) lo = hi = s.start[(size_t)b * d + i];
-    else if (i < s.m_lin) lo = hi = s.goal[(size_t)b * d + (i - d)];
+    else if (i < s.m_pin) lo = hi = s.goal[(size_t)b * d + (i - d)];
+    else if (i < s.m_lin) { lo = -INFINITY; hi = s.vmax[b]; }      // prob.py:329-338: lb = -inf, ub = val - b
     else { lo = -INFINITY; hi = INFINITY; }
     q0.l[(size_t)b * m0 + i] = lo; q0.u[(size_t)b * m0 + i] = hi;
     q0.w[(size_t)b * m0 + i] = 1;
@@ -307,28 +312,16 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
     double *qv = q1.q + (size_t)b * n;
     for (int i = tid; i < n; i += SCO_BLOCK) qv[i] = 0.0;
     double *Av = q1.Aval + (size_t)b * q1.nnzA;
-    // x columns: [pin 1.0]? [R hinge entries (written by convexify)] [NE equality entries]? [bound 1.0]
-    const bool goal_pin = s.m_lin == 2 * d;
-    for (int col = tid; col < n_x; col += SCO_BLOCK) {
-      const int t = col / d;
-      int pz = q1.Ap[col];
-      if (t == 0 || (t == s.T - 1 && goal_pin)) Av[pz++] = 1.0;
-      for (int r = 0; r < s.R; r++) Av[pz++] = 0.0;
-      if (t == s.T - 1) for (int r = 0; r < s.NE; r++) Av[pz++] = 0.0;
-      Av[pz] = 1.0;
-    }
-    // slack columns: hinge t_i (-1 in its row); equality rows p_i (-1) then n_i (+1) (prob.py:303-312)
-    for (int sidx = tid; sidx < s.n_slack; sidx += SCO_BLOCK) {
-      const int pz = q1.Ap[n_x + sidx];
-      const int ke = sidx - s.T * s.R;
-      Av[pz] = (ke >= 0 && (ke & 1)) ? 1.0 : -1.0; Av[pz + 1] = 1.0;
-    }
+    // constant entries (pins, velocity rows, slack and bound entries; zeros where convexify writes the
+    // Jacobian), built once on the host (sco_sqp_create)
+    for (int t = tid; t < q1.nnzA; t += SCO_BLOCK) Av[t] = s.a1c[t];
     double *l = q1.l + (size_t)b * m, *u = q1.u + (size_t)b * m;
     int *w = q1.w + (size_t)b * m;
     for (int i = tid; i < m; i += SCO_BLOCK) {
       double lo, hi;
       if (i < d) lo = hi = s.start[(size_t)b * d + i];
-      else if (i < s.m_lin) lo = hi = s.goal[(size_t)b * d + (i - d)];
+      else if (i < s.m_pin) lo = hi = s.goal[(size_t)b * d + (i - d)];
+      else if (i < s.m_lin) { lo = -INFINITY; hi = s.vmax[b]; }
       else if (i < s.m_lin + s.T * s.R) { lo = -INFINITY; hi = 0.0; }
       else if (i < s.m_lin + s.m_nl) { lo = 0.0; hi = 0.0; }              // equality rows: set by convexify
       else if (i < s.m_lin + s.m_nl + n_x) { lo = -INFINITY; hi = INFINITY; }
@@ -697,7 +690,8 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
 extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
   if (!desc || !out) { sco_set_error("sco_sqp_create: null pointer"); return SCO_ERR_ARG; }
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
-      desc->horizon > 256 || (desc->family != SCO_FAM_ARM_CIRCLES && desc->family != SCO_FAM_ARM_REACH)) {
+      desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS)) ||
+      ((desc->family & 15) != SCO_FAM_ARM_CIRCLES && (desc->family & 15) != SCO_FAM_ARM_REACH)) {
     sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
   }
   int ndev = 0;
@@ -719,11 +713,25 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
 static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc) {
   SCO_HIP(hipStreamCreate(&h->stream));
   const int B = desc->batch, d = desc->dof, T = desc->horizon, K = desc->n_points, O = desc->n_obstacles;
-  const bool reach = desc->family == SCO_FAM_ARM_REACH;
+  const bool reach = (desc->family & 15) == SCO_FAM_ARM_REACH, vel = (desc->family & SCO_FAM_FLAG_VEL_LIMITS) != 0;
   const int NE = reach ? 2 : 0;                  // equality rows (end-effector x, y) on the last timestep
-  const int R = K * O, n_x = d * T, n_slack = T * R + 2 * NE, n = n_x + n_slack, m_lin = reach ? d : 2 * d;
+  const int m_pin = reach ? d : 2 * d, dT1 = d * (T - 1), m_vel = vel ? 2 * dT1 : 0;
+  const int R = K * O, n_x = d * T, n_slack = T * R + 2 * NE, n = n_x + n_slack, m_lin = m_pin + m_vel;
   const int m_nl = T * R + NE, m = m_lin + m_nl + n;
-  // ---- projection QP pattern: P = diag, A = [pins ; I]
+  // linear rows of column (t, j), ascending: pin, velocity rows "theta[t] - theta[t-1] <= vmax" (+1),
+  // "theta[t+1] - theta[t] <= vmax" (-1), then the two negated rows
+  auto linear_entries = [&](int t, int j, std::vector<int> &Ai, std::vector<double> &Av) {
+    if (t == 0) { Ai.push_back(j); Av.push_back(1.0); }
+    if (t == T - 1 && !reach) { Ai.push_back(d + j); Av.push_back(1.0); }
+    if (vel) {
+      if (t >= 1) { Ai.push_back(m_pin + (t - 1) * d + j); Av.push_back(1.0); }
+      if (t <= T - 2) { Ai.push_back(m_pin + t * d + j); Av.push_back(-1.0); }
+      if (t >= 1) { Ai.push_back(m_pin + dT1 + (t - 1) * d + j); Av.push_back(-1.0); }
+      if (t <= T - 2) { Ai.push_back(m_pin + dT1 + t * d + j); Av.push_back(1.0); }
+    }
+  };
+  std::vector<double> a0c, a1c;
+  // ---- projection QP pattern: P = diag, A = [linear rows ; I]
   {
     std::vector<int> Pp(n_x + 1), Pi(n_x), Ap(n_x + 1), Ai;
     for (int i = 0; i < n_x; i++) { Pp[i] = i; Pi[i] = i; }
@@ -731,9 +739,8 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
     for (int col = 0; col < n_x; col++) {
       Ap[col] = (int)Ai.size();
       const int t = col / d, j = col % d;
-      if (t == 0) Ai.push_back(j);
-      if (t == T - 1 && !reach) Ai.push_back(d + j);
-      Ai.push_back(m_lin + col);
+      linear_entries(t, j, Ai, a0c);
+      Ai.push_back(m_lin + col); a0c.push_back(1.0);
     }
     Ap[n_x] = (int)Ai.size();
     int rc = sco_qp_create_on_stream(device, B, n_x, m_lin + n_x, Pp.data(), Pi.data(), Ap.data(), Ai.data(), h->stream, &h->qp0);
@@ -755,20 +762,20 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
       Ap[col] = (int)Ai.size();
       if (col < n_x) {
         const int t = col / d, j = col % d;
-        if (t == 0) Ai.push_back(j);
-        if (t == T - 1 && !reach) Ai.push_back(d + j);
+        linear_entries(t, j, Ai, a1c);
         jpos[col] = (int)Ai.size();
-        for (int r = 0; r < R; r++) Ai.push_back(m_lin + t * R + r);
+        for (int r = 0; r < R; r++) { Ai.push_back(m_lin + t * R + r); a1c.push_back(0.0); }     // Jacobian slots
         if (t == T - 1 && reach) {
           epos[j] = (int)Ai.size();
-          for (int r = 0; r < NE; r++) Ai.push_back(m_lin + T * R + r);
+          for (int r = 0; r < NE; r++) { Ai.push_back(m_lin + T * R + r); a1c.push_back(0.0); }
         }
-        Ai.push_back(m_lin + m_nl + col);
+        Ai.push_back(m_lin + m_nl + col); a1c.push_back(1.0);
       } else {
-        // hinge slack i sits in hinge row i; equality row r has p_r (slack T R + 2 r) and n_r (+ 1)
-        const int sidx = col - n_x;
-        Ai.push_back(m_lin + (sidx < T * R ? sidx : T * R + (sidx - T * R) / 2));
-        Ai.push_back(m_lin + m_nl + col);
+        // hinge slack i sits in hinge row i (-1); equality row r has p_r (slack T R + 2 r, -1) and n_r (+1)
+        // (prob.py:265-275, 303-312); then the slack's bound row
+        const int sidx = col - n_x, ke = sidx - T * R;
+        Ai.push_back(m_lin + (ke < 0 ? sidx : T * R + ke / 2)); a1c.push_back((ke >= 0 && (ke & 1)) ? 1.0 : -1.0);
+        Ai.push_back(m_lin + m_nl + col); a1c.push_back(1.0);
       }
     }
     Ap[n] = (int)Ai.size();
@@ -779,11 +786,11 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   s.batch = B; s.d = d; s.T = T; s.K = K; s.O = O; s.R = R; s.n_x = n_x; s.n_slack = n_slack; s.n = n;
   s.m_lin = m_lin; s.m_nl = m_nl; s.m = m; s.prox_count = desc->prox_count > 0 ? desc->prox_count : 1;
   s.analytic_jac = desc->analytic_jac; s.trace_cap = 64;
-  s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE);
+  s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE); s.m_pin = m_pin; s.m_vel = m_vel;
   int rc = 0;
 #define AL(f, cnt) if ((rc = sq_alloc(h, (cnt), &s.f))) return rc;
   AL(x0, (size_t)B * n_x) AL(start, (size_t)B * d) AL(goal, (size_t)B * d) AL(link_len, (size_t)B * d)
-  AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2)
+  AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2) AL(vmax, (size_t)B)
   AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
   AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
   AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, 1)
@@ -796,6 +803,10 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   { double *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_frac = p; }
   { int *p; if ((rc = sq_alloc(h, (size_t)n_x, &p))) return rc; s.jpos = p;
     SCO_HIP(hipMemcpy(p, jpos.data(), n_x * sizeof(int), hipMemcpyHostToDevice)); }
+  { double *p; if ((rc = sq_alloc(h, a0c.size(), &p))) return rc; s.a0c = p;
+    SCO_HIP(hipMemcpy(p, a0c.data(), a0c.size() * sizeof(double), hipMemcpyHostToDevice)); }
+  { double *p; if ((rc = sq_alloc(h, a1c.size(), &p))) return rc; s.a1c = p;
+    SCO_HIP(hipMemcpy(p, a1c.data(), a1c.size() * sizeof(double), hipMemcpyHostToDevice)); }
   { unsigned int *p; if ((rc = sq_alloc(h, (size_t)s.NB, &p))) return rc; s.gmask = p; }
   { unsigned int *p; if ((rc = sq_alloc(h, (size_t)32, &p))) return rc; s.goverlap = p; }
   if ((rc = sq_alloc(h, (size_t)B * 32, &s.mvec))) return rc;
@@ -845,12 +856,25 @@ extern "C" int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, c
 
 extern "C" int sco_sqp_load_target(sco_sqp *h, const double *target) {
   if (!h || !target) { sco_set_error("sco_sqp_load_target: null pointer"); return SCO_ERR_ARG; }
-  if (h->desc.family != SCO_FAM_ARM_REACH) { sco_set_error("sco_sqp_load_target: family has no target"); return SCO_ERR_ARG; }
+  if ((h->desc.family & 15) != SCO_FAM_ARM_REACH) { sco_set_error("sco_sqp_load_target: family has no target"); return SCO_ERR_ARG; }
   if (!h->loaded) { sco_set_error("sco_sqp_load_target: call sco_sqp_load first"); return SCO_ERR_STATE; }
   SCO_HIP(hipSetDevice(h->device));
   SCO_HIP(hipMemcpyAsync(h->d.target, target, (size_t)h->d.batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   SCO_HIP(hipStreamSynchronize(h->stream));
   h->target_loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax) {
+  if (!h || !vmax) { sco_set_error("sco_sqp_load_vel_limit: null pointer"); return SCO_ERR_ARG; }
+  if (!(h->desc.family & SCO_FAM_FLAG_VEL_LIMITS)) { sco_set_error("sco_sqp_load_vel_limit: family has no velocity limits"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_load_vel_limit: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  for (int b = 0; b < h->d.batch; b++)
+    if (!(vmax[b] > 0.0)) { sco_set_error("sco_sqp_load_vel_limit: vmax must be positive"); return SCO_ERR_ARG; }
+  SCO_HIP(hipSetDevice(h->device));
+  SCO_HIP(hipMemcpyAsync(h->d.vmax, vmax, (size_t)h->d.batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipStreamSynchronize(h->stream));
+  h->vel_loaded = true; h->solved = false;
   return SCO_OK;
 }
 
@@ -891,8 +915,11 @@ static hipEvent_t next_event(sco_sqp *h, size_t &cursor) {
 extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco_qp_settings *qs) {
   if (!h || !params || !qs) { sco_set_error("sco_sqp_solve: null pointer"); return SCO_ERR_ARG; }
   if (!h->loaded) { sco_set_error("sco_sqp_solve: call sco_sqp_load first"); return SCO_ERR_STATE; }
-  if (h->desc.family == SCO_FAM_ARM_REACH && !h->target_loaded) {
+  if ((h->desc.family & 15) == SCO_FAM_ARM_REACH && !h->target_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_target first"); return SCO_ERR_STATE;
+  }
+  if ((h->desc.family & SCO_FAM_FLAG_VEL_LIMITS) && !h->vel_loaded) {
+    sco_set_error("sco_sqp_solve: call sco_sqp_load_vel_limit first"); return SCO_ERR_STATE;
   }
   SCO_HIP(hipSetDevice(h->device));
   SqpDev &s = h->d;

@@ -306,3 +306,46 @@ def test_family_specific_calls_are_validated(gpu):
                 target=r["target"])
         with pytest.raises(ValueError):
             tb.set_groups([["all"]] * 6)                  # the reach block is a seventh block
+
+
+def test_velocity_limits_match_oracle(gpu):
+    """SCO_FAM_FLAG_VEL_LIMITS: linear inequality rows |theta[t+1] - theta[t]| <= vmax in every QP,
+    with and without the reach equality."""
+    for kw in (dict(vel_limit=0.6), dict(vel_limit=0.6, reach=True), dict(vel_limit=0.3, groups="split", reach=True)):
+        arrays, probs = af.make_batch(6, d=3, T=6, K=2, O=2, **kw)
+        res = sb.solve_batch(arrays)
+        _compare(res, probs, range(6))
+        x = res.x.reshape(6, 6, 3)
+        ok = res.qp_solves > 1                      # problems whose projection QP was feasible
+        assert np.all(np.abs(np.diff(x[ok], axis=1)) <= kw["vel_limit"] + 1e-4)
+
+
+def test_velocity_limits_match_reference_golden_runs_incl_infeasible_projection(gpu):
+    import sys
+    sys.path.insert(0, GOLD)
+    from vel_cases import CASES
+    g = np.load(os.path.join(GOLD, "trajopt_vel.npz"))
+    for prefix, kw, i in CASES:
+        arrays, _ = af.make_batch(1, first=i, **kw)
+        res = sb.solve_batch(arrays)
+        assert np.abs(res.x[0] - g[prefix + "x"]).max() < TOL, prefix
+        assert bool(res.success[0]) == bool(g[prefix + "success"]), prefix
+        nq = int(g[prefix + "n_qp"])
+        assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix
+        assert [int(v) for v in res.trace[0][:, 7]] == [int(g["%sqp%d_iters" % (prefix, k)]) for k in range(nq)], prefix
+    # x0_: pins and limits contradict each other -> the projection QP is primal infeasible (-3),
+    # Solver.solve gives up with the variables untouched (solver.py:81-82)
+    arrays, _ = af.make_batch(1, d=3, T=6, K=2, O=2, vel_limit=0.05)
+    res = sb.solve_batch(arrays)
+    assert not res.success[0] and res.qp_solves[0] == 1 and res.sqp_iters[0] == 0
+    assert np.array_equal(res.x[0], arrays["x0"][0])
+
+
+def test_velocity_limits_7x20_batch(gpu):
+    arrays, probs = af.make_batch(4, vel_limit=0.3)
+    res = sb.solve_batch(arrays)
+    _compare(res, probs, range(2))
+    with sb.TrajOptBatch(1, 3, 6, 2, 2, vel_limits=True) as tb:
+        a = af.make_batch(1, d=3, T=6, K=2, O=2, vel_limit=0.5)[0]
+        with pytest.raises(ValueError):
+            tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"])
