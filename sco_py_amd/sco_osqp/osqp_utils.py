@@ -11,6 +11,11 @@ sparse triplets directly and hands them to the MI355X solver through the C ABI
 from types import SimpleNamespace
 from typing import List
 
+import atexit
+import collections
+import os
+import threading
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -199,6 +204,39 @@ def assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs):
     return P, q, A, l, u, index
 
 
+# Device handles are kept per sparsity pattern: the SQP loop sends the same pattern again for every
+# trust-region retry and every SQP iteration (the re-appended rows are folded into weights), and
+# creating a handle (symbolic analysis + device allocations) costs more than a well-conditioned QP.
+_HANDLE_CACHE = collections.OrderedDict()
+_HANDLE_CACHE_MAX = 8
+_TIER_SWITCHES = ("SCO_QP_NO_ELIM", "SCO_QP_NO_RL", "SCO_QP_NO_REG", "SCO_QP_NO_FAST", "SCO_QP_FORCE_BIG", "SCO_QP_NO_BT")
+_HANDLE_LOCK = threading.Lock()
+
+
+def clear_handle_cache():
+    """Free every cached device handle (also runs at interpreter exit)."""
+    with _HANDLE_LOCK:
+        while _HANDLE_CACHE:
+            _, qp = _HANDLE_CACHE.popitem()
+            qp.close()
+
+
+atexit.register(clear_handle_cache)
+
+
+def _cached_handle(B, n, m, P0, A0):
+    key = (B, n, m, P0.indptr.tobytes(), P0.indices.tobytes(), A0.indptr.tobytes(), A0.indices.tobytes(),
+           tuple(os.environ.get(k) for k in _TIER_SWITCHES))     # the tier is chosen when a handle is created
+    qp = _HANDLE_CACHE.pop(key, None)
+    if qp is None:
+        qp = _lib.BatchedQP(B, n, m, P0.indptr, P0.indices, A0.indptr, A0.indices)
+    _HANDLE_CACHE[key] = qp                      # most recently used last
+    while len(_HANDLE_CACHE) > _HANDLE_CACHE_MAX:
+        _, old = _HANDLE_CACHE.popitem(last=False)
+        old.close()
+    return qp
+
+
 def _solve_qp_batch(requests):
     """Solve a list of QPs that share ONE sparsity pattern and one settings tuple in a
     single device launch.  Each request is a dict with P, q, A, l, u, w (row weights or
@@ -209,20 +247,22 @@ def _solve_qp_batch(requests):
     n, m = A0.shape[1], A0.shape[0]
     eps_abs, eps_rel, max_iter, rho, sigma = r0["settings"]
     B = len(requests)
-    qp = _lib.BatchedQP(B, n, m, P0.indptr, P0.indices, A0.indptr, A0.indices)
-    try:
-        Pv = np.stack([r["P"].data for r in requests]) if P0.nnz else np.zeros((B, 0))
-        Av = np.stack([r["A"].data for r in requests]) if A0.nnz else np.zeros((B, 0))
-        w = None
-        if any(r["w"] is not None for r in requests):
-            w = np.stack([r["w"] if r["w"] is not None else np.ones(m, dtype=np.int32) for r in requests])
-        qp.load(Pv, np.stack([r["q"] for r in requests]), Av,
-                np.stack([r["l"] for r in requests]), np.stack([r["u"] for r in requests]), w)
-        st = _lib.default_qp_settings(rho=rho, sigma=sigma, eps_abs=eps_abs, eps_rel=eps_rel,
-                                      max_iter=int(max_iter))
-        x, _y, status, iters, _res = qp.solve(st)
-    finally:
-        qp.close()
+    Pv = np.stack([r["P"].data for r in requests]) if P0.nnz else np.zeros((B, 0))
+    Av = np.stack([r["A"].data for r in requests]) if A0.nnz else np.zeros((B, 0))
+    w = None
+    if any(r["w"] is not None for r in requests):
+        w = np.stack([r["w"] if r["w"] is not None else np.ones(m, dtype=np.int32) for r in requests])
+    st = _lib.default_qp_settings(rho=rho, sigma=sigma, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=int(max_iter))
+    with _HANDLE_LOCK:
+        qp = _cached_handle(B, n, m, P0, A0)
+        try:
+            qp.load(Pv, np.stack([r["q"] for r in requests]), Av,
+                    np.stack([r["l"] for r in requests]), np.stack([r["u"] for r in requests]), w)
+            x, _y, status, iters, _res = qp.solve(st)
+        except Exception:
+            _HANDLE_CACHE.popitem()              # do not keep a handle that failed
+            qp.close()
+            raise
     return [(x[b], int(status[b]), int(iters[b])) for b in range(B)]
 
 

@@ -365,3 +365,29 @@ def test_repeated_penalty_rows_are_folded_into_weights(backend):
         uniq, counts = osqp_utils.fold_repeated_constraints(prob._osqp_lin_cnt_exprs)
         assert len(uniq) == 1 and counts.tolist() == [k]           # ... the device sees one row of weight k
         assert prob.optimize()
+
+
+@pytest.mark.gpu
+def test_device_handles_are_reused_per_sparsity_pattern(gpu):
+    """The seam keeps one device handle per sparsity pattern (the SQP loop sends the same pattern for
+    every trust-region retry); least recently used handles are closed."""
+    from sco_py_amd.sco_osqp import osqp_utils as ou
+    ou.clear_handle_cache()
+
+    def solve_scalar(ub):
+        v = ou.OSQPVar("x", ub=ub)
+        out, _ = ou.optimize([v], [], [ou.OSQPQuadraticObj(np.array([v]), np.array([v]), np.array([2.0]))],
+                             [ou.OSQPLinearObj(v, -4.0)], [])
+        return out.x[0]
+
+    assert abs(solve_scalar(np.inf) - 2.0) < 1e-5
+    assert abs(solve_scalar(1.5) - 1.5) < 1e-5         # same pattern, other bounds: the handle is reused
+    assert len(ou._HANDLE_CACHE) == 1
+    first = next(iter(ou._HANDLE_CACHE.values()))
+    for k in range(2, 2 + ou._HANDLE_CACHE_MAX):        # other patterns (k variables) push it out
+        vs = [ou.OSQPVar("x%02d" % i) for i in range(k)]
+        ou.optimize(vs, [], [ou.OSQPQuadraticObj(np.array(vs), np.array(vs), np.full(k, 2.0))],
+                    [ou.OSQPLinearObj(v, -4.0) for v in vs], [])
+    assert len(ou._HANDLE_CACHE) == ou._HANDLE_CACHE_MAX and first not in ou._HANDLE_CACHE.values()
+    ou.clear_handle_cache()
+    assert len(ou._HANDLE_CACHE) == 0
