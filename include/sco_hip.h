@@ -71,7 +71,11 @@ typedef struct sco_qp_settings {
   int max_iter;             /* osqp_utils.py:10  100000                  */
   int check_termination;    /* OSQP default 25                           */
   int scaling;              /* OSQP default 10 Ruiz passes               */
-  int reserved;
+  int warm_start;           /* 0 (default, what the reference does: a new OSQP object per QP, cold start,
+                               osqp_utils.py:195) | 1: start ADMM from the handle's previous solution
+                               (x, y; z = A x), as OSQP's own warm start does.  NOT parity mode: iterates and
+                               iteration counts change, the solution agrees to the QP tolerances.  Honoured by
+                               the row-local tier (the one 7-DOF x 20 runs on); other tiers start cold.  */
 } sco_qp_settings;
 
 void sco_qp_default_settings(sco_qp_settings *s);
@@ -149,7 +153,8 @@ typedef struct sco_sqp_params {
                                rounded to 6 decimals (expr.py:13, 31-41, 323-332, 362-371): a
                                point within rounding of an earlier one reuses that point's
                                f values / affine model.  1 = reproduce (default)            */
-  int reserved;
+  int warm_start_qps;       /* 0 (default, reference behaviour) | 1: every penalty QP of a problem starts from
+                               the solution of its previous one (sco_qp_settings.warm_start); beyond parity   */
 } sco_sqp_params;
 
 void sco_sqp_default_params(sco_sqp_params *p);

@@ -28,7 +28,7 @@ class QpSettings(C.Structure):
         ("eps_abs", C.c_double), ("eps_rel", C.c_double),
         ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
         ("max_iter", C.c_int), ("check_termination", C.c_int), ("scaling", C.c_int),
-        ("reserved", C.c_int),
+        ("warm_start", C.c_int),
     ]
 
 
@@ -42,7 +42,7 @@ class SqpParams(C.Structure):
         ("initial_penalty_coeff", C.c_double),
         ("max_merit_coeff_increases", C.c_int), ("compound_penalty", C.c_int),
         ("duplicate_rows", C.c_int), ("max_sqp_iters", C.c_int),
-        ("memoize_rounded", C.c_int), ("reserved", C.c_int),
+        ("memoize_rounded", C.c_int), ("warm_start_qps", C.c_int),
     ]
 
 

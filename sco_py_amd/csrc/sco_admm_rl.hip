@@ -202,6 +202,7 @@ struct RlArgs {
   const int *w, *active;
   double *x, *y, *resid;
   int *status, *iters;
+  int warm;          // start from the previous (unscaled) solution held in x / y instead of zero
   double *stamp;     // diagnostic build only (SCO_STAMP), else unused
 };
 
@@ -379,12 +380,36 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   for (int i = tid; i < LCAP_M; i += LT) s_tv[i] = 0.0;
   for (int i = tid; i < LCAP_NC; i += LT) { s_rv[i] = 0.0; s_xc[i] = 0.0; }
   __syncthreads();
-  // t' of the start point x = z = y = 0:  t = 0, g_e = -q_e / K_ee, t'_i = -rw_i a_ie g_e
-#pragma unroll
-  for (int q = 0; q < 2; q++)
-    if (r_i[q] >= 0) s_tv[r_i[q]] = -(r_w[q] * r_rho[q]) * r_ae[q] * ge;
   const double cscale = a.cscale[b];
   const double alpha = a.alpha, sigma = a.sigma;
+  if (a.warm) {
+    // OSQP-style warm start from the previous solution of this handle (x, y unscaled in a.x / a.y):
+    //   x_s = x / D,  y_s = c y / (E w),  z = A_s x_s;  then t, g_e, t' as after any iteration
+    const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
+    if (cown >= 0) { xcv = a.x[(size_t)b * n + cvar] / Dg[cvar]; sxc[cown] = xcv; }
+    if (eown >= 0) xe = a.x[(size_t)b * n + evar] / Dg[evar];
+    if (tid == 0) sxc[n_c] = 0.0;
+    __syncthreads();
+    double axc[2];
+    axc[0] = rl_dot_row(wr0, vr0, ro[0], sxc); axc[1] = rl_dot_row(wr1, vr1, ro[1], sxc);
+    double tq[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (r_i[q] >= 0) {
+        r_z[q] = axc[q] + r_ae[q] * xe;
+        r_y[q] = a.y[(size_t)b * m + r_i[q]] * cscale / (Eg[r_i[q]] * r_w[q]);
+        tq[q] = r_w[q] * (r_rho[q] * r_z[q] - r_y[q]);
+      }
+    if (eown >= 0) ge = ((sigma * xe - qe) + r_ae[0] * tq[0] + r_ae[1] * tq[1]) * kinv;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (r_i[q] >= 0) s_tv[r_i[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
+  } else {
+    // t' of the start point x = z = y = 0:  t = 0, g_e = -q_e / K_ee, t'_i = -rw_i a_ie g_e
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (r_i[q] >= 0) s_tv[r_i[q]] = -(r_w[q] * r_rho[q]) * r_ae[q] * ge;
+  }
   __syncthreads();
 
   int status = 0, iter = 0;
@@ -695,6 +720,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.As = d.As; ra.W = d.W; ra.qs = d.qs; ra.kee_inv = d.kee_inv; ra.ls = d.ls; ra.us = d.us; ra.rho = d.rho;
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
+  ra.warm = a.warm;
   ra.stamp = nullptr;
 #ifdef SCO_STAMP
   {

@@ -64,6 +64,7 @@ struct AdmmArgs {
   QpDev d;
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   int max_iter, check;
+  int warm;     // start from the previous solution in d.x / d.y (row-local tier only)
 };
 
 bool fast_plan_build(const QpPlan &pl, FastHost &fh);
@@ -147,7 +148,7 @@ struct sco_qp {
   bool own_stream = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   std::vector<void *> allocs;
-  bool loaded = false;
+  bool loaded = false, solved_once = false;
   size_t lds_setup = 0, lds_admm = 0;
   double last_ms[2] = {0, 0};
 };

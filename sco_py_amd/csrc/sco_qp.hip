@@ -50,7 +50,7 @@ extern "C" void sco_qp_default_settings(sco_qp_settings *s) {
   s->rho = 0.1; s->sigma = 5e-10; s->alpha = 1.6;
   s->eps_abs = 1e-6; s->eps_rel = 1e-9;
   s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
-  s->max_iter = 100000; s->check_termination = 25; s->scaling = 10; s->reserved = 0;
+  s->max_iter = 100000; s->check_termination = 25; s->scaling = 10; s->warm_start = 0;
 }
 
 // --------------------------------------------------------------------------
@@ -723,7 +723,8 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
   QpDev d = qp->d; d.active = active_dev;
   SetupArgs sa{d, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling};
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
-              st->max_iter, st->check_termination};
+              st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0};
+  qp->solved_once = true;
   SCO_HIP(hipEventRecord(qp->ev[0], qp->stream));
   if (qp->use_big) {
     int r_ = big_launch(aa, st->scaling, qp->Pp_dev, qp->Pi_dev, qp->big, qp->bigd, qp->use_bt ? &qp->bt : nullptr,

@@ -671,7 +671,7 @@ extern "C" void sco_sqp_default_params(sco_sqp_params *p) {
   p->trust_shrink_ratio = 0.1; p->trust_expand_ratio = 1.5; p->cnt_tolerance = 1e-4;
   p->merit_coeff_increase_ratio = 10.0; p->initial_trust_region_size = 1.0; p->initial_penalty_coeff = 1e3;
   p->max_merit_coeff_increases = 1; p->compound_penalty = 1; p->duplicate_rows = 1; p->max_sqp_iters = 0;
-  p->memoize_rounded = 1; p->reserved = 0;
+  p->memoize_rounded = 1; p->warm_start_qps = 0;
 }
 
 template <typename T>
@@ -951,6 +951,15 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   SCO_HIP(hipStreamSynchronize(h->stream));
   h->rounds = 1;
   // ---- rounds: one QP solve per active problem
+  sco_qp_settings qsl = *qs;
+  if (params->warm_start_qps) {
+    // beyond parity: every penalty QP starts from the previous one's solution; the first one from zero
+    qsl.warm_start = 1;
+    const QpDev &q1 = h->qp1->d;
+    SCO_HIP(hipMemsetAsync(q1.x, 0, (size_t)q1.batch * q1.n * sizeof(double), h->stream));
+    SCO_HIP(hipMemsetAsync(q1.y, 0, (size_t)q1.batch * q1.m * sizeof(double), h->stream));
+    h->qp1->solved_once = true;
+  }
   const int round_cap = p.max_qp_solves + 8;
   while (n_active > 0 && h->rounds < round_cap) {
     SCO_HIP(hipMemsetAsync(s.n_active, 0, sizeof(int), h->stream));
@@ -958,7 +967,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     SCO_HIP(hipGetLastError());
     mark(0);
     mid = next_event(h, ec); stage.push_back(1);
-    rc = sco_qp_launch(h->qp1, qs, s.active, mid);
+    rc = sco_qp_launch(h->qp1, &qsl, s.active, mid);
     if (rc) return rc;
     mark(2);
     hipLaunchKernelGGL(sqp_post_kernel, grid, block, 0, h->stream, s, h->qp1->d, p);

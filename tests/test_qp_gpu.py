@@ -257,3 +257,30 @@ def test_structured_tier_is_run_to_run_deterministic(gpu, monkeypatch):
         outs.append(qp.solve()); qp.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][3], outs[1][3])
+
+
+def test_warm_start_is_opt_in_and_converges_to_the_same_answer(gpu):
+    """sco_qp_settings.warm_start (beyond parity: the reference always starts cold): re-solving from the
+    previous solution ends at the first termination check; a perturbed QP needs fewer iterations than
+    from zero and agrees to the QP tolerances."""
+    rng = np.random.default_rng(11)
+    probs = [penalty_qp(rng, 5, 3, 4) for _ in range(4)]
+    n, m, Pp, Pi, Ap, Ai, Pval, q, Aval, l, u = _stack(probs)
+    qp = _lib.BatchedQP(4, n, m, Pp, Pi, Ap, Ai)
+    qp.load(Pval, q, Aval, l, u)
+    x0, y0, st0, it0, _ = qp.solve()
+    xa, _, sta, ita, _ = qp.solve()                                   # default: cold again, identical
+    assert np.array_equal(xa, x0) and np.array_equal(ita, it0)
+    warm = _lib.default_qp_settings(warm_start=1)
+    xw, _, stw, itw, _ = qp.solve(warm)
+    assert np.all(stw == 1) and np.all(itw <= 50) and np.all(itw <= it0)
+    assert np.abs(xw - x0).max() < 1e-5
+    q2 = q + 0.05 * rng.standard_normal(q.shape)                      # a nearby QP: cold vs warm
+    qp.load(Pval, q2, Aval, l, u)
+    xc, _, stc, itc, _ = qp.solve()
+    qp.load(Pval, q, Aval, l, u); qp.solve()                          # previous solution = the old QP's
+    qp.load(Pval, q2, Aval, l, u)
+    xw2, _, stw2, itw2, _ = qp.solve(warm)
+    qp.close()
+    assert np.array_equal(stc, stw2) and np.abs(xw2 - xc).max() < 1e-4
+    assert itw2.sum() < itc.sum()

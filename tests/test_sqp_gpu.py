@@ -349,3 +349,24 @@ def test_velocity_limits_7x20_batch(gpu):
         a = af.make_batch(1, d=3, T=6, K=2, O=2, vel_limit=0.5)[0]
         with pytest.raises(ValueError):
             tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"])
+
+
+def test_warm_started_qps_in_the_device_loop(gpu):
+    """sco_sqp_params.warm_start_qps (beyond parity): same kind of answer with fewer ADMM iterations;
+    repeated solves stay deterministic (the first penalty QP always starts from zero)."""
+    arrays, probs = af.make_batch(64)
+    cold_p = _lib.default_sqp_params(compound_penalty=0, duplicate_rows=0, max_sqp_iters=12)
+    warm_p = _lib.default_sqp_params(compound_penalty=0, duplicate_rows=0, max_sqp_iters=12, warm_start_qps=1)
+    with sb.TrajOptBatch(64, 7, 20, 5, 2) as tb:
+        tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                arrays["point_frac"], arrays["obstacles"])
+        tb.solve(cold_p); cold = tb.fetch()
+        tb.solve(warm_p); w1 = tb.fetch()
+        tb.solve(warm_p); w2 = tb.fetch()
+    assert np.array_equal(w1.x, w2.x) and np.array_equal(w1.admm_iters, w2.admm_iters)
+    assert w1.admm_iters.sum() < 0.8 * cold.admm_iters.sum()
+    both = cold.success & w1.success
+    assert both.sum() >= 0.8 * cold.success.sum()
+    assert np.all(w1.max_violation[w1.success] <= 1e-4)
+    x = w1.x.reshape(64, 20, 7)
+    assert np.abs(x[:, 0, :] - arrays["start"]).max() < 1e-4 and np.abs(x[:, -1, :] - arrays["goal"]).max() < 1e-4
