@@ -325,3 +325,24 @@ def test_random_sparsity_patterns_match_oracle(gpu, seed):
     probs[1] = (probs[1][0], probs[1][1], probs[1][2],
                 np.minimum(probs[1][3], (probs[1][2] @ np.zeros(n)) - 0.0), np.maximum(probs[1][4], 0.0))   # 0 feasible
     _check(probs, resid_tol=TOL)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_infeasible_qps_get_the_oracles_status(gpu, seed):
+    """Primal infeasible (two contradictory equality rows) and dual infeasible (a free direction with a
+    linear cost and no curvature) variants of random QPs: certificates are detected at the same check."""
+    rng = np.random.default_rng(900 + seed)
+    n, m = int(rng.integers(5, 25)), int(rng.integers(3, 20))
+    P, q, A, lo, hi = _random_qp(rng, n, m, 0.3)
+    a = rng.standard_normal(n)
+    A1 = np.vstack([a, a, A]); lo1 = np.concatenate([[1.0, -1.0], lo]); hi1 = np.concatenate([[1.0, -1.0], hi])
+    _, _, st, _ = _check([(P, q, A1, lo1, hi1)], resid_tol=np.inf)
+    assert st[0] in (-3, 3)
+    j = int(np.argmin(np.abs(P).sum(axis=0) + 1e9 * (np.abs(P).sum(axis=0) > 0)))      # a variable without curvature, if any
+    P2 = P.copy(); P2[j, :] = 0.0; P2[:, j] = 0.0
+    A2 = A.copy(); lo2, hi2 = lo.copy(), hi.copy()
+    rows = np.nonzero(A2[:, j])[0]
+    lo2[rows] = -np.inf; hi2[rows] = np.inf                                            # nothing bounds x_j any more
+    q2 = q.copy(); q2[j] = 1.0
+    _, _, st, _ = _check([(P2, q2, A2, lo2, hi2)], resid_tol=np.inf)
+    assert st[0] in (-4, 4)
