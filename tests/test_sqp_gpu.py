@@ -370,3 +370,26 @@ def test_warm_started_qps_in_the_device_loop(gpu):
     assert np.all(w1.max_violation[w1.success] <= 1e-4)
     x = w1.x.reshape(64, 20, 7)
     assert np.abs(x[:, 0, :] - arrays["start"]).max() < 1e-4 and np.abs(x[:, -1, :] - arrays["goal"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_and_feature_mixes_match_oracle(gpu, seed):
+    """Random small descriptors with random combinations of reach / velocity limits / groups / analytic
+    Jacobians / solver knobs: same decisions, iteration counts and answers as the oracle."""
+    rng = np.random.default_rng(4000 + seed)
+    d, T, K, O = int(rng.integers(1, 6)), int(rng.integers(2, 9)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    kw = dict(d=d, T=T, K=K, O=O, reach=bool(rng.integers(2)))
+    if rng.integers(2):
+        kw["vel_limit"] = float(rng.uniform(0.4, 1.5))
+    if rng.integers(2):
+        kw["groups"] = ["halves", "split"][int(rng.integers(2))]
+    analytic = bool(rng.integers(2))
+    knobs = dict(initial_penalty_coeff=float(10 ** rng.uniform(0.5, 3)), max_merit_coeff_increases=int(rng.integers(1, 4)),
+                 compound_penalty=int(rng.integers(2)), duplicate_rows=int(rng.integers(2)))
+    arrays, probs = af.make_batch(3, first=int(rng.integers(0, 50)), **kw)
+    res = sb.solve_batch(arrays, params=_lib.default_sqp_params(max_sqp_iters=40, **knobs), analytic_jac=analytic)
+    op = sr.SolverParams(initial_penalty_coeff=knobs["initial_penalty_coeff"],
+                         max_merit_coeff_increases=knobs["max_merit_coeff_increases"],
+                         compound_penalty=bool(knobs["compound_penalty"]), duplicate_rows=bool(knobs["duplicate_rows"]),
+                         max_qp_solves=40)
+    _compare(res, probs, range(3), op, analytic=analytic)
