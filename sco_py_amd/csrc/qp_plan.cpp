@@ -80,8 +80,11 @@ int qp_plan_build(int n, int m, const int *Pp, const int *Pi, const int *Ap, con
     deg[j] = d;
   }
   std::vector<int> cand;
+  // allow_elim == 2: only variables that sit in at most two rows (what the row-local kernels can keep
+  // in one thread); == 1: any variable without an off-diagonal P entry
   if (allow_elim)
-    for (int j = 0; j < n; j++) if (!has_offdiag[j]) cand.push_back(j);
+    for (int j = 0; j < n; j++)
+      if (!has_offdiag[j] && (allow_elim != 2 || Ap[j + 1] - Ap[j] <= 2)) cand.push_back(j);
   std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return deg[a] < deg[b]; });
   std::vector<char> in_e(n, 0), blocked(n, 0);
   for (int j : cand) {

@@ -47,6 +47,7 @@ struct QpPlan {
 };
 
 // Returns 0 on success, negative on a malformed pattern.  allow_elim = 0 forces
-// E = {} (dense core of order n), used to cross-check the elimination path.
+// E = {} (dense core of order n), used to cross-check the elimination path;
+// allow_elim = 2 eliminates only variables that sit in at most two rows.
 int qp_plan_build(int n, int m, const int *Pp, const int *Pi, const int *Ap, const int *Ai,
                   int allow_elim, QpPlan &out);

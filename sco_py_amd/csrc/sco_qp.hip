@@ -597,7 +597,16 @@ static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const
   const char *force_big = getenv("SCO_QP_FORCE_BIG");
   if (qp->lds_setup > lds_cap || qp->lds_admm > lds_cap || pl.n_c > SCO_BLOCK || (force_big && force_big[0] == '1')) {
     // working set beyond a CU's LDS: the global-memory tier (sco_qp_big.hip)
-    if (pl.n_c > 1024 || !big_plan_build(pl, qp->big)) {
+    bool ok_big = pl.n_c <= 1024 && big_plan_build(pl, qp->big);
+    if (!ok_big && !(no_elim && no_elim[0] == '1')) {
+      // the global-memory kernels keep an eliminated variable and its (at most two) rows in one thread:
+      // send variables with more rows to the core and analyse again
+      rc = qp_plan_build(n, m, Pp, Pi, Ap, Ai, 2, qp->plan);
+      if (rc != 0) { sco_set_error("sco_qp_create: malformed sparsity pattern"); return SCO_ERR_ARG; }
+      qp->big = BigHost();
+      ok_big = pl.n_c <= 1024 && big_plan_build(pl, qp->big);
+    }
+    if (!ok_big) {
       char buf[256];
       snprintf(buf, sizeof buf, "sco_qp_create: pattern not supported (setup %zu B, admm %zu B of LDS, core %d)",
                qp->lds_setup, qp->lds_admm, pl.n_c);

@@ -346,3 +346,13 @@ def test_random_infeasible_qps_get_the_oracles_status(gpu, seed):
     q2 = q.copy(); q2[j] = 1.0
     _, _, st, _ = _check([(P2, q2, A2, lo2, hi2)], resid_tol=np.inf)
     assert st[0] in (-4, 4)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("no_bt", ["0", "1"])
+def test_random_sparsity_patterns_through_the_global_memory_tier(gpu, monkeypatch, seed, no_bt):
+    monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    monkeypatch.setenv("SCO_QP_NO_BT", no_bt)
+    rng = np.random.default_rng(700 + seed)
+    n, m = int(rng.integers(4, 40)), int(rng.integers(0, 40))
+    _check([_random_qp(rng, n, m, float(rng.uniform(0.05, 0.4)))], resid_tol=TOL)
