@@ -356,3 +356,12 @@ def test_random_sparsity_patterns_through_the_global_memory_tier(gpu, monkeypatc
     rng = np.random.default_rng(700 + seed)
     n, m = int(rng.integers(4, 40)), int(rng.integers(0, 40))
     _check([_random_qp(rng, n, m, float(rng.uniform(0.05, 0.4)))], resid_tol=TOL)
+
+
+def test_a_qp_that_needs_the_global_memory_tier_by_itself(gpu):
+    """No switches: 300 variables with a dense-ish core exceed the LDS tiers and land on the dense form of
+    the global-memory tier (the core is not banded)."""
+    rng = np.random.default_rng(31)
+    prob = _random_qp(rng, 300, 150, 0.02)
+    info, x, st, it = _check([prob], resid_tol=TOL)
+    assert info["n_core"] > 256 and info["lds_admm"] == 0
