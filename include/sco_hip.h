@@ -75,7 +75,8 @@ typedef struct sco_qp_settings {
                                osqp_utils.py:195) | 1: start ADMM from the handle's previous solution
                                (x, y; z = A x), as OSQP's own warm start does.  NOT parity mode: iterates and
                                iteration counts change, the solution agrees to the QP tolerances.  Honoured by
-                               the row-local tier (the one 7-DOF x 20 runs on); other tiers start cold.  */
+                               the row-local tier (the one 7-DOF x 20 runs on) and the structured global-memory
+                               tier (12-DOF x 50); the other tiers start cold.  */
 } sco_qp_settings;
 
 void sco_qp_default_settings(sco_qp_settings *s);

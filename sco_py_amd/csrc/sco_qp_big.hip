@@ -99,7 +99,7 @@ struct BigArgs {
   int n_free;
   double *ws; size_t ws_stride;
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
-  int max_iter, check, scaling;
+  int max_iter, check, scaling, warm;
   // block-tridiagonal core (bt_bs > 0): S goes to block storage instead of the dense array
   int bt_bs, bt_nb, bt_mid;
   double *bt_blk; size_t bt_stride;
@@ -1091,16 +1091,44 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
     }
     for (int t = tid; t < a.nchunks * CH_STRIDE; t += BTT) s_dsc[t] = a.ch_desc[t];
   }
-  for (int j = tid; j < n; j += BTT) { x[j] = 0.0; sdx[j] = 0.0; }
-  for (int i = tid; i < m; i += BTT) { z[i] = 0.0; y[i] = 0.0; tp[i] = 0.0; sdy[i] = 0.0; }
-  __syncthreads();
-  for (int c = tid; c < n_c; c += BTT) s_q[c] = qs[d.core_var[c]];
-  for (int e = tid; e < n_e; e += BTT) {
-    const double g = -qs[d.elim_var[e]] * kinv[e];
-    ge[e] = g;
-    for (int r = a.er_ptr[e]; r < a.er_ptr[e + 1]; r++) {
-      const int i = a.er_row[r];
-      tp[i] = -((double)w[i] * rho[i]) * As[a.row_epos[i]] * g;
+  if (a.warm) {
+    // OSQP-style warm start from the handle's previous (unscaled) solution in x / y:
+    //   x_s = x / D,  y_s = c y / (E w),  z = A_s x_s,  t = w (rho z - y)
+    for (int j = tid; j < n; j += BTT) { x[j] = x[j] / Dg[j]; sdx[j] = 0.0; }
+    for (int i = tid; i < m; i += BTT) { y[i] = y[i] * cscale / (Eg[i] * (double)w[i]); sdy[i] = 0.0; }
+    __syncthreads();
+    for (int c = tid; c < n_c; c += BTT) { s_q[c] = qs[d.core_var[c]]; s_x[c] = x[d.core_var[c]]; }
+    for (int i = tid; i < m; i += BTT) {
+      double ax = 0.0;
+      for (int s2 = d.Rp[i]; s2 < d.Rp[i + 1]; s2++) ax += As[d.Rpos[s2]] * x[d.Rj[s2]];
+      z[i] = ax;
+      tp[i] = (double)w[i] * (rho[i] * ax - y[i]);
+    }
+    __syncthreads();
+    for (int e = tid; e < n_e; e += BTT) {
+      const int j = d.elim_var[e];
+      double acc = sigma * x[j] - qs[j];
+      for (int r = a.er_ptr[e]; r < a.er_ptr[e + 1]; r++) acc += As[a.row_epos[a.er_row[r]]] * tp[a.er_row[r]];
+      ge[e] = acc * kinv[e];
+    }
+    __syncthreads();
+    for (int e = tid; e < n_e; e += BTT)              // t' = t - rw a_e g_e on the rows of every eliminated variable
+      for (int r = a.er_ptr[e]; r < a.er_ptr[e + 1]; r++) {
+        const int i = a.er_row[r];
+        tp[i] -= ((double)w[i] * rho[i]) * As[a.row_epos[i]] * ge[e];
+      }
+  } else {
+    for (int j = tid; j < n; j += BTT) { x[j] = 0.0; sdx[j] = 0.0; }
+    for (int i = tid; i < m; i += BTT) { z[i] = 0.0; y[i] = 0.0; tp[i] = 0.0; sdy[i] = 0.0; }
+    __syncthreads();
+    for (int c = tid; c < n_c; c += BTT) s_q[c] = qs[d.core_var[c]];
+    for (int e = tid; e < n_e; e += BTT) {
+      const double g = -qs[d.elim_var[e]] * kinv[e];
+      ge[e] = g;
+      for (int r = a.er_ptr[e]; r < a.er_ptr[e + 1]; r++) {
+        const int i = a.er_row[r];
+        tp[i] = -((double)w[i] * rho[i]) * As[a.row_epos[i]] * g;
+      }
     }
   }
   __syncthreads();
@@ -1356,7 +1384,7 @@ int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, con
   ba.ws = bd.ws; ba.ws_stride = bh.ws_doubles;
   ba.rho = a.rho; ba.sigma = a.sigma; ba.alpha = a.alpha; ba.eps_abs = a.eps_abs; ba.eps_rel = a.eps_rel;
   ba.eps_prim_inf = a.eps_prim_inf; ba.eps_dual_inf = a.eps_dual_inf;
-  ba.max_iter = a.max_iter; ba.check = a.check; ba.scaling = scaling;
+  ba.max_iter = a.max_iter; ba.check = a.check; ba.scaling = scaling; ba.warm = a.warm;
   if (th) {
     ba.bt_bs = th->bs; ba.bt_nb = th->nb; ba.bt_mid = th->nb >= 4 ? th->nb / 2 : th->nb - 1; ba.bt_blk = td->blk; ba.bt_stride = th->blk_doubles;
     ba.ch_desc = td->ch_desc; ba.it = td->it; ba.cent = td->cent; ba.nchunks = th->nchunks;

@@ -259,12 +259,16 @@ def test_structured_tier_is_run_to_run_deterministic(gpu, monkeypatch):
     assert np.array_equal(outs[0][3], outs[1][3])
 
 
-def test_warm_start_is_opt_in_and_converges_to_the_same_answer(gpu):
+@pytest.mark.parametrize("tier", ["row-local", "structured"])
+def test_warm_start_is_opt_in_and_converges_to_the_same_answer(gpu, monkeypatch, tier):
     """sco_qp_settings.warm_start (beyond parity: the reference always starts cold): re-solving from the
-    previous solution ends at the first termination check; a perturbed QP needs fewer iterations than
-    from zero and agrees to the QP tolerances."""
+    previous solution needs a fraction of the iterations (not zero: z restarts at A x and the triple is
+    only converged to the tolerances); a perturbed QP needs fewer iterations than from zero and agrees to
+    the QP tolerances."""
+    if tier == "structured":
+        monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
     rng = np.random.default_rng(11)
-    probs = [penalty_qp(rng, 5, 3, 4) for _ in range(4)]
+    probs = [penalty_qp(rng, 5, 3, 20 if tier == "structured" else 4) for _ in range(4)]   # 20 rows per block: dense chunks
     n, m, Pp, Pi, Ap, Ai, Pval, q, Aval, l, u = _stack(probs)
     qp = _lib.BatchedQP(4, n, m, Pp, Pi, Ap, Ai)
     qp.load(Pval, q, Aval, l, u)
@@ -273,7 +277,7 @@ def test_warm_start_is_opt_in_and_converges_to_the_same_answer(gpu):
     assert np.array_equal(xa, x0) and np.array_equal(ita, it0)
     warm = _lib.default_qp_settings(warm_start=1)
     xw, _, stw, itw, _ = qp.solve(warm)
-    assert np.all(stw == 1) and np.all(itw <= 50) and np.all(itw <= it0)
+    assert np.all(stw == 1) and np.all(itw <= it0) and itw.sum() < 0.5 * it0.sum()
     assert np.abs(xw - x0).max() < 1e-5
     q2 = q + 0.05 * rng.standard_normal(q.shape)                      # a nearby QP: cold vs warm
     qp.load(Pval, q2, Aval, l, u)
