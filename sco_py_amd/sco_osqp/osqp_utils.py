@@ -207,6 +207,11 @@ def assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, osqp_lin_cnt_exprs):
 # Device handles are kept per sparsity pattern: the SQP loop sends the same pattern again for every
 # trust-region retry and every SQP iteration (the re-appended rows are folded into weights), and
 # creating a handle (symbolic analysis + device allocations) costs more than a well-conditioned QP.
+# Extension (off by default, NOT reference behaviour): start every QP from the previous solution of the
+# same pattern's handle, as OSQP's own warm start would; the reference builds a new OSQP object per QP and
+# always starts cold (osqp_utils.py:195).  Iterates and iteration counts change, answers agree to the QP tolerances.
+WARM_START = False
+
 _HANDLE_CACHE = collections.OrderedDict()
 _HANDLE_CACHE_MAX = 8
 _TIER_SWITCHES = ("SCO_QP_NO_ELIM", "SCO_QP_NO_RL", "SCO_QP_NO_REG", "SCO_QP_NO_FAST", "SCO_QP_FORCE_BIG", "SCO_QP_NO_BT")
@@ -252,7 +257,8 @@ def _solve_qp_batch(requests):
     w = None
     if any(r["w"] is not None for r in requests):
         w = np.stack([r["w"] if r["w"] is not None else np.ones(m, dtype=np.int32) for r in requests])
-    st = _lib.default_qp_settings(rho=rho, sigma=sigma, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=int(max_iter))
+    st = _lib.default_qp_settings(rho=rho, sigma=sigma, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=int(max_iter),
+                                  warm_start=1 if WARM_START else 0)
     with _HANDLE_LOCK:
         qp = _cached_handle(B, n, m, P0, A0)
         try:

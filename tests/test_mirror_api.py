@@ -391,3 +391,33 @@ def test_device_handles_are_reused_per_sparsity_pattern(gpu):
     assert len(ou._HANDLE_CACHE) == ou._HANDLE_CACHE_MAX and first not in ou._HANDLE_CACHE.values()
     ou.clear_handle_cache()
     assert len(ou._HANDLE_CACHE) == 0
+
+
+@pytest.mark.gpu
+def test_warm_start_extension_of_the_seam(gpu):
+    """osqp_utils.WARM_START (off by default): same optimum, never more ADMM iterations on a repeated
+    pattern (how many fewer depends on how far the multipliers move between two QPs)."""
+    import trajopt_build as tb
+    from oracle import arm_family as af
+    from sco_py_amd.sco_osqp import osqp_utils as ou
+    real, log = ou._solve_qp_batch, []
+
+    def logged(reqs):
+        out = real(reqs); log.append(out[0][2]); return out
+
+    results = {}
+    try:
+        ou._solve_qp_batch = logged
+        for warm in (False, True):
+            ou.clear_handle_cache(); del log[:]
+            ou.WARM_START = warm
+            pr = af.make_problem(3, d=3, T=6, K=2, O=2)
+            prob, traj, _, _ = tb.build_prob(M, pr)
+            s = M.Solver(); s.initial_penalty_coeff = 10.0; s.max_merit_coeff_increases = 3
+            ok = s.solve(prob, method="penalty_sqp")
+            results[warm] = (ok, traj.get_value().ravel().copy(), list(log))
+    finally:
+        ou._solve_qp_batch = real; ou.WARM_START = False; ou.clear_handle_cache()
+    assert results[False][0] == results[True][0]
+    assert np.abs(results[False][1] - results[True][1]).max() < 1e-3
+    assert sum(results[True][2]) <= sum(results[False][2])
