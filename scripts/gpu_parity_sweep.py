@@ -1,0 +1,28 @@
+"""Parity sweep: GPU device loop vs oracle on problems [first, first+N) of the 7x20 workload (parity mode)."""
+import sys, os, time
+import numpy as np
+from concurrent.futures import ProcessPoolExecutor
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import arm_family as af, sco_ref as sr
+
+def ref_one(i):
+    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i)), emulate_memo=True)
+    return i, out.trace, out.x, out.success
+
+if __name__ == "__main__":
+    first, N = int(sys.argv[1]), int(sys.argv[2])
+    with ProcessPoolExecutor(32) as ex:                 # oracle on the host cores first (no GPU touched yet)
+        refs = list(ex.map(ref_one, range(first, first + N), chunksize=4))
+    from sco_py_amd import batch as sb
+    arrays, _ = af.make_batch(N, first=first)
+    res = sb.solve_batch(arrays)
+    bad = 0; worst = 0.0
+    for k, (i, tr, x, ok) in enumerate(refs):
+        g = res.trace[k]
+        same = g.shape == tr[:64].shape and np.array_equal(g[:, 0], tr[:64, 0]) and np.array_equal(g[:, 6:8], tr[:64, 6:8])
+        dx = float(np.abs(res.x[k] - x).max())
+        worst = max(worst, dx)
+        if not same or dx > 1e-6 or bool(res.success[k]) != ok:
+            bad += 1
+            print("MISMATCH problem", i, "gpu", g[:, [0, 6, 7]].astype(int).tolist(), "oracle", tr[:, [0, 6, 7]].astype(int).tolist(), "dx %.2e" % dx)
+    print("problems %d..%d: %d mismatches, worst |dx| %.2e" % (first, first + N - 1, bad, worst))
