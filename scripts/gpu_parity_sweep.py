@@ -5,17 +5,27 @@ from concurrent.futures import ProcessPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import arm_family as af, sco_ref as sr
 
+MODE = sys.argv[3] if len(sys.argv) > 3 else "parity"          # parity | intended (quirks off, at most 20 QPs)
+KW = {}
+for tok in sys.argv[4:]:                                         # reach, vel, groups
+    if tok == "reach": KW["reach"] = True
+    if tok == "vel": KW["vel_limit"] = 0.4
+    if tok == "groups": KW["groups"] = "split"
+
+
 def ref_one(i):
-    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i)), emulate_memo=True)
+    params = sr.SolverParams(compound_penalty=False, duplicate_rows=False, max_qp_solves=20) if MODE == "intended" else None
+    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i, **KW)), params, emulate_memo=True)
     return i, out.trace, out.x, out.success
 
 if __name__ == "__main__":
     first, N = int(sys.argv[1]), int(sys.argv[2])
     with ProcessPoolExecutor(32) as ex:                 # oracle on the host cores first (no GPU touched yet)
         refs = list(ex.map(ref_one, range(first, first + N), chunksize=4))
-    from sco_py_amd import batch as sb
-    arrays, _ = af.make_batch(N, first=first)
-    res = sb.solve_batch(arrays)
+    from sco_py_amd import batch as sb, _lib
+    arrays, _ = af.make_batch(N, first=first, **KW)
+    p = _lib.default_sqp_params(compound_penalty=0, duplicate_rows=0, max_sqp_iters=20) if MODE == "intended" else None
+    res = sb.solve_batch(arrays, params=p)
     bad = 0; worst = 0.0
     for k, (i, tr, x, ok) in enumerate(refs):
         g = res.trace[k]
@@ -25,4 +35,4 @@ if __name__ == "__main__":
         if not same or dx > 1e-6 or bool(res.success[k]) != ok:
             bad += 1
             print("MISMATCH problem", i, "gpu", g[:, [0, 6, 7]].astype(int).tolist(), "oracle", tr[:, [0, 6, 7]].astype(int).tolist(), "dx %.2e" % dx)
-    print("problems %d..%d: %d mismatches, worst |dx| %.2e" % (first, first + N - 1, bad, worst))
+    print("%s %s problems %d..%d: %d mismatches, worst |dx| %.2e" % (MODE, sorted(KW), first, first + N - 1, bad, worst))
