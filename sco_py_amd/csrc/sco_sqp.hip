@@ -250,8 +250,10 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
   const double c = (double)s.prox_count;
   const double *x0 = s.x0 + (size_t)b * n_x;
   for (int i = tid; i < n_x; i += SCO_BLOCK) {
-    q0.Pval[(size_t)b * q0.nnzP + i] = 2.0 * c;
-    q0.q[(size_t)b * n_x + i] = (-2.0 * x0[i]) * c;
+    // entries whose initial value is unknown (NaN) take no part in the distance (prob.py:394-404)
+    const bool known = !isnan(x0[i]);
+    q0.Pval[(size_t)b * q0.nnzP + i] = known ? 2.0 * c : 0.0;
+    q0.q[(size_t)b * n_x + i] = known ? (-2.0 * x0[i]) * c : 0.0;
     s.x[(size_t)b * n_x + i] = x0[i];
   }
   for (int t = tid; t < q0.nnzA; t += SCO_BLOCK) q0.Aval[(size_t)b * q0.nnzA + t] = s.a0c[t];

@@ -393,3 +393,16 @@ def test_random_shapes_and_feature_mixes_match_oracle(gpu, seed):
                          compound_penalty=bool(knobs["compound_penalty"]), duplicate_rows=bool(knobs["duplicate_rows"]),
                          max_qp_solves=40)
     _compare(res, probs, range(3), op, analytic=analytic)
+
+
+def test_unknown_initial_values_are_left_out_of_the_projection(gpu):
+    """NaN entries of the initial trajectory (Variable values that are not known yet) do not enter
+    find_closest_feasible_point's distance (prob.py:394-404): same answer as the oracle."""
+    arrays, probs = af.make_batch(4, d=3, T=6, K=2, O=2)
+    for b in range(4):
+        x0 = arrays["x0"][b].reshape(6, 3)
+        x0[2 + (b % 2), :] = np.nan; x0[4, b % 3] = np.nan
+        probs[b]["x0"] = arrays["x0"][b].copy()
+    res = sb.solve_batch(arrays)
+    assert np.all(np.isfinite(res.x))
+    _compare(res, probs, range(4))
