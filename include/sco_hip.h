@@ -235,6 +235,15 @@ int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco_qp_setting
 int sco_sqp_fetch(sco_sqp *h, double *x, int *success, int *sqp_iters, int *qp_solves,
                   long long *admm_iters, double *merit, double *max_violation);
 
+/* Per-problem diagnostics of the last solve (bit flags): where this implementation had to leave the
+ * reference's unbounded behaviour. */
+#define SCO_SQP_FLAG_MEMO_FULL 1   /* a point could not be added to the Q3 memo histories (40 evaluated / 24
+                                      convexified points per constraint block); the reference caches without
+                                      bound, so a LATER point rounding onto it would be recomputed here          */
+#define SCO_SQP_FLAG_CAPPED 2      /* max_sqp_iters stopped the problem (the reference's loops are unbounded)   */
+#define SCO_SQP_FLAG_TRACE_FULL 4  /* more decisions than sco_sqp_trace keeps (64)                              */
+int sco_sqp_fetch_flags(sco_sqp *h, int *flags);
+
 /* Per-problem decision trace of the last solve, for stage-wise parity checks:
  * trace[batch][cap][8] = {kind, merit, model_merit, new_merit, trust, penalty,
  * qp_status, qp_iters}; n_entries[batch].  kind: 0 projection QP, 1 accepted step,

@@ -130,10 +130,13 @@ class TrajOptBatch(object):
             admm.ctypes.data_as(C.POINTER(C.c_longlong)), _lib.dptr(merit), _lib.dptr(viol)))
         nc = np.zeros(B, dtype=np.uint32)
         _lib.check(_lib.load().sco_sqp_fetch_groups(self._h, nc.ctypes.data_as(C.POINTER(C.c_uint))))
+        flags = np.zeros(B, dtype=np.int32)
+        _lib.check(_lib.load().sco_sqp_fetch_flags(self._h, _lib.iptr(flags)))
         gids = getattr(self, "group_ids", ["all"])
         groups = [[g for k, g in enumerate(gids) if (int(m) >> k) & 1] for m in nc]
         return SimpleNamespace(x=x, success=success.astype(bool), sqp_iters=sqp_iters, qp_solves=qp_solves,
-                               admm_iters=admm, merit=merit, max_violation=viol, nonconverged_groups=groups)
+                               admm_iters=admm, merit=merit, max_violation=viol, nonconverged_groups=groups,
+                               flags=flags)      # bit flags SCO_SQP_FLAG_* (memo history full, capped, trace full)
 
     def trace(self, cap=64):
         """Per-problem decision trace: list of (n_rows, 8) arrays with columns

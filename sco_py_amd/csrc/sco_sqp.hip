@@ -44,6 +44,7 @@ struct SqpScalars {
   double penalty, trust, slack_cost, merit, merit_viol;
   long long admm_iters;
   int state, k, sqp_iters, qp_solves, success, escalations, n_trace, spawned;
+  int flags;      // SCO_SQP_FLAG_*
 };
 
 struct SqpDev {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
   if (tid == 0) {
     SqpScalars &sc = s.sc[b];
     sc.state = ST_PROJECT; sc.k = 0; sc.sqp_iters = 0; sc.qp_solves = 0; sc.success = 0;
-    sc.escalations = 0; sc.n_trace = 0; sc.spawned = 0; sc.admm_iters = 0;
+    sc.escalations = 0; sc.n_trace = 0; sc.spawned = 0; sc.admm_iters = 0; sc.flags = 0;
     sc.slack_cost = 1.0; sc.merit = 0.0; sc.merit_viol = 0.0;
     s.active[b] = 1; s.nonconv[b] = 0u;
   }
@@ -482,11 +483,11 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         if (ev_hit[t] < 0 && hn[t] < H) {
           for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(xb[j] * 1e6);
           hn[t] += 1;
-        }
+        } else if (ev_hit[t] < 0) atomicOr(&sc.flags, SCO_SQP_FLAG_MEMO_FULL);
         if (cv_hit[t] < 0 && cn[t] < HC) {
           for (int j = 0; j < d; j++) ckey[((size_t)t * HC + cn[t]) * d + j] = rint(xb[j] * 1e6);
           cn[t] += 1;
-        }
+        } else if (cv_hit[t] < 0) atomicOr(&sc.flags, SCO_SQP_FLAG_MEMO_FULL);
       }
     if (tid == 0) {
       sc.merit_viol = v[1];
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
         const double *xb = xq + (t < T ? t : T - 1) * d;
         for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(xb[j] * 1e6);
         hn[t] += 1;
-      }
+      } else if (ev_hit[t] < 0) atomicOr(&sc.flags, SCO_SQP_FLAG_MEMO_FULL);
   block_reduce_sm<3, 1>(v, red);
   // constraint groups: which violated groups stopped improving, and do their overlapping groups too
   // (solver.py:155-161, 209-235)
@@ -623,6 +624,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
     if (kind != STEP_BAD && kind != STEP_YCONV)
       s.nonconv[b] = (kind == STEP_GROUP) ? (s.G > 0 ? g_report : 1u) : 0u;
     sc.qp_solves = qp_solves; sc.admm_iters += iters;
+    if (capped) atomicOr(&sc.flags, SCO_SQP_FLAG_CAPPED);
+    if (sc.n_trace >= s.trace_cap) atomicOr(&sc.flags, SCO_SQP_FLAG_TRACE_FULL);
     trace_row(s, b, sc, kind, merit, model_merit, new_merit, trust, pen, status, iters);
     sc.trust = new_trust;
     if (ret < 0 && !capped) {
@@ -896,6 +899,17 @@ extern "C" int sco_sqp_set_groups(sco_sqp *h, int n_groups, const unsigned int *
   SCO_HIP(hipMemcpy((void *)s.goverlap, overlap, sizeof overlap, hipMemcpyHostToDevice));
   s.G = n_groups;
   h->solved = false;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_fetch_flags(sco_sqp *h, int *flags) {
+  if (!h || !flags) return SCO_ERR_ARG;
+  if (!h->solved) { sco_set_error("sco_sqp_fetch_flags: call sco_sqp_solve first"); return SCO_ERR_STATE; }
+  SCO_HIP(hipSetDevice(h->device));
+  const size_t B = h->d.batch;
+  std::vector<SqpScalars> sc(B);
+  SCO_HIP(hipMemcpy(sc.data(), h->d.sc, B * sizeof(SqpScalars), hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < B; b++) flags[b] = sc[b].flags;
   return SCO_OK;
 }
 

@@ -406,3 +406,16 @@ def test_unknown_initial_values_are_left_out_of_the_projection(gpu):
     res = sb.solve_batch(arrays)
     assert np.all(np.isfinite(res.x))
     _compare(res, probs, range(4))
+
+
+def test_diagnostic_flags(gpu):
+    """fetch().flags: bit 2 = stopped by max_sqp_iters (the reference's loops are unbounded); parity-mode
+    runs of the small workload set no flag."""
+    arrays, _ = af.make_batch(8, d=3, T=6, K=2, O=2)
+    res = sb.solve_batch(arrays)
+    assert np.all(res.flags == 0)
+    p = _lib.default_sqp_params(compound_penalty=0, duplicate_rows=0, max_sqp_iters=3)
+    res = sb.solve_batch(arrays, params=p)
+    capped = (res.flags & 2) != 0
+    assert capped.any() and np.all(res.qp_solves[capped] == 3) and not np.any(res.success[capped])
+    assert np.all(res.qp_solves[~capped] <= 3)
