@@ -156,6 +156,10 @@ typedef struct sco_sqp_params {
                                f values / affine model.  1 = reproduce (default)            */
   int warm_start_qps;       /* 0 (default, reference behaviour) | 1: every penalty QP of a problem starts from
                                the solution of its previous one (sco_qp_settings.warm_start); beyond parity   */
+  int admm_slice;           /* scheduling only, results are bit-identical: ADMM iterations per device launch.
+                               Problems whose QP ends inside a slice go on to their next QP while the others
+                               continue (no waiting for the slowest QP of a round).  0 = default (6250),
+                               < 0 = off (one launch per QP, lock-step rounds)                               */
 } sco_sqp_params;
 
 void sco_sqp_default_params(sco_sqp_params *p);

@@ -42,7 +42,7 @@ class SqpParams(C.Structure):
         ("initial_penalty_coeff", C.c_double),
         ("max_merit_coeff_increases", C.c_int), ("compound_penalty", C.c_int),
         ("duplicate_rows", C.c_int), ("max_sqp_iters", C.c_int),
-        ("memoize_rounded", C.c_int), ("warm_start_qps", C.c_int),
+        ("memoize_rounded", C.c_int), ("warm_start_qps", C.c_int), ("admm_slice", C.c_int),
     ]
 
 

@@ -203,6 +203,12 @@ struct RlArgs {
   double *x, *y, *resid;
   int *status, *iters;
   int warm;          // start from the previous (unscaled) solution held in x / y instead of zero
+  // time slicing (slice > 0): at most `slice` iterations per launch; an unfinished solve leaves status 0,
+  // its iteration count in prog[b] and its scaled state in the s* arrays, and the next launch resumes it
+  // bit-exactly (nothing is recomputed)
+  int slice;
+  int *prog;
+  double *sx, *sz, *sy, *st, *sg;
   double *stamp;     // diagnostic build only (SCO_STAMP), else unused
 };
 
@@ -382,7 +388,18 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   __syncthreads();
   const double cscale = a.cscale[b];
   const double alpha = a.alpha, sigma = a.sigma;
-  if (a.warm) {
+  const int it0 = a.slice > 0 ? a.prog[b] : 0;
+  if (it0 > 0) {
+    // resume an unfinished solve: every loop-carried value comes back from memory
+    if (cown >= 0) xcv = a.sx[(size_t)b * n + cvar];
+    if (eown >= 0) { xe = a.sx[(size_t)b * n + evar]; ge = a.sg[(size_t)b * n_e + eown]; }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (r_i[q] >= 0) {
+        r_z[q] = a.sz[(size_t)b * m + r_i[q]]; r_y[q] = a.sy[(size_t)b * m + r_i[q]];
+        s_tv[r_i[q]] = a.st[(size_t)b * m + r_i[q]];
+      }
+  } else if (a.warm) {
     // OSQP-style warm start from the previous solution of this handle (x, y unscaled in a.x / a.y):
     //   x_s = x / D,  y_s = c y / (E w),  z = A_s x_s;  then t, g_e, t' as after any iteration
     const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
@@ -495,10 +512,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       STAMP(5)
     }
   };
-  iter = 0;
-  while (!status && iter < a.max_iter) {
-    int next = a.max_iter;
-    if (a.check > 0) { next = (iter / a.check + 1) * a.check; if (next > a.max_iter) next = a.max_iter; }
+  iter = it0;
+  const int stop = (a.slice > 0 && it0 + a.slice < a.max_iter) ? it0 + a.slice : a.max_iter;
+  while (!status && iter < stop) {
+    int next = stop;
+    if (a.check > 0) { next = (iter / a.check + 1) * a.check; if (next > stop) next = stop; }
     // four iterations per trip: a loop trip costs several hundred cycles of refetch (profiles/r01_v6_stamps.txt)
     while (iter + 4 < next) { iter += 4; step(false); step(false); step(false); step(false); }
     while (iter + 1 < next) { iter++; step(false); }
@@ -633,6 +651,20 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       __syncthreads();
     }
   }
+  if (!status && iter < a.max_iter) {
+    // the slice is used up: park the solve
+    if (cown >= 0) a.sx[(size_t)b * n + cvar] = xcv;
+    if (eown >= 0) { a.sx[(size_t)b * n + evar] = xe; a.sg[(size_t)b * n_e + eown] = ge; }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (r_i[q] >= 0) {
+        a.sz[(size_t)b * m + r_i[q]] = r_z[q]; a.sy[(size_t)b * m + r_i[q]] = r_y[q];
+        a.st[(size_t)b * m + r_i[q]] = s_tv[r_i[q]];
+      }
+    if (tid == 0) { a.prog[b] = iter; a.status[b] = 0; a.iters[b] = iter; }
+    return;
+  }
+  if (a.slice > 0 && tid == 0) a.prog[b] = 0;
   if (!status) status = SCO_QP_MAX_ITER_REACHED;
   if (iter > a.max_iter) iter = a.max_iter;
 #ifdef SCO_STAMP
@@ -721,6 +753,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
   ra.warm = a.warm;
+  ra.slice = a.slice; ra.prog = d.prog; ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.st = d.st; ra.sg = d.sg;
   ra.stamp = nullptr;
 #ifdef SCO_STAMP
   {

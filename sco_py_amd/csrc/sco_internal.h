@@ -45,6 +45,9 @@ struct QpDev {
   // optional per-problem activity mask (NULL = all active); inactive problems
   // are skipped by both kernels
   const int *active;
+  // parked solves of the row-local tier (time slicing): iterations done, scaled x / z / y / t' / g_e
+  int *prog;
+  double *sx, *sz, *sy, *st, *sg;
 };
 
 // ---- fast ADMM path (sco_admm_fast.hip) ------------------------------------
@@ -65,6 +68,7 @@ struct AdmmArgs {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   int max_iter, check;
   int warm;     // start from the previous solution in d.x / d.y (row-local tier only)
+  int slice;    // > 0: at most this many ADMM iterations per launch (row-local tier only), see RlArgs
 };
 
 bool fast_plan_build(const QpPlan &pl, FastHost &fh);
@@ -160,3 +164,9 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
 // is non-zero; no host synchronisation.
 // `mid` (may be null) is recorded between the two kernels so callers can split the time.
 int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, hipEvent_t mid);
+// Time-sliced variant for the SQP loop: setup runs for the problems flagged in `setup_mask` (those that start
+// a new QP), ADMM for the ones in `active_dev` for at most `slice` iterations (0 = to the end); a problem whose
+// solve is not finished keeps status 0 and is resumed by the next call.  Returns the slice actually used
+// through *sliced (0 if the handle's tier cannot park a solve).
+int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
+                         int slice, hipEvent_t mid, int *sliced);

@@ -639,6 +639,7 @@ static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const
   AL(Ps, B * pl.nnzP) AL(As, B * pl.nnzA) AL(qs, B * n) AL(ls, B * m) AL(us, B * m) AL(D, B * n) AL(E, B * m)
   AL(cscale, B) AL(rho, B * m) AL(kee_inv, B * pl.n_e) AL(cpl, B * pl.ncpl) AL(W, (qp->use_bt ? 1 : B) * pl.n_c * pl.n_c)
   AL(x, B * n) AL(y, B * m) AL(resid, B * 2) AL(status, B) AL(iters, B)
+  AL(prog, B) AL(sx, B * n) AL(sz, B * m) AL(sy, B * m) AL(st, B * m) AL(sg, B * pl.n_e)
 #undef AL
   SCO_HIP(hipFuncSetAttribute((const void *)qp_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
@@ -729,10 +730,20 @@ extern "C" int sco_qp_set_bounds(sco_qp *qp, const double *l, const double *u) {
 }
 
 int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, hipEvent_t mid) {
+  return sco_qp_launch_sliced(qp, st, active_dev, active_dev, 0, mid, nullptr);
+}
+
+int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
+                         int slice, hipEvent_t mid, int *sliced) {
+  // only the row-local tier can park a solve; slices end on a termination check
+  if (!qp->use_rl || qp->use_big || st->check_termination <= 0 || slice <= 0) slice = 0;
+  else slice = std::max(1, slice / st->check_termination) * st->check_termination;
+  if (sliced) *sliced = slice;
   QpDev d = qp->d; d.active = active_dev;
-  SetupArgs sa{d, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling};
+  QpDev dsetup = qp->d; dsetup.active = setup_mask;
+  SetupArgs sa{dsetup, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling};
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
-              st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0};
+              st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0, slice};
   qp->solved_once = true;
   SCO_HIP(hipEventRecord(qp->ev[0], qp->stream));
   if (qp->use_big) {

@@ -64,6 +64,7 @@ struct SqpDev {
   unsigned char *mask;
   SqpScalars *sc;
   int *active, *n_active;
+  int *newqp;        // [B] 1 = this round's pre kernel prepared a new QP for the problem (setup mask)
   const int *jpos;   // [T*d] CSC position of J[t][0][j] in qp1's A values
   const int *epos;   // [d]   CSC position of the first equality-row entry of column (T-1, j)
   // constraint groups (prob.py:81-86, 135-142): G = 0 means the default single group "all"
@@ -350,7 +351,10 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
   const int b = blockIdx.x, tid = threadIdx.x;
   SqpScalars &sc = s.sc[b];
   const int state = sc.state;
-  if (state == ST_DONE) return;
+  // a problem whose QP is parked between two ADMM slices keeps its QP untouched
+  const bool parked = q1.prog && q1.prog[b] > 0;
+  if (tid == 0) s.newqp[b] = (state != ST_DONE && !parked) ? 1 : 0;
+  if (state == ST_DONE || parked) return;
   __shared__ double red[NWAVE * 4];
   const int n_x = s.n_x, d = s.d, T = s.T, R = s.R, O = s.O, n = s.n, m = s.m;
   double *x = s.x + (size_t)b * n_x, *xs = s.x_saved + (size_t)b * n_x;
@@ -513,6 +517,10 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   const int b = blockIdx.x, tid = threadIdx.x;
   SqpScalars &sc = s.sc[b];
   if (sc.state != ST_TRIAL) return;
+  if (q1.prog && q1.prog[b] > 0) {             // its QP is parked between two ADMM slices: nothing to decide yet
+    if (tid == 0) atomicAdd(s.n_active, 1);
+    return;
+  }
   __shared__ double red[NWAVE * 4];
   const int n_x = s.n_x, d = s.d, T = s.T, R = s.R, O = s.O, n = s.n;
   double *x = s.x + (size_t)b * n_x, *xs = s.x_saved + (size_t)b * n_x;
@@ -552,13 +560,17 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
     v[3] = fmax(v[3], row_viol(q, gs[e] - rhs));                 // max violation at the SAVED point
   }
   __syncthreads();
-  if (p.memo)
-    for (int t = tid; t < NB; t += SCO_BLOCK)
+  if (p.memo) {
+    for (int t = tid; t < NB; t += SCO_BLOCK) {
       if (ev_hit[t] < 0 && hn[t] < H) {
         const double *xb = xq + (t < T ? t : T - 1) * d;
         for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(xb[j] * 1e6);
         hn[t] += 1;
-      } else if (ev_hit[t] < 0) atomicOr(&sc.flags, SCO_SQP_FLAG_MEMO_FULL);
+      } else if (ev_hit[t] < 0) {
+        atomicOr(&sc.flags, SCO_SQP_FLAG_MEMO_FULL);
+      }
+    }
+  }
   block_reduce_sm<3, 1>(v, red);
   // constraint groups: which violated groups stopped improving, and do their overlapping groups too
   // (solver.py:155-161, 209-235)
@@ -676,7 +688,7 @@ extern "C" void sco_sqp_default_params(sco_sqp_params *p) {
   p->trust_shrink_ratio = 0.1; p->trust_expand_ratio = 1.5; p->cnt_tolerance = 1e-4;
   p->merit_coeff_increase_ratio = 10.0; p->initial_trust_region_size = 1.0; p->initial_penalty_coeff = 1e3;
   p->max_merit_coeff_increases = 1; p->compound_penalty = 1; p->duplicate_rows = 1; p->max_sqp_iters = 0;
-  p->memoize_rounded = 1; p->warm_start_qps = 0;
+  p->memoize_rounded = 1; p->warm_start_qps = 0; p->admm_slice = 0;
 }
 
 template <typename T>
@@ -798,7 +810,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2) AL(vmax, (size_t)B)
   AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
   AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
-  AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, 1)
+  AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, 1) AL(newqp, (size_t)B)
   s.H = 40; s.HC = 24;
   AL(hkey, (size_t)B * s.NB * s.H * d) AL(hval, (size_t)B * s.NB * s.H * s.RM) AL(ckey, (size_t)B * s.NB * s.HC * d)
   AL(cJ, (size_t)B * s.NB * s.HC * s.RM * d) AL(cb, (size_t)B * s.NB * s.HC * s.RM) AL(hn, (size_t)B * s.NB)
@@ -976,14 +988,19 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     SCO_HIP(hipMemsetAsync(q1.y, 0, (size_t)q1.batch * q1.m * sizeof(double), h->stream));
     h->qp1->solved_once = true;
   }
-  const int round_cap = p.max_qp_solves + 8;
+  // time slicing (scheduling only): every launch advances each active QP by at most `slice` ADMM iterations; a
+  // problem whose QP ended goes through post / pre / setup and joins the next launch with its next QP
+  const int slice_req = params->admm_slice < 0 ? 0 : (params->admm_slice > 0 ? params->admm_slice : 6250);
+  SCO_HIP(hipMemsetAsync(h->qp1->d.prog, 0, (size_t)s.batch * sizeof(int), h->stream));
+  const long long slices_per_qp = slice_req > 0 ? (qsl.max_iter + slice_req - 1) / slice_req : 1;
+  const long long round_cap = ((long long)p.max_qp_solves + 8) * slices_per_qp;
   while (n_active > 0 && h->rounds < round_cap) {
     SCO_HIP(hipMemsetAsync(s.n_active, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(sqp_pre_kernel, grid, block, 0, h->stream, s, h->qp1->d, p);
     SCO_HIP(hipGetLastError());
     mark(0);
     mid = next_event(h, ec); stage.push_back(1);
-    rc = sco_qp_launch(h->qp1, &qsl, s.active, mid);
+    rc = sco_qp_launch_sliced(h->qp1, &qsl, s.newqp, s.active, slice_req, mid, nullptr);
     if (rc) return rc;
     mark(2);
     hipLaunchKernelGGL(sqp_post_kernel, grid, block, 0, h->stream, s, h->qp1->d, p);

@@ -52,7 +52,7 @@ def test_default_settings_are_the_reference_values():
 def test_struct_layouts_match_the_c_side():
     # sizes the C compiler gives the same declarations
     assert ctypes.sizeof(_lib.QpSettings) == 7 * 8 + 4 * 4
-    assert ctypes.sizeof(_lib.SqpParams) == 9 * 8 + 6 * 4
+    assert ctypes.sizeof(_lib.SqpParams) == 9 * 8 + 7 * 4 + 4        # 7 ints, padded to the 8-byte alignment
     assert ctypes.sizeof(_lib.TrajoptDesc) == 8 * 4
 
 

@@ -419,3 +419,21 @@ def test_diagnostic_flags(gpu):
     capped = (res.flags & 2) != 0
     assert capped.any() and np.all(res.qp_solves[capped] == 3) and not np.any(res.success[capped])
     assert np.all(res.qp_solves[~capped] <= 3)
+
+
+def test_time_slicing_changes_the_schedule_not_the_results(gpu):
+    """sco_sqp_params.admm_slice: parked and resumed ADMM solves continue bit-exactly, so any slice length
+    gives the same trajectories, decisions and iteration counts as one launch per QP."""
+    arrays, _ = af.make_batch(48)
+    outs = []
+    with sb.TrajOptBatch(48, 7, 20, 5, 2) as tb:
+        tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                arrays["point_frac"], arrays["obstacles"])
+        for sl in (-1, 0, 1000, 30, 77777):
+            tb.solve(_lib.default_sqp_params(admm_slice=sl))
+            r = tb.fetch(); r.trace = tb.trace()
+            outs.append(r)
+    for r in outs[1:]:
+        assert np.array_equal(r.x, outs[0].x) and np.array_equal(r.admm_iters, outs[0].admm_iters)
+        assert np.array_equal(r.success, outs[0].success) and np.array_equal(r.qp_solves, outs[0].qp_solves)
+        assert all(np.array_equal(a, b) for a, b in zip(r.trace, outs[0].trace))
