@@ -185,8 +185,8 @@ def main():
         it_pen = sum(int(t[1:, 7].sum()) for t in traces)
         admm_bytes += it_proj * algorithmic_bytes_per_iter(n0, m0) + it_pen * algorithmic_bytes_per_iter(n, m)
         admm_ms += tm["admm_ms"]
-        admm_launches += max(len(t) for t in traces)
-        qp_launches += max(len(t) for t in traces) - 1        # penalty-QP launches (the projection launch is tiny)
+        admm_launches += tm["rounds"]
+        qp_launches += tm["rounds"] - 1                       # penalty-QP launches (the projection launch is tiny)
         admm_iters_total += it_proj + it_pen
         qp_solves_total += int(res.qp_solves.sum())
     sync()
@@ -204,7 +204,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath) and B == 1024 and not args.intended and not big:
             with open(tpath) as fh:
-                traffic = json.load(fh)["hbm_bytes_per_launch"]
+                tj = json.load(fh)
+            # PMC figure of one whole step (all penalty-QP launches), spread over this run's launches
+            per_step = tj.get("hbm_bytes_per_step")
+            traffic = per_step * args.steps / max(qp_launches, 1) if per_step else None
         tpath_big = os.path.join(ROOT, "profiles", "r01_traffic_12x50.json")
         if big and os.path.exists(tpath_big) and not args.intended:
             with open(tpath_big) as fh:      # measured per problem-iteration at B = 64; scaled to this run's launches
@@ -229,7 +232,8 @@ def main():
                     "admm_iters_per_s": admm_iters_total * world / elapsed,
                     "stage_ms_per_step": dict(zip(["convexify", "qp_setup", "admm", "decide", "total"],
                                                   (stage_ms / args.steps).round(3).tolist())),
-                    "success_fraction": float(np.mean(allrec["success"] != 0))},
+                    "success_fraction": float(np.mean(allrec["success"] != 0)),
+                    "admm_launches_per_step": qp_launches / args.steps},
             "roofline": {"bound": "hbm", "kernel": "qp_admm_bt_kernel" if big else "qp_admm_rl_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
                          "traffic": traffic, "algorithmic_bytes_per_launch": admm_bytes / max(qp_launches, 1),

@@ -247,6 +247,9 @@ int sco_sqp_fetch(sco_sqp *h, double *x, int *success, int *sqp_iters, int *qp_s
 #define SCO_SQP_FLAG_CAPPED 2      /* max_sqp_iters stopped the problem (the reference's loops are unbounded)   */
 #define SCO_SQP_FLAG_TRACE_FULL 4  /* more decisions than sco_sqp_trace keeps (64)                              */
 int sco_sqp_fetch_flags(sco_sqp *h, int *flags);
+/* Number of device rounds (pre -> QP setup -> ADMM launch -> post) of the last solve, the projection round
+ * included; with time slicing one QP spans several rounds. */
+int sco_sqp_last_rounds(const sco_sqp *h, int *rounds);
 
 /* Per-problem decision trace of the last solve, for stage-wise parity checks:
  * trace[batch][cap][8] = {kind, merit, model_merit, new_merit, trust, penalty,

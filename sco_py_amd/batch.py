@@ -148,8 +148,10 @@ class TrajOptBatch(object):
     def last_timing(self):
         ms = np.zeros(5)
         _lib.check(_lib.load().sco_sqp_last_timing(self._h, _lib.dptr(ms)))
+        rounds = C.c_int(0)
+        _lib.check(_lib.load().sco_sqp_last_rounds(self._h, C.byref(rounds)))
         return dict(convexify_ms=float(ms[0]), qp_setup_ms=float(ms[1]), admm_ms=float(ms[2]),
-                    decide_ms=float(ms[3]), total_ms=float(ms[4]))
+                    decide_ms=float(ms[3]), total_ms=float(ms[4]), rounds=int(rounds.value))
 
 
 def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_jac=False, prox_count=2):

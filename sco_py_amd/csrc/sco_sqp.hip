@@ -1069,6 +1069,12 @@ extern "C" int sco_sqp_trace(sco_sqp *h, int cap, double *trace, int *n_entries)
   return SCO_OK;
 }
 
+extern "C" int sco_sqp_last_rounds(const sco_sqp *h, int *rounds) {
+  if (!h || !rounds) return SCO_ERR_ARG;
+  *rounds = h->rounds;
+  return SCO_OK;
+}
+
 extern "C" int sco_sqp_last_timing(const sco_sqp *h, double ms[5]) {
   if (!h || !ms) return SCO_ERR_ARG;
   memcpy(ms, h->last_ms, 5 * sizeof(double));
