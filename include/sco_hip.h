@@ -77,6 +77,15 @@ typedef struct sco_qp_settings {
                                iteration counts change, the solution agrees to the QP tolerances.  Honoured by
                                the row-local tier (the one 7-DOF x 20 runs on) and the structured global-memory
                                tier (12-DOF x 50); the other tiers start cold.  */
+  int adaptive_rho;         /* osqp_utils.py:13  DEFAULT_ADAPTIVE_RHO = False (solver.py:39 lets the caller turn it on).
+                               1: OSQP's rho update -- every adaptive_rho_interval iterations, after the termination
+                               test, rho <- rho sqrt(normalised primal / normalised dual residual) clipped to
+                               [1e-6, 1e6], taken when it leaves [rho / tol, rho tol]; the reduced system is then
+                               refactored and the solve resumes from its iterates.  Runs on the on-chip tiers (the
+                               solve is parked and resumed around every update); the global-memory tier answers
+                               SCO_ERR_CAPACITY.  Not part of parity mode.  */
+  int adaptive_rho_interval;/* 0 = 4 x check_termination (OSQP's value when it does not time itself: 100)         */
+  double adaptive_rho_tolerance; /* OSQP default 5                                                                  */
 } sco_qp_settings;
 
 void sco_qp_default_settings(sco_qp_settings *s);

@@ -22,6 +22,19 @@
  *     [1e-4, 1e4], cold start x = z = y = 0 (the reference
  *     rebuilds the OSQP object for every QP so warm_start is inert).
  *
+ * adaptive_rho (solver.py:39 / osqp_utils.py:13, default False in the reference):
+ * OSQP's update as recalled from osqp 0.6 (auxil.c compute_rho_estimate /
+ * adapt_rho): every `adaptive_rho_interval` iterations, after the termination
+ * test, with the SCALED iterates
+ *     rho_new = rho * sqrt( (|Ax - z| / (max(|z|, |Ax|) + 1e-10))
+ *                         / (|Px + q + A'y| / (max(|q|, |A'y|, |Px|) + 1e-10) + 1e-10) )
+ * clipped to [1e-6, 1e6]; taken (rho vector rebuilt, KKT refactored) when it
+ * leaves [rho / tol, rho * tol], tol = adaptive_rho_tolerance = 5.  OSQP's
+ * default interval is chosen from wall-clock time (profiling builds) and is
+ * therefore not reproducible; interval 0 here means the value of its
+ * non-profiling build, 4 x check_termination = 100.  Parity unpinned like the
+ * rest of the iterate sequence.
+ *
  * PARITY STATUS: "parity unpinned" at the iterate level -- OSQP's iterate
  * sequence, iteration counts and sub-tolerance digits cannot be checked here
  * (library absent).  The SOLUTION is pinned by the reference's own analytic
@@ -53,6 +66,7 @@
 #define MIN_SCALING 1e-4
 #define MAX_SCALING 1e4
 #define RHO_MIN 1e-6
+#define RHO_MAX 1e6
 #define RHO_TOL 1e-4
 #define RHO_EQ_OVER_RHO_INEQ 1e3
 
@@ -61,12 +75,17 @@ typedef struct {
   int max_iter, check_termination, scaling;
   int expand_dups; /* 1: replicate weighted rows physically, 0: fold weights */
   int linsys;      /* 0: sparse KKT LDL' (OSQP default), 1: dense reduced Cholesky */
+  int adaptive_rho;           /* 0 (reference default) | 1 */
+  int adaptive_rho_interval;  /* 0: 4 x check_termination (100 when that is 0) */
+  double adaptive_rho_tolerance;
 } osqp_ref_settings;
 
 typedef struct {
   int status;      /* OSQP status_val: 1, 2, -2, -3, 3, -4, 4 */
   int iters;
   double obj, pri_res, dua_res;
+  double rho;      /* the last rho in use */
+  int rho_updates;
 } osqp_ref_info;
 
 void osqp_ref_default_settings(osqp_ref_settings *s) {
@@ -75,6 +94,7 @@ void osqp_ref_default_settings(osqp_ref_settings *s) {
   s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
   s->max_iter = 100000; s->check_termination = 25; s->scaling = 10;
   s->expand_dups = 1; s->linsys = 0;
+  s->adaptive_rho = 0; s->adaptive_rho_interval = 0; s->adaptive_rho_tolerance = 5.0;
 }
 
 static double dmax(double a, double b) { return a > b ? a : b; }
@@ -573,6 +593,18 @@ static int check_termination(admm_t *a, int approximate) {
   return 0;
 }
 
+/* OSQP's rho estimate from the scaled iterates (update_info has filled Ax_, Px_, Aty) */
+static double rho_estimate(admm_t *a, double rho) {
+  qp_t *W = a->W; int n = W->n, m = W->m;
+  double pri = 0.0, dua = 0.0;
+  for (int i = 0; i < m; i++) pri = dmax(pri, fabs(a->Ax_[i] - a->z[i]));
+  for (int j = 0; j < n; j++) dua = dmax(dua, fabs(W->q[j] + a->Px_[j] + a->Aty[j]));
+  pri /= dmax(norm_inf(a->z, m), norm_inf(a->Ax_, m)) + 1e-10;
+  dua /= dmax(norm_inf(W->q, n), dmax(norm_inf(a->Aty, n), norm_inf(a->Px_, n))) + 1e-10;
+  double est = rho * sqrt(pri / (dua + 1e-10));
+  return dmin(dmax(est, RHO_MIN), RHO_MAX);
+}
+
 /* Optional per-check trace: trace[4*k + {0,1,2,3}] = iter, pri_res, dua_res, obj
  * for the k-th termination check, up to trace_cap entries. */
 int osqp_ref_solve(int n, int m_in,
@@ -653,6 +685,10 @@ int osqp_ref_solve(int n, int m_in,
   else {
     const double alpha = st->alpha, sigma = st->sigma;
     int iter, status = 0, checked = 0;
+    int interval = st->adaptive_rho_interval > 0 ? st->adaptive_rho_interval
+                 : (st->check_termination > 0 ? 4 * st->check_termination : 100);
+    double rho_now = st->rho;
+    info->rho_updates = 0;
     for (iter = 1; iter <= st->max_iter; iter++) {
       { double *t = x; x = xp; xp = t; t = z; z = zp; zp = t; }
       /* ---- x~, z~ ---- */
@@ -683,14 +719,27 @@ int osqp_ref_solve(int n, int m_in,
         y[i] += a.dy[i];
       }
       checked = st->check_termination && (iter % st->check_termination == 0);
-      if (!checked) continue;
+      const int adapt = st->adaptive_rho && (iter % interval == 0) && iter < st->max_iter;
+      if (!checked && !adapt) continue;
       a.x = x; a.z = z;
       update_info(&a);
-      if (trace && trace_len && *trace_len < trace_cap) {
-        int k = *trace_len; trace[4 * k] = iter; trace[4 * k + 1] = a.pri; trace[4 * k + 2] = a.dua; trace[4 * k + 3] = a.obj; (*trace_len)++;
+      if (checked) {
+        if (trace && trace_len && *trace_len < trace_cap) {
+          int k = *trace_len; trace[4 * k] = iter; trace[4 * k + 1] = a.pri; trace[4 * k + 2] = a.dua; trace[4 * k + 3] = a.obj; (*trace_len)++;
+        }
+        status = check_termination(&a, 0);
+        if (status) break;
       }
-      status = check_termination(&a, 0);
-      if (status) break;
+      if (adapt) {
+        const double est = rho_estimate(&a, rho_now), tol = st->adaptive_rho_tolerance;
+        if (est > rho_now * tol || est < rho_now / tol) {
+          rho_now = est; info->rho_updates++;
+          set_rho_vec(&W, rho_now);
+          if (F) { ldl_free(F); F = kkt_factor(&W, st->sigma); }
+          else { free(C->L); free(C); C = reduced_factor(&W, st->sigma); }
+          if (!F && !C) { rc = -1; status = -7; break; }
+        }
+      }
     }
     if (!status) {
       iter = st->max_iter;
@@ -699,7 +748,7 @@ int osqp_ref_solve(int n, int m_in,
       if (!status) status = check_termination(&a, 1);
       if (!status) status = -2;
     }
-    info->status = status; info->iters = iter;
+    info->status = status; info->iters = iter; info->rho = rho_now;
     info->pri_res = a.pri; info->dua_res = a.dua; info->obj = a.obj;
     /* unscale solution */
     for (int j = 0; j < n; j++) x_out[j] = W.D[j] * x[j];

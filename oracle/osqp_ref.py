@@ -28,12 +28,13 @@ class Settings(C.Structure):
         ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
         ("max_iter", C.c_int), ("check_termination", C.c_int), ("scaling", C.c_int),
         ("expand_dups", C.c_int), ("linsys", C.c_int),
+        ("adaptive_rho", C.c_int), ("adaptive_rho_interval", C.c_int), ("adaptive_rho_tolerance", C.c_double),
     ]
 
 
 class Info(C.Structure):
     _fields_ = [("status", C.c_int), ("iters", C.c_int), ("obj", C.c_double),
-                ("pri_res", C.c_double), ("dua_res", C.c_double)]
+                ("pri_res", C.c_double), ("dua_res", C.c_double), ("rho", C.c_double), ("rho_updates", C.c_int)]
 
 
 def build(force=False):
@@ -112,7 +113,8 @@ def solve(P, q, A, l, u, w=None, trace_cap=0, **settings):
     res.x = x[:n].copy()
     res.y = y[:m].copy()
     res.info = SimpleNamespace(status_val=info.status, iter=info.iters, obj_val=info.obj,
-                               pri_res=info.pri_res, dua_res=info.dua_res)
+                               pri_res=info.pri_res, dua_res=info.dua_res, rho_estimate=info.rho,
+                               rho_updates=info.rho_updates)
     res.trace = trace[: tl.value].copy()
     return res
 

@@ -28,7 +28,8 @@ class QpSettings(C.Structure):
         ("eps_abs", C.c_double), ("eps_rel", C.c_double),
         ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
         ("max_iter", C.c_int), ("check_termination", C.c_int), ("scaling", C.c_int),
-        ("warm_start", C.c_int),
+        ("warm_start", C.c_int), ("adaptive_rho", C.c_int), ("adaptive_rho_interval", C.c_int),
+        ("adaptive_rho_tolerance", C.c_double),
     ]
 
 

@@ -207,6 +207,8 @@ struct RlArgs {
   // its iteration count in prog[b] and its scaled state in the s* arrays, and the next launch resumes it
   // bit-exactly (nothing is recomputed)
   int slice;
+  const int *rflag;  // adaptive rho: rflag[b] != 0 = rho changed while the solve was parked (setup has refactored):
+                     // the cached right-hand sides t', g_e are rebuilt from x, z, y
   int *prog;
   double *sx, *sz, *sy, *st, *sg;
   double *stamp;     // diagnostic build only (SCO_STAMP), else unused
@@ -399,6 +401,16 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         r_z[q] = a.sz[(size_t)b * m + r_i[q]]; r_y[q] = a.sy[(size_t)b * m + r_i[q]];
         s_tv[r_i[q]] = a.st[(size_t)b * m + r_i[q]];
       }
+    if (a.rflag && a.rflag[b]) {
+      double tq[2] = {0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (r_i[q] >= 0) tq[q] = r_w[q] * (r_rho[q] * r_z[q] - r_y[q]);
+      if (eown >= 0) ge = ((sigma * xe - qe) + r_ae[0] * tq[0] + r_ae[1] * tq[1]) * kinv;
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (r_i[q] >= 0) s_tv[r_i[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
+    }
   } else if (a.warm) {
     // OSQP-style warm start from the previous solution of this handle (x, y unscaled in a.x / a.y):
     //   x_s = x / D,  y_s = c y / (E w),  z = A_s x_s;  then t, g_e, t' as after any iteration
@@ -753,7 +765,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
   ra.warm = a.warm;
-  ra.slice = a.slice; ra.prog = d.prog; ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.st = d.st; ra.sg = d.sg;
+  ra.slice = a.slice; ra.rflag = a.adaptive ? d.rflag : nullptr; ra.prog = d.prog; ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.st = d.st; ra.sg = d.sg;
   ra.stamp = nullptr;
 #ifdef SCO_STAMP
   {

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,10 @@ struct QpDev {
   // parked solves of the row-local tier (time slicing): iterations done, scaled x / z / y / t' / g_e
   int *prog;
   double *sx, *sz, *sy, *st, *sg;
+  // adaptive rho (opt-in): rho in use per problem, "rho changed: re-derive the cached right-hand sides on
+  // resume" flag, "run setup" mask, number of updates
+  double *rho_b;
+  int *rflag, *smask, *nupd, *amask;   // amask: problems still parked (sco_qp_solve's own loop)
 };
 
 // ---- fast ADMM path (sco_admm_fast.hip) ------------------------------------
@@ -68,7 +73,8 @@ struct AdmmArgs {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   int max_iter, check;
   int warm;     // start from the previous solution in d.x / d.y (row-local tier only)
-  int slice;    // > 0: at most this many ADMM iterations per launch (row-local tier only), see RlArgs
+  int slice;    // > 0: at most this many ADMM iterations per launch (row-local and generic kernels), see RlArgs
+  int adaptive; // the handle's rflag array is live (adaptive rho)
 };
 
 bool fast_plan_build(const QpPlan &pl, FastHost &fh);
@@ -168,5 +174,10 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
 // a new QP), ADMM for the ones in `active_dev` for at most `slice` iterations (0 = to the end); a problem whose
 // solve is not finished keeps status 0 and is resumed by the next call.  Returns the slice actually used
 // through *sliced (0 if the handle's tier cannot park a solve).
+// With st->adaptive_rho the slice is the rho-update interval and `setup_mask` names the problems that START a
+// QP (device array, or SCO_MASK_ALL / SCO_MASK_NONE); setup then also runs for parked problems whose rho changed.
+#define SCO_MASK_ALL ((const int *)(uintptr_t)1)
+#define SCO_MASK_NONE ((const int *)(uintptr_t)2)
 int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
                          int slice, hipEvent_t mid, int *sliced);
+int sco_qp_adaptive_interval(const sco_qp_settings *st);

@@ -51,6 +51,7 @@ extern "C" void sco_qp_default_settings(sco_qp_settings *s) {
   s->eps_abs = 1e-6; s->eps_rel = 1e-9;
   s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
   s->max_iter = 100000; s->check_termination = 25; s->scaling = 10; s->warm_start = 0;
+  s->adaptive_rho = 0; s->adaptive_rho_interval = 0; s->adaptive_rho_tolerance = 5.0;
 }
 
 // --------------------------------------------------------------------------
@@ -108,12 +109,14 @@ struct SetupArgs {
   const int *Pp, *Pi;
   double rho, sigma;
   int scaling;
+  int per_problem_rho;      // adaptive rho: the problem's current rho is d.rho_b[b]
 };
 
 __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
   const QpDev &d = a.d;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (d.active && !d.active[b]) return;
+  const double rho0 = a.per_problem_rho ? d.rho_b[b] : a.rho;
   const int n = d.n, m = d.m, nnzP = d.nnzP, nnzA = d.nnzA, n_e = d.n_e, n_c = d.n_c, ncpl = d.ncpl;
 
   extern __shared__ double lds[];
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
       ls[i] = li; us[i] = ui;
       double r;
       if (li < -SCO_INFTY * SCO_MIN_SCALING && ui > SCO_INFTY * SCO_MIN_SCALING) r = SCO_RHO_MIN;
-      else if (ui - li < SCO_RHO_TOL) r = SCO_RHO_EQ_OVER_RHO_INEQ * a.rho;
-      else r = a.rho;
+      else if (ui - li < SCO_RHO_TOL) r = SCO_RHO_EQ_OVER_RHO_INEQ * rho0;
+      else r = rho0;
       rho[i] = r;
       Et[i] = r * (double)w[i];
     }
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (d.active && !d.active[b]) return;
   const int n = d.n, m = d.m, nnzA = d.nnzA, n_e = d.n_e, n_c = d.n_c, ncpl = d.ncpl;
+  const int it0 = a.slice > 0 ? d.prog[b] : 0;
 
   extern __shared__ double lds[];
   AdmmLds s;
@@ -436,11 +440,16 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
   {
     const double *gAs = d.As + (size_t)b * nnzA;
     for (int t = tid; t < nnzA; t += SCO_BLOCK) s.As[t] = gAs[t];
-    for (int j = tid; j < n; j += SCO_BLOCK) { s.qs[j] = d.qs[(size_t)b * n + j]; s.x[j] = 0.0; s.sdx[j] = 0.0; }
+    // a parked solve (time slicing / adaptive rho) comes back from its scaled x, z, y; t = w (rho z - y) is
+    // rebuilt with the rho in force now
+    for (int j = tid; j < n; j += SCO_BLOCK) {
+      s.qs[j] = d.qs[(size_t)b * n + j]; s.x[j] = it0 > 0 ? d.sx[(size_t)b * n + j] : 0.0; s.sdx[j] = 0.0;
+    }
     for (int i = tid; i < m; i += SCO_BLOCK) {
       s.ls[i] = d.ls[(size_t)b * m + i]; s.us[i] = d.us[(size_t)b * m + i];
       s.rho[i] = d.rho[(size_t)b * m + i]; s.w[i] = d.w[(size_t)b * m + i];
-      s.z[i] = 0.0; s.y[i] = 0.0; s.t[i] = 0.0; s.sdy[i] = 0.0;
+      const double z0 = it0 > 0 ? d.sz[(size_t)b * m + i] : 0.0, y0 = it0 > 0 ? d.sy[(size_t)b * m + i] : 0.0;
+      s.z[i] = z0; s.y[i] = y0; s.t[i] = (double)s.w[i] * (s.rho[i] * z0 - y0); s.sdy[i] = 0.0;
     }
     for (int e = tid; e < n_e; e += SCO_BLOCK) s.kinv[e] = d.kee_inv[(size_t)b * n_e + e];
     for (int k = tid; k < ncpl; k += SCO_BLOCK) s.cpl[k] = d.cpl[(size_t)b * ncpl + k];
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
 
   int status = 0, iter = 0;
   double pri = 0.0, dua = 0.0;
-  for (iter = 1; iter <= a.max_iter; iter++) {
+  for (iter = it0 + 1; iter <= a.max_iter; iter++) {
     const bool chk = (a.check > 0 && iter % a.check == 0) || iter == a.max_iter;
     // (1) right-hand side  sigma x - q + A' t,  t = w (rho z - y); eliminated part scaled by K_ee^-1
     for (int j = tid; j < n; j += SCO_BLOCK) {
@@ -515,7 +524,15 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
       status = admm_check(a, s, b, 0, cscale, &pri, &dua);
       if (status) break;
     }
+    if (a.slice > 0 && iter == it0 + a.slice && iter < a.max_iter) {
+      // the slice is used up (it ends on a termination check): park the solve
+      for (int j = tid; j < n; j += SCO_BLOCK) d.sx[(size_t)b * n + j] = s.x[j];
+      for (int i = tid; i < m; i += SCO_BLOCK) { d.sz[(size_t)b * m + i] = s.z[i]; d.sy[(size_t)b * m + i] = s.y[i]; }
+      if (tid == 0) { d.prog[b] = iter; d.status[b] = 0; d.iters[b] = iter; }
+      return;
+    }
   }
+  if (a.slice > 0 && tid == 0) d.prog[b] = 0;
   if (!status) {
     iter = a.max_iter;
     status = admm_check(a, s, b, 1, cscale, &pri, &dua);
@@ -531,6 +548,69 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
       d.status[b] = status; d.iters[b] = iter;
       d.resid[2 * (size_t)b] = pri; d.resid[2 * (size_t)b + 1] = dua;
     }
+  }
+}
+
+// --------------------------------------------------------------------------
+// adaptive rho (opt-in): OSQP's estimate from the SCALED iterates of a parked solve
+//   rho <- rho sqrt( (|Ax - z| / (max(|z|, |Ax|) + 1e-10)) / (|Px + q + A'y| / (max(|q|, |A'y|, |Px|) + 1e-10) + 1e-10) )
+// clipped to [1e-6, 1e6]; taken when it leaves [rho / tol, rho tol] (osqp 0.6 auxil.c compute_rho_estimate /
+// adapt_rho, as recalled: the library is not available here, see oracle/osqp_ref.c).  One workgroup per problem;
+// fixed summation order, so the result does not depend on scheduling.
+// mode 0: problems flagged in `newqp` start a QP (rho = rho0); 1: every problem does; 2: none does.
+// --------------------------------------------------------------------------
+struct RhoArgs {
+  QpDev d;
+  const int *newqp;
+  int mode, interval;
+  double rho0, tol;
+};
+
+__global__ __launch_bounds__(SCO_BLOCK) void qp_rho_update_kernel(RhoArgs a) {
+  const QpDev &d = a.d;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (d.active && !d.active[b]) {
+    if (tid == 0) { d.smask[b] = 0; d.rflag[b] = 0; }
+    return;
+  }
+  const bool fresh = a.mode == 1 || (a.mode == 0 && a.newqp[b]);
+  if (fresh) {
+    if (tid == 0) { d.rho_b[b] = a.rho0; d.smask[b] = 1; d.rflag[b] = 0; d.nupd[b] = 0; }
+    return;
+  }
+  const int it = d.prog[b];
+  if (it <= 0 || it % a.interval != 0) {
+    if (tid == 0) { d.smask[b] = 0; d.rflag[b] = 0; }
+    return;
+  }
+  __shared__ double red[NWAVE * 8];
+  const int n = d.n, m = d.m;
+  const double *x = d.sx + (size_t)b * n, *z = d.sz + (size_t)b * m, *y = d.sy + (size_t)b * m;
+  const double *As = d.As + (size_t)b * d.nnzA, *Ps = d.Ps + (size_t)b * d.nnzP, *qs = d.qs + (size_t)b * n;
+  const int *w = d.w + (size_t)b * m;
+  double v[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < m; i += SCO_BLOCK) {
+    double ax = 0.0;
+    for (int t = d.Rp[i]; t < d.Rp[i + 1]; t++) ax += As[d.Rpos[t]] * x[d.Rj[t]];
+    v[0] = fmax(v[0], fabs(ax - z[i])); v[1] = fmax(v[1], fabs(z[i])); v[2] = fmax(v[2], fabs(ax));
+  }
+  for (int j = tid; j < n; j += SCO_BLOCK) {
+    double px = 0.0, aty = 0.0;
+    for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * x[d.Fi[t]];
+    for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) aty += As[t] * ((double)w[d.Ai[t]] * y[d.Ai[t]]);
+    v[3] = fmax(v[3], fabs(px + qs[j] + aty)); v[4] = fmax(v[4], fabs(qs[j]));
+    v[5] = fmax(v[5], fabs(aty)); v[6] = fmax(v[6], fabs(px));
+  }
+  block_reduce<7, true>(v, red);
+  if (tid == 0) {
+    const double rho = d.rho_b[b];
+    const double pri = v[0] / (fmax(v[1], v[2]) + 1e-10);
+    const double dua = v[3] / (fmax(v[4], fmax(v[5], v[6])) + 1e-10);
+    double est = rho * sqrt(pri / (dua + 1e-10));
+    est = fmin(fmax(est, SCO_RHO_MIN), 1e6);
+    const int changed = (est > rho * a.tol || est < rho / a.tol) ? 1 : 0;
+    if (changed) { d.rho_b[b] = est; d.nupd[b] += 1; }
+    d.smask[b] = changed; d.rflag[b] = changed;
   }
 }
 
@@ -640,6 +720,7 @@ static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const
   AL(cscale, B) AL(rho, B * m) AL(kee_inv, B * pl.n_e) AL(cpl, B * pl.ncpl) AL(W, (qp->use_bt ? 1 : B) * pl.n_c * pl.n_c)
   AL(x, B * n) AL(y, B * m) AL(resid, B * 2) AL(status, B) AL(iters, B)
   AL(prog, B) AL(sx, B * n) AL(sz, B * m) AL(sy, B * m) AL(st, B * m) AL(sg, B * pl.n_e)
+  AL(rho_b, B) AL(rflag, B) AL(smask, B) AL(nupd, B) AL(amask, B)
 #undef AL
   SCO_HIP(hipFuncSetAttribute((const void *)qp_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
@@ -733,17 +814,37 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
   return sco_qp_launch_sliced(qp, st, active_dev, active_dev, 0, mid, nullptr);
 }
 
+int sco_qp_adaptive_interval(const sco_qp_settings *st) {
+  if (st->adaptive_rho_interval > 0) {
+    // park points sit on termination checks
+    if (st->check_termination > 0)
+      return std::max(1, (st->adaptive_rho_interval + st->check_termination / 2) / st->check_termination) * st->check_termination;
+    return st->adaptive_rho_interval;
+  }
+  return st->check_termination > 0 ? 4 * st->check_termination : 100;
+}
+
 int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
                          int slice, hipEvent_t mid, int *sliced) {
-  // only the row-local tier can park a solve; slices end on a termination check
-  if (!qp->use_rl || qp->use_big || st->check_termination <= 0 || slice <= 0) slice = 0;
-  else slice = std::max(1, slice / st->check_termination) * st->check_termination;
+  const bool adaptive = st->adaptive_rho != 0;
+  if (adaptive) {
+    if (qp->use_big) {
+      sco_set_error("adaptive_rho: the global-memory tier cannot park a solve (pattern too large for the on-chip tiers)");
+      return SCO_ERR_CAPACITY;
+    }
+    if (!(st->adaptive_rho_tolerance > 1.0)) { sco_set_error("adaptive_rho_tolerance must be > 1"); return SCO_ERR_ARG; }
+    slice = sco_qp_adaptive_interval(st);       // every launch ends on a rho update
+  } else if ((!qp->use_rl && (qp->use_reg || qp->use_fast)) || qp->use_big || st->check_termination <= 0 || slice <= 0) {
+    slice = 0;                                  // the register / sliced-ELL / global-memory kernels run to the end
+  } else {
+    slice = std::max(1, slice / st->check_termination) * st->check_termination;   // slices end on a termination check
+  }
   if (sliced) *sliced = slice;
   QpDev d = qp->d; d.active = active_dev;
-  QpDev dsetup = qp->d; dsetup.active = setup_mask;
-  SetupArgs sa{dsetup, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling};
+  QpDev dsetup = qp->d; dsetup.active = adaptive ? qp->d.smask : setup_mask;
+  SetupArgs sa{dsetup, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling, adaptive ? 1 : 0};
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
-              st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0, slice};
+              st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0, slice, adaptive ? 1 : 0};
   qp->solved_once = true;
   SCO_HIP(hipEventRecord(qp->ev[0], qp->stream));
   if (qp->use_big) {
@@ -753,6 +854,14 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
     SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
     return SCO_OK;
   }
+  if (adaptive) {
+    // rho of the problems that start a QP / of the parked ones that reached an update point; sets d.smask, d.rflag
+    RhoArgs ra{d, setup_mask, setup_mask == SCO_MASK_ALL ? 1 : (setup_mask == SCO_MASK_NONE ? 2 : 0),
+               slice, st->rho, st->adaptive_rho_tolerance};
+    if (ra.mode) ra.newqp = nullptr;
+    hipLaunchKernelGGL(qp_rho_update_kernel, dim3(d.batch), dim3(SCO_BLOCK), 0, qp->stream, ra);
+    SCO_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(qp_setup_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_setup, qp->stream, sa);
   SCO_HIP(hipGetLastError());
   SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
@@ -760,10 +869,10 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
   if (qp->use_rl) {
     int r_ = rl_launch(aa, qp->rl, qp->rld, qp->stream);
     if (r_) return r_;
-  } else if (qp->use_reg) {
+  } else if (qp->use_reg && !adaptive) {
     int r_ = reg_launch(aa, qp->reg, qp->regd, qp->stream);
     if (r_) return r_;
-  } else if (qp->use_fast) {
+  } else if (qp->use_fast && !adaptive) {
     int r_ = fast_launch(aa, qp->fast, qp->fastd, qp->stream);
     if (r_) return r_;
   } else {
@@ -782,9 +891,41 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
     sco_set_error("sco_qp_solve: bad settings"); return SCO_ERR_ARG;
   }
   SCO_HIP(hipSetDevice(qp->device));
-  int rc = sco_qp_launch(qp, settings, nullptr, nullptr);
-  if (rc) return rc;
   const QpDev &d = qp->d; const size_t B = d.batch;
+  int rc;
+  if (settings->adaptive_rho) {
+    // one launch per rho-update interval; a problem that has not ended stays parked and is resumed by the next one
+    SCO_HIP(hipMemsetAsync(d.prog, 0, B * sizeof(int), qp->stream));
+    std::vector<int> prog(B);
+    const long long cap = (long long)settings->max_iter / sco_qp_adaptive_interval(settings) + 2;
+    float ms_setup = 0, ms_admm = 0;
+    for (long long round = 0; round < cap; round++) {
+      // from the second launch on only the parked problems run (a finished one would start over)
+      rc = sco_qp_launch_sliced(qp, settings, round == 0 ? SCO_MASK_ALL : SCO_MASK_NONE, round == 0 ? nullptr : d.amask,
+                                0, nullptr, nullptr);
+      if (rc) return rc;
+      SCO_HIP(hipMemcpyAsync(prog.data(), d.prog, B * sizeof(int), hipMemcpyDeviceToHost, qp->stream));
+      SCO_HIP(hipStreamSynchronize(qp->stream));
+      float t0 = 0, t1 = 0;
+      SCO_HIP(hipEventElapsedTime(&t0, qp->ev[0], qp->ev[1]));
+      SCO_HIP(hipEventElapsedTime(&t1, qp->ev[1], qp->ev[2]));
+      ms_setup += t0; ms_admm += t1;
+      bool parked = false;
+      for (size_t b = 0; b < B; b++) { prog[b] = prog[b] > 0 ? 1 : 0; parked = parked || prog[b]; }
+      if (!parked) break;
+      SCO_HIP(hipMemcpyAsync(d.amask, prog.data(), B * sizeof(int), hipMemcpyHostToDevice, qp->stream));
+    }
+    if (x) SCO_HIP(hipMemcpyAsync(x, d.x, B * d.n * sizeof(double), hipMemcpyDeviceToHost, qp->stream));
+    if (y && d.m) SCO_HIP(hipMemcpyAsync(y, d.y, B * d.m * sizeof(double), hipMemcpyDeviceToHost, qp->stream));
+    if (status) SCO_HIP(hipMemcpyAsync(status, d.status, B * sizeof(int), hipMemcpyDeviceToHost, qp->stream));
+    if (iters) SCO_HIP(hipMemcpyAsync(iters, d.iters, B * sizeof(int), hipMemcpyDeviceToHost, qp->stream));
+    if (resid) SCO_HIP(hipMemcpyAsync(resid, d.resid, B * 2 * sizeof(double), hipMemcpyDeviceToHost, qp->stream));
+    SCO_HIP(hipStreamSynchronize(qp->stream));
+    qp->last_ms[0] = ms_setup; qp->last_ms[1] = ms_admm;
+    return SCO_OK;
+  }
+  rc = sco_qp_launch(qp, settings, nullptr, nullptr);
+  if (rc) return rc;
   if (x) SCO_HIP(hipMemcpyAsync(x, d.x, B * d.n * sizeof(double), hipMemcpyDeviceToHost, qp->stream));
   if (y && d.m) SCO_HIP(hipMemcpyAsync(y, d.y, B * d.m * sizeof(double), hipMemcpyDeviceToHost, qp->stream));
   if (status) SCO_HIP(hipMemcpyAsync(status, d.status, B * sizeof(int), hipMemcpyDeviceToHost, qp->stream));

@@ -990,7 +990,8 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   }
   // time slicing (scheduling only): every launch advances each active QP by at most `slice` ADMM iterations; a
   // problem whose QP ended goes through post / pre / setup and joins the next launch with its next QP
-  const int slice_req = params->admm_slice < 0 ? 0 : (params->admm_slice > 0 ? params->admm_slice : 6250);
+  int slice_req = params->admm_slice < 0 ? 0 : (params->admm_slice > 0 ? params->admm_slice : 6250);
+  if (qsl.adaptive_rho) slice_req = sco_qp_adaptive_interval(&qsl);     // one launch per rho-update interval
   SCO_HIP(hipMemsetAsync(h->qp1->d.prog, 0, (size_t)s.batch * sizeof(int), h->stream));
   const long long slices_per_qp = slice_req > 0 ? (qsl.max_iter + slice_req - 1) / slice_req : 1;
   const long long round_cap = ((long long)p.max_qp_solves + 8) * slices_per_qp;

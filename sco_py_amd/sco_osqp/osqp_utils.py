@@ -245,12 +245,12 @@ def _cached_handle(B, n, m, P0, A0):
 def _solve_qp_batch(requests):
     """Solve a list of QPs that share ONE sparsity pattern and one settings tuple in a
     single device launch.  Each request is a dict with P, q, A, l, u, w (row weights or
-    None) and settings = (eps_abs, eps_rel, max_iter, rho, sigma).
+    None) and settings = (eps_abs, eps_rel, max_iter, rho, sigma, adaptive_rho).
     Returns a list of (x, status, iters)."""
     r0 = requests[0]
     P0, A0 = r0["P"], r0["A"]
     n, m = A0.shape[1], A0.shape[0]
-    eps_abs, eps_rel, max_iter, rho, sigma = r0["settings"]
+    eps_abs, eps_rel, max_iter, rho, sigma, adaptive_rho = r0["settings"]
     B = len(requests)
     Pv = np.stack([r["P"].data for r in requests]) if P0.nnz else np.zeros((B, 0))
     Av = np.stack([r["A"].data for r in requests]) if A0.nnz else np.zeros((B, 0))
@@ -258,7 +258,7 @@ def _solve_qp_batch(requests):
     if any(r["w"] is not None for r in requests):
         w = np.stack([r["w"] if r["w"] is not None else np.ones(m, dtype=np.int32) for r in requests])
     st = _lib.default_qp_settings(rho=rho, sigma=sigma, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=int(max_iter),
-                                  warm_start=1 if WARM_START else 0)
+                                  warm_start=1 if WARM_START else 0, adaptive_rho=1 if adaptive_rho else 0)
     with _HANDLE_LOCK:
         qp = _cached_handle(B, n, m, P0, A0)
         try:
@@ -272,11 +272,11 @@ def _solve_qp_batch(requests):
     return [(x[b], int(status[b]), int(iters[b])) for b in range(B)]
 
 
-def _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma, w=None):
+def _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma, w=None, adaptive_rho=False):
     """One QP on the GPU through the C ABI.  Inside ``batching.solve_many`` the call is
     parked until every concurrently running solve has reached its next QP, and QPs with
     the same pattern go to the device together.  Returns (x, status, iters)."""
-    req = dict(P=P, q=q, A=A, l=l, u=u, w=w, settings=(eps_abs, eps_rel, max_iter, rho, sigma))
+    req = dict(P=P, q=q, A=A, l=l, u=u, w=w, settings=(eps_abs, eps_rel, max_iter, rho, sigma, 1.0 if adaptive_rho else 0.0))
     from . import batching
     server = batching.current_server()
     if server is not None:
@@ -303,15 +303,13 @@ def optimize(
 
     Returns ``(solve_res, var_to_index_dict)``; callers read ``solve_res.x`` and
     ``solve_res.info.status_val`` (prob.py:197, 202)."""
-    if adaptive_rho:
-        # the reference default is False (osqp_utils.py:13) and OpenTAMP never enables it
-        raise NotImplementedError("adaptive_rho=True is not supported by the MI355X solver")
     uniq_cnts, counts = fold_repeated_constraints(osqp_lin_cnt_exprs)
     P, q, A, l, u, index = assemble_qp(osqp_vars, osqp_quad_objs, osqp_lin_objs, uniq_cnts)
     w = None
     if counts.size and int(counts.max()) > 1:
         w = np.concatenate([counts, np.ones(len(osqp_vars), dtype=np.int32)])     # bound rows appear once
-    x, status, iters = _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma, w=w)
+    x, status, iters = _solve_qp(P, q, A, l, u, eps_abs, eps_rel, max_iter, rho, sigma, w=w,
+                                 adaptive_rho=bool(adaptive_rho))
     solve_res = SimpleNamespace(x=x, info=SimpleNamespace(status_val=status, iter=iters))
     if status == -2 and verbose:
         print("ERROR! OSQP Solver hit max iteration limit. Either reduce your tolerances "

@@ -59,9 +59,10 @@ def oracle_qp_backend(monkeypatch):
     def cpu_batch(requests):
         out = []
         for rq in requests:
-            eps_abs, eps_rel, max_iter, rho, sigma = rq["settings"]
+            eps_abs, eps_rel, max_iter, rho, sigma, adaptive = rq["settings"]
             r = osqp_ref.solve(rq["P"], rq["q"], rq["A"], rq["l"], rq["u"], w=rq["w"], eps_abs=eps_abs,
-                               eps_rel=eps_rel, max_iter=int(max_iter), rho=rho, sigma=sigma)
+                               eps_rel=eps_rel, max_iter=int(max_iter), rho=rho, sigma=sigma,
+                               adaptive_rho=1 if adaptive else 0)
             log.append(dict(P=rq["P"].toarray(), q=rq["q"].copy(), A=rq["A"].toarray(), l=rq["l"].copy(),
                             u=rq["u"].copy(), w=None if rq["w"] is None else rq["w"].copy(), x=r.x.copy(),
                             status=r.info.status_val, iters=r.info.iter))

@@ -40,6 +40,7 @@ def test_default_settings_are_the_reference_values():
     # osqp_utils.py:10-15 of the reference + OSQP 0.6 defaults
     assert (s.rho, s.sigma, s.eps_abs, s.eps_rel, s.max_iter) == (0.1, 5e-10, 1e-6, 1e-9, 100000)
     assert (s.alpha, s.check_termination, s.scaling) == (1.6, 25, 10)
+    assert (s.adaptive_rho, s.adaptive_rho_interval, s.adaptive_rho_tolerance) == (0, 0, 5.0)   # osqp_utils.py:13
     p = _lib.default_sqp_params()
     # solver.py:17-28
     assert (p.improve_ratio_threshold, p.min_trust_region_size, p.min_approx_improve) == (0.25, 1e-4, 1e-8)
@@ -51,7 +52,7 @@ def test_default_settings_are_the_reference_values():
 
 def test_struct_layouts_match_the_c_side():
     # sizes the C compiler gives the same declarations
-    assert ctypes.sizeof(_lib.QpSettings) == 7 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.QpSettings) == 7 * 8 + 6 * 4 + 8
     assert ctypes.sizeof(_lib.SqpParams) == 9 * 8 + 7 * 4 + 4        # 7 ints, padded to the 8-byte alignment
     assert ctypes.sizeof(_lib.TrajoptDesc) == 8 * 4
 

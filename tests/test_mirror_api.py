@@ -421,3 +421,20 @@ def test_warm_start_extension_of_the_seam(gpu):
     assert results[False][0] == results[True][0]
     assert np.abs(results[False][1] - results[True][1]).max() < 1e-3
     assert sum(results[True][2]) <= sum(results[False][2])
+
+
+def test_adaptive_rho_is_passed_down_the_seam(backend):
+    """Solver.solve(..., adaptive_rho=True) (solver.py:39): the flag reaches the QP solve; same optimum."""
+    prob, var, atom = _one_var_prob(0.0)
+    prob.add_obj_expr(M.BoundExpr(M.QuadExpr(np.array([[2.0]]), np.array([[-4.0]]), np.zeros((1, 1))), var))
+    seen = []
+    from sco_py_amd.sco_osqp import osqp_utils
+    real = osqp_utils._solve_qp_batch
+    osqp_utils._solve_qp_batch = lambda reqs: (seen.extend(r["settings"] for r in reqs), real(reqs))[1]
+    try:
+        assert M.Solver().solve(prob, method="penalty_sqp", adaptive_rho=True)
+    finally:
+        osqp_utils._solve_qp_batch = real
+    assert np.allclose(var.get_value(), 2.0, atol=1e-4)
+    # the projection QP runs with the defaults (SURVEY Q7), the penalty QPs with the caller's settings
+    assert [s[5] for s in seen][0] == 0.0 and all(s[5] == 1.0 for s in seen[1:]) and len(seen) > 1

@@ -122,3 +122,35 @@ def test_termination_trace_is_every_25_iterations():
     r = o.solve(P, q, A, l, u, trace_cap=4096)
     assert np.array_equal(r.trace[:, 0], 25 * (1 + np.arange(r.trace.shape[0])))
     assert r.trace[-1, 0] == r.info.iter
+
+
+def test_adaptive_rho_reaches_the_same_answer():
+    """adaptive_rho (solver.py:39 lets a caller turn it on; off by default, osqp_utils.py:13): OSQP's update rule as
+    restated in osqp_ref.c.  Same optimum (KKT check), both linear-system back-ends and both duplicate-row forms
+    agree with each other, and a badly scaled penalty QP needs a fraction of the iterations."""
+    from test_qp_plan import penalty_qp
+    rng = np.random.default_rng(29)
+    P, q, A, l, u = penalty_qp(rng, 20, 7, 10)
+    fixed = o.solve(P, q, A, l, u)
+    ad = o.solve(P, q, A, l, u, adaptive_rho=1)
+    assert fixed.info.status_val == ad.info.status_val == 1
+    assert ad.info.rho_updates >= 1 and ad.info.rho_estimate != 0.1 and fixed.info.rho_updates == 0
+    assert ad.info.iter < 0.5 * fixed.info.iter
+    assert np.abs(ad.x - fixed.x).max() < 1e-4
+    prim, stat, comp = o.kkt_violation(P, q, A, l, u, ad.x, ad.y)
+    assert prim < 5e-6 and stat < 5e-5 and comp < 5e-4
+    red = o.solve(P, q, A, l, u, adaptive_rho=1, linsys=1)
+    assert red.info.iter == ad.info.iter and np.abs(red.x - ad.x).max() < 1e-9
+    w = np.ones(A.shape[0], dtype=int); w[7:207] = 2
+    phys = o.solve(P, q, A, l, u, w=w, expand_dups=1, adaptive_rho=1)
+    fold = o.solve(P, q, A, l, u, w=w, expand_dups=0, adaptive_rho=1)
+    assert phys.info.iter == fold.info.iter and phys.info.rho_updates == fold.info.rho_updates
+    assert np.abs(phys.x - fold.x).max() < 1e-9
+
+
+def test_adaptive_rho_interval_and_tolerance():
+    P, q, A, l, u = _random_qp(1)
+    base = o.solve(P, q, A, l, u, adaptive_rho=1)
+    assert o.solve(P, q, A, l, u, adaptive_rho=1, adaptive_rho_interval=100).info.iter == base.info.iter   # 0 = 4 x 25
+    never = o.solve(P, q, A, l, u, adaptive_rho=1, adaptive_rho_tolerance=1e9)
+    assert never.info.rho_updates == 0 and never.info.iter == o.solve(P, q, A, l, u).info.iter

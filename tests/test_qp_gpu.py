@@ -369,3 +369,52 @@ def test_a_qp_that_needs_the_global_memory_tier_by_itself(gpu):
     prob = _random_qp(rng, 300, 150, 0.02)
     info, x, st, it = _check([prob], resid_tol=TOL)
     assert info["n_core"] > 256 and info["lds_admm"] == 0
+
+
+@pytest.mark.parametrize("tier", ["row-local", "generic", "generic-instead-of-register"])
+def test_adaptive_rho_matches_the_oracle_rule(gpu, monkeypatch, tier):
+    """adaptive_rho=True (solver.py:39 / osqp_utils.py:13; off in the reference's defaults): OSQP's rho update
+    every 4 x check_termination iterations.  The solve is parked at each update point, rho re-estimated from the
+    scaled iterates, the reduced system refactored and the solve resumed -- same statuses and iteration counts as
+    the oracle with the same rule."""
+    if tier != "row-local":
+        monkeypatch.setenv("SCO_QP_NO_RL", "1")
+    if tier == "generic":
+        monkeypatch.setenv("SCO_QP_NO_REG", "1"); monkeypatch.setenv("SCO_QP_NO_FAST", "1")
+    rng = np.random.default_rng(23)
+    probs = [penalty_qp(rng, 6, 3, 4) for _ in range(6)]
+    m = len(probs[0][3])
+    w = np.ones((6, m), dtype=np.int32); w[:, 3:3 + 24] = 2
+    st = _lib.default_qp_settings(adaptive_rho=1)
+    _, x_ad, st_ad, it_ad = _check(probs, w=w, settings=st, adaptive_rho=1, expand_dups=0, resid_tol=1e-7)
+    _, x_fx, st_fx, it_fx = _check(probs, w=w, expand_dups=0)
+    assert not np.array_equal(it_ad, it_fx)                          # some of them did change rho
+    ok = (st_ad == 1) & (st_fx == 1)
+    assert ok.any() and np.abs(x_ad[ok] - x_fx[ok]).max() < 1e-4
+
+
+def test_adaptive_rho_interval_and_tolerance_are_honoured(gpu):
+    rng = np.random.default_rng(29)
+    probs = [penalty_qp(rng, 20, 7, 10) for _ in range(4)]
+    _, _, _, it_fx = _check(probs)
+    for kw in (dict(), dict(adaptive_rho_interval=50), dict(adaptive_rho_interval=250, adaptive_rho_tolerance=2.0)):
+        st = _lib.default_qp_settings(adaptive_rho=1, **kw)
+        _, _, _, it_ad = _check(probs, settings=st, adaptive_rho=1, resid_tol=1e-7, **kw)
+        assert it_ad.sum() < 0.6 * it_fx.sum()                       # 1600 against 3950 with the default interval
+
+
+def test_adaptive_rho_is_refused_on_the_global_memory_tier(gpu, monkeypatch):
+    monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    rng = np.random.default_rng(31)
+    probs = [penalty_qp(rng, 5, 3, 4) for _ in range(2)]
+    n, m, Pp, Pi, Ap, Ai, Pval, q, Aval, l, u = _stack(probs)
+    qp = _lib.BatchedQP(2, n, m, Pp, Pi, Ap, Ai)
+    try:
+        qp.load(Pval, q, Aval, l, u)
+        with pytest.raises(_lib.ScoHipError) as e:
+            qp.solve(_lib.default_qp_settings(adaptive_rho=1))
+        assert e.value.code == -5 and "adaptive_rho" in str(e.value)
+        x, _, st, _, _ = qp.solve()                   # the handle is still usable
+        assert np.all(st == 1)
+    finally:
+        qp.close()

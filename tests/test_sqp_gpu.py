@@ -16,9 +16,10 @@ TOL = 1e-6          # abs, BASELINE.json north_star
 SMALL = dict(d=3, T=6, K=2, O=2)
 
 
-def _compare(res, probs, which, oracle_params=None, analytic=False, memo=True):
+def _compare(res, probs, which, oracle_params=None, analytic=False, memo=True, qp_settings=None):
     for b in which:
-        ref = sr.penalty_sqp(sr.trajopt_flat(probs[b], analytic_jac=analytic), oracle_params, emulate_memo=memo)
+        ref = sr.penalty_sqp(sr.trajopt_flat(probs[b], analytic_jac=analytic), oracle_params, emulate_memo=memo,
+                             qp_settings=qp_settings)
         tr = res.trace[b]
         rt = ref.trace[:64]                       # the device keeps the first 64 decisions of a problem
         assert tr.shape == rt.shape, (b, tr.shape, ref.trace.shape)
@@ -437,3 +438,34 @@ def test_time_slicing_changes_the_schedule_not_the_results(gpu):
         assert np.array_equal(r.x, outs[0].x) and np.array_equal(r.admm_iters, outs[0].admm_iters)
         assert np.array_equal(r.success, outs[0].success) and np.array_equal(r.qp_solves, outs[0].qp_solves)
         assert all(np.array_equal(a, b) for a, b in zip(r.trace, outs[0].trace))
+
+
+def test_adaptive_rho_in_the_device_loop(gpu):
+    """sco_qp_settings.adaptive_rho (solver.py:39; reference default off): the device loop parks every QP at each
+    rho-update point, re-estimates rho, refactors and resumes.  Not parity mode.  Small problems follow the oracle
+    (same rule) decision for decision; on 7-DOF x 20 the ill-conditioned QPs that run to max_iter sit so close to
+    the rho thresholds that the oracle's KKT route (sigma = 5e-10 leaves 1e-7 of noise in its residuals) and the
+    device's reduced system part ways there, so only the well-conditioned part is compared: the projection and
+    the first penalty QP, iteration for iteration."""
+    st = _lib.default_qp_settings(adaptive_rho=1)
+    arrays, probs = af.make_batch(6, **SMALL)
+    res = sb.solve_batch(arrays, qp_settings=st)
+    for b in range(6):
+        ref = sr.penalty_sqp(sr.trajopt_flat(probs[b]), qp_settings=dict(adaptive_rho=1))
+        tr, rt = res.trace[b], ref.trace[:64]
+        assert tr.shape == rt.shape and np.array_equal(tr[:, 0], rt[:, 0]), b          # same decisions
+        assert np.array_equal(tr[:, 6], rt[:, 6]) and np.array_equal(tr[:2, 7], rt[:2, 7]), b
+        assert bool(res.success[b]) == ref.success
+        assert np.abs(res.x[b] - ref.x).max() < 1e-4, (b, np.abs(res.x[b] - ref.x).max())
+        assert abs(res.max_violation[b] - ref.max_violation) < 1e-5
+    assert res.admm_iters.sum() < 0.75 * sb.solve_batch(arrays).admm_iters.sum()
+    arrays, probs = af.make_batch(3)
+    res = sb.solve_batch(arrays, qp_settings=st)
+    for b in range(3):
+        ref = sr.penalty_sqp(sr.trajopt_flat(probs[b]), qp_settings=dict(adaptive_rho=1))
+        assert np.array_equal(res.trace[b][:2, [0, 6, 7]], ref.trace[:2, [0, 6, 7]]), b
+        assert np.abs(res.trace[b][:2, 1:4] - ref.trace[:2, 1:4]).max() < 1e-6 * (1 + np.abs(ref.trace[:2, 1:4]).max())
+    fixed = sb.solve_batch(arrays)
+    assert np.all(res.trace[b][1, 7] < 0.2 * fixed.trace[b][1, 7] for b in range(3))   # first penalty QP: 2275 vs 21625 ...
+    again = sb.solve_batch(arrays, qp_settings=st)
+    assert np.array_equal(again.x, res.x) and np.array_equal(again.admm_iters, res.admm_iters)    # deterministic
