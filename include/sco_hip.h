@@ -131,6 +131,10 @@ int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings,
  * info[2] = LDS bytes of the ADMM kernel, info[3] = nnz of the coupling block. */
 int sco_qp_info(const sco_qp *qp, int info[4]);
 
+/* After a solve with adaptive_rho: the rho each problem ended with (rho[batch]) and how many times it changed
+ * (updates[batch]); either pointer may be NULL.  (OSQP reports the same as info.rho_estimate / info.rho_updates.) */
+int sco_qp_adaptive_info(sco_qp *qp, double *rho, int *updates);
+
 /* Device time of the last sco_qp_solve, split by kernel, in milliseconds,
  * measured with HIP events on the library's own stream:
  * ms[0] = setup (scaling + factor), ms[1] = ADMM loop. */

@@ -72,6 +72,7 @@ ABI = {
     "sco_qp_set_bounds": (C.c_int, [C.c_void_p, _DP, _DP]),
     "sco_qp_solve": (C.c_int, [C.c_void_p, C.POINTER(QpSettings), _DP, _DP, _IP, _IP, _DP]),
     "sco_qp_info": (C.c_int, [C.c_void_p, _IP]),
+    "sco_qp_adaptive_info": (C.c_int, [C.c_void_p, _DP, _IP]),
     "sco_qp_last_timing": (C.c_int, [C.c_void_p, _DP]),
     "sco_sqp_default_params": (None, [C.POINTER(SqpParams)]),
     "sco_sqp_create": (C.c_int, [C.c_int, C.POINTER(TrajoptDesc), C.POINTER(C.c_void_p)]),
@@ -207,6 +208,12 @@ class BatchedQP(object):
         out = np.zeros(4, dtype=np.int32)
         check(load().sco_qp_info(self._h, iptr(out)))
         return dict(n_elim=int(out[0]), n_core=int(out[1]), lds_admm=int(out[2]), ncpl=int(out[3]))
+
+    def adaptive_info(self):
+        """(rho each problem ended with, number of rho updates) of the last adaptive_rho solve."""
+        rho = np.zeros(self.batch); upd = np.zeros(self.batch, dtype=np.int32)
+        check(load().sco_qp_adaptive_info(self._h, dptr(rho), iptr(upd)))
+        return rho, upd
 
     def last_timing(self):
         ms = np.zeros(2)

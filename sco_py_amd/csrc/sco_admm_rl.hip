@@ -207,8 +207,14 @@ struct RlArgs {
   // its iteration count in prog[b] and its scaled state in the s* arrays, and the next launch resumes it
   // bit-exactly (nothing is recomputed)
   int slice;
-  const int *rflag;  // adaptive rho: rflag[b] != 0 = rho changed while the solve was parked (setup has refactored):
-                     // the cached right-hand sides t', g_e are rebuilt from x, z, y
+  // adaptive rho (ADAPT instantiations only): every ad_interval iterations, after the termination test, OSQP's
+  // estimate from the scaled residual norms the test has just formed; when it leaves [rho / tol, rho tol] the solve
+  // parks, leaves the new rho in rho_b[b] and raises smask[b] (setup must refactor) and rflag[b] (the resume
+  // rebuilds the cached right-hand sides t', g_e from x, z, y)
+  int ad_interval;
+  double ad_tol;
+  double *rho_b;
+  int *rflag, *smask, *nupd;
   int *prog;
   double *sx, *sz, *sy, *st, *sg;
   double *stamp;     // diagnostic build only (SCO_STAMP), else unused
@@ -306,7 +312,7 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
-template <int TR, int TC, int CW>
+template <int TR, int TC, int CW, bool ADAPT>
 __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (a.active && !a.active[b]) return;
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         r_z[q] = a.sz[(size_t)b * m + r_i[q]]; r_y[q] = a.sy[(size_t)b * m + r_i[q]];
         s_tv[r_i[q]] = a.st[(size_t)b * m + r_i[q]];
       }
-    if (a.rflag && a.rflag[b]) {
+    if (ADAPT && a.rflag[b]) {
       double tq[2] = {0.0, 0.0};
 #pragma unroll
       for (int q = 0; q < 2; q++)
@@ -440,9 +446,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       if (r_i[q] >= 0) s_tv[r_i[q]] = -(r_w[q] * r_rho[q]) * r_ae[q] * ge;
   }
   __syncthreads();
+  if (ADAPT && tid == 0) { a.rflag[b] = 0; a.smask[b] = 0; }
 
   int status = 0, iter = 0;
   double pri = 0.0, dua = 0.0;
+  double rho_new = 0.0;       // ADAPT: > 0 = park now, this is the rho to continue with
 #ifdef SCO_STAMP
   // diagnostic build only: cycles per phase per wavefront (never compiled into the product)
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   };
   iter = it0;
   const int stop = (a.slice > 0 && it0 + a.slice < a.max_iter) ? it0 + a.slice : a.max_iter;
-  while (!status && iter < stop) {
+  while (!status && iter < stop && !(ADAPT && rho_new > 0.0)) {
     int next = stop;
     if (a.check > 0) { next = (iter / a.check + 1) * a.check; if (next > stop) next = stop; }
     // four iterations per trip: a loop trip costs several hundred cycles of refetch (profiles/r01_v6_stamps.txt)
@@ -535,6 +543,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     iter++; step(true);
     {
       // ---- termination test (formulas of admm_check in sco_qp.hip) ---------------------
+      const bool adapt_pt = ADAPT && iter % a.ad_interval == 0 && iter < a.max_iter;
+      double vs[7] = {0, 0, 0, 0, 0, 0, 0};       // ADAPT: the same norms of the SCALED iterates
       for (int approximate = 0; approximate < 2 && !status; approximate++) {
         if (approximate && iter < a.max_iter) break;
         const double *Ps = a.Ps + (size_t)b * a.nnzP;
@@ -554,6 +564,9 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               v[0] = fmax(v[0], fabs(ei * (ax - r_z[q])));
               v[1] = fmax(v[1], fabs(ei * r_z[q]));
               v[2] = fmax(v[2], fabs(ei * ax));
+              if (ADAPT && adapt_pt) {
+                vs[0] = fmax(vs[0], fabs(ax - r_z[q])); vs[1] = fmax(vs[1], fabs(r_z[q])); vs[2] = fmax(vs[2], fabs(ax));
+              }
             }
         }
         const double aty_c = rl_dot_col<CW>(wcol, vcol, co, swy);     // whole wave: the trip count is wave-uniform
@@ -563,6 +576,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           for (int t = a.pc_ptr[cown]; t < a.pc_ptr[cown + 1]; t++) px += Ps[a.pc_pos[t]] * sxc[a.pc_core[t]];
           const double dj = 1.0 / Dg[cvar];
           v[3] = fabs(dj * (qc + px + aty)); v[4] = fabs(dj * qc); v[5] = fabs(dj * aty); v[6] = fabs(dj * px);
+          if (ADAPT && adapt_pt) { vs[3] = fabs(qc + px + aty); vs[4] = fabs(qc); vs[5] = fabs(aty); vs[6] = fabs(px); }
         }
         if (eown >= 0) {
           const int pd = a.role[(size_t)12 * LT + tid];
@@ -571,6 +585,10 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           const double dj = 1.0 / Dg[evar];
           v[3] = fmax(v[3], fabs(dj * (qe + px + aty))); v[4] = fmax(v[4], fabs(dj * qe));
           v[5] = fmax(v[5], fabs(dj * aty)); v[6] = fmax(v[6], fabs(dj * px));
+          if (ADAPT && adapt_pt) {
+            vs[3] = fmax(vs[3], fabs(qe + px + aty)); vs[4] = fmax(vs[4], fabs(qe));
+            vs[5] = fmax(vs[5], fabs(aty)); vs[6] = fmax(vs[6], fabs(px));
+          }
         }
         lblock_reduce<7, true>(v, s_red);
         pri = v[0]; dua = cinv * v[3];
@@ -661,10 +679,20 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         }
       }
       __syncthreads();
+      if (ADAPT && adapt_pt && !status) {
+        // OSQP's rho estimate (compute_rho_estimate / adapt_rho of osqp 0.6, as recalled; oracle/osqp_ref.c)
+        lblock_reduce<7, true>(vs, s_red);
+        const double rho = a.rho_b[b];
+        const double pn = vs[0] / (fmax(vs[1], vs[2]) + 1e-10);
+        const double dn = vs[3] / (fmax(vs[4], fmax(vs[5], vs[6])) + 1e-10);
+        const double est = fmin(fmax(rho * sqrt(pn / (dn + 1e-10)), SCO_RHO_MIN), 1e6);
+        if (est > rho * a.ad_tol || est < rho / a.ad_tol) rho_new = est;
+      }
     }
   }
   if (!status && iter < a.max_iter) {
-    // the slice is used up: park the solve
+    // the slice is used up (or rho changes): park the solve
+    if (ADAPT && rho_new > 0.0 && tid == 0) { a.rho_b[b] = rho_new; a.rflag[b] = 1; a.smask[b] = 1; a.nupd[b] += 1; }
     if (cown >= 0) a.sx[(size_t)b * n + cvar] = xcv;
     if (eown >= 0) { a.sx[(size_t)b * n + evar] = xe; a.sg[(size_t)b * n_e + eown] = ge; }
 #pragma unroll
@@ -734,21 +762,26 @@ int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd) {
   return SCO_OK;
 }
 
-template <int TR, int TC, int CW = LCW>
-static int rl_launch_one(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
+template <int TR, int TC, int CW, bool ADAPT>
+static int rl_launch_k(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
   // hipFuncSetAttribute applies to the current device only
   static bool attr_done[64] = {};
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
   dev_ &= 63;
   if (!attr_done[dev_]) {
-    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC, CW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC, CW, ADAPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 108 * 1024));
     attr_done[dev_] = true;
   }
-  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC, CW>), dim3(batch), dim3(LT), lds, st, ra);
+  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC, CW, ADAPT>), dim3(batch), dim3(LT), lds, st, ra);
   SCO_HIP(hipGetLastError());
   return SCO_OK;
+}
+template <int TR, int TC, int CW = LCW>
+static int rl_launch_one(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
+  // the adaptive-rho variant is a separate instantiation: the default kernel's code is untouched by it
+  return ra.ad_interval > 0 ? rl_launch_k<TR, TC, CW, true>(ra, batch, lds, st) : rl_launch_k<TR, TC, CW, false>(ra, batch, lds, st);
 }
 
 int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t st) {
@@ -765,7 +798,9 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
   ra.warm = a.warm;
-  ra.slice = a.slice; ra.rflag = a.adaptive ? d.rflag : nullptr; ra.prog = d.prog; ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.st = d.st; ra.sg = d.sg;
+  ra.slice = a.slice; ra.prog = d.prog;
+  ra.ad_interval = a.adaptive ? a.ad_interval : 0; ra.ad_tol = a.ad_tol;
+  ra.rho_b = d.rho_b; ra.rflag = d.rflag; ra.smask = d.smask; ra.nupd = d.nupd; ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.st = d.st; ra.sg = d.sg;
   ra.stamp = nullptr;
 #ifdef SCO_STAMP
   {

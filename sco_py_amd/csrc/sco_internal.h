@@ -74,7 +74,10 @@ struct AdmmArgs {
   int max_iter, check;
   int warm;     // start from the previous solution in d.x / d.y (row-local tier only)
   int slice;    // > 0: at most this many ADMM iterations per launch (row-local and generic kernels), see RlArgs
-  int adaptive; // the handle's rflag array is live (adaptive rho)
+  int adaptive; // adaptive rho: every ad_interval iterations the kernel estimates rho; when it must change the solve
+                // parks with the new rho in d.rho_b[b] and d.smask[b] = d.rflag[b] = 1
+  int ad_interval;
+  double ad_tol;
 };
 
 bool fast_plan_build(const QpPlan &pl, FastHost &fh);

@@ -421,6 +421,33 @@ __device__ int admm_check(const AdmmArgs &a, const AdmmLds &s, int b, int approx
   return 0;
 }
 
+// OSQP's rho estimate from the SCALED iterates in LDS (osqp 0.6 auxil.c compute_rho_estimate, as recalled; the
+// library is not available here, see oracle/osqp_ref.c):
+//   rho sqrt( (|Ax - z| / (max(|z|, |Ax|) + 1e-10)) / (|Px + q + A'y| / (max(|q|, |A'y|, |Px|) + 1e-10) + 1e-10) )
+// clipped to [1e-6, 1e6].  Fixed summation order: the value does not depend on scheduling.
+__device__ double admm_rho_estimate(const AdmmArgs &a, const AdmmLds &s, int b, double rho) {
+  const QpDev &d = a.d;
+  const int tid = threadIdx.x, n = d.n, m = d.m;
+  const double *Ps = d.Ps + (size_t)b * d.nnzP;
+  double v[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < m; i += SCO_BLOCK) {
+    double ax = 0.0;
+    for (int t = d.Rp[i]; t < d.Rp[i + 1]; t++) ax += s.As[d.Rpos[t]] * s.x[d.Rj[t]];
+    v[0] = fmax(v[0], fabs(ax - s.z[i])); v[1] = fmax(v[1], fabs(s.z[i])); v[2] = fmax(v[2], fabs(ax));
+  }
+  for (int j = tid; j < n; j += SCO_BLOCK) {
+    double px = 0.0, aty = 0.0;
+    for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * s.x[d.Fi[t]];
+    for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) aty += s.As[t] * ((double)s.w[d.Ai[t]] * s.y[d.Ai[t]]);
+    v[3] = fmax(v[3], fabs(px + s.qs[j] + aty)); v[4] = fmax(v[4], fabs(s.qs[j]));
+    v[5] = fmax(v[5], fabs(aty)); v[6] = fmax(v[6], fabs(px));
+  }
+  block_reduce<7, true>(v, s.red);
+  const double pri = v[0] / (fmax(v[1], v[2]) + 1e-10);
+  const double dua = v[3] / (fmax(v[4], fmax(v[5], v[6])) + 1e-10);
+  return fmin(fmax(rho * sqrt(pri / (dua + 1e-10)), SCO_RHO_MIN), 1e6);
+}
+
 __global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
   const QpDev &d = a.d;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -457,6 +484,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
   const double *W = d.W + (size_t)b * n_c * n_c;
   const double cscale = d.cscale[b];
   const double alpha = a.alpha, sigma = a.sigma;
+  if (a.adaptive && tid == 0) { d.smask[b] = 0; d.rflag[b] = 0; }
   __syncthreads();
 
   int status = 0, iter = 0;
@@ -524,8 +552,15 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
       status = admm_check(a, s, b, 0, cscale, &pri, &dua);
       if (status) break;
     }
-    if (a.slice > 0 && iter == it0 + a.slice && iter < a.max_iter) {
-      // the slice is used up (it ends on a termination check): park the solve
+    double rho_new = 0.0;
+    if (a.adaptive && iter % a.ad_interval == 0 && iter < a.max_iter) {
+      const double rho = d.rho_b[b], est = admm_rho_estimate(a, s, b, rho);
+      if (est > rho * a.ad_tol || est < rho / a.ad_tol) rho_new = est;
+    }
+    if (rho_new > 0.0 || (a.slice > 0 && iter == it0 + a.slice && iter < a.max_iter)) {
+      // rho must change (setup refactors, then the solve resumes), or the slice is used up (it ends on a
+      // termination check): park the solve
+      if (rho_new > 0.0 && tid == 0) { d.rho_b[b] = rho_new; d.rflag[b] = 1; d.smask[b] = 1; d.nupd[b] += 1; }
       for (int j = tid; j < n; j += SCO_BLOCK) d.sx[(size_t)b * n + j] = s.x[j];
       for (int i = tid; i < m; i += SCO_BLOCK) { d.sz[(size_t)b * m + i] = s.z[i]; d.sy[(size_t)b * m + i] = s.y[i]; }
       if (tid == 0) { d.prog[b] = iter; d.status[b] = 0; d.iters[b] = iter; }
@@ -552,66 +587,24 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_admm_kernel(AdmmArgs a) {
 }
 
 // --------------------------------------------------------------------------
-// adaptive rho (opt-in): OSQP's estimate from the SCALED iterates of a parked solve
-//   rho <- rho sqrt( (|Ax - z| / (max(|z|, |Ax|) + 1e-10)) / (|Px + q + A'y| / (max(|q|, |A'y|, |Px|) + 1e-10) + 1e-10) )
-// clipped to [1e-6, 1e6]; taken when it leaves [rho / tol, rho tol] (osqp 0.6 auxil.c compute_rho_estimate /
-// adapt_rho, as recalled: the library is not available here, see oracle/osqp_ref.c).  One workgroup per problem;
-// fixed summation order, so the result does not depend on scheduling.
-// mode 0: problems flagged in `newqp` start a QP (rho = rho0); 1: every problem does; 2: none does.
+// adaptive rho (opt-in).  The ADMM kernels estimate rho themselves (every ad_interval iterations, after the
+// termination test) and park the solve when it must change; this kernel only gives the problems that START a QP
+// their initial rho and raises their setup flag.
+// mode 0: problems flagged in `newqp` start a QP; 1: every active problem does.
 // --------------------------------------------------------------------------
-struct RhoArgs {
+struct RhoInitArgs {
   QpDev d;
   const int *newqp;
-  int mode, interval;
-  double rho0, tol;
+  int mode;
+  double rho0;
 };
 
-__global__ __launch_bounds__(SCO_BLOCK) void qp_rho_update_kernel(RhoArgs a) {
+__global__ void qp_rho_init_kernel(RhoInitArgs a) {
   const QpDev &d = a.d;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (d.active && !d.active[b]) {
-    if (tid == 0) { d.smask[b] = 0; d.rflag[b] = 0; }
-    return;
-  }
-  const bool fresh = a.mode == 1 || (a.mode == 0 && a.newqp[b]);
-  if (fresh) {
-    if (tid == 0) { d.rho_b[b] = a.rho0; d.smask[b] = 1; d.rflag[b] = 0; d.nupd[b] = 0; }
-    return;
-  }
-  const int it = d.prog[b];
-  if (it <= 0 || it % a.interval != 0) {
-    if (tid == 0) { d.smask[b] = 0; d.rflag[b] = 0; }
-    return;
-  }
-  __shared__ double red[NWAVE * 8];
-  const int n = d.n, m = d.m;
-  const double *x = d.sx + (size_t)b * n, *z = d.sz + (size_t)b * m, *y = d.sy + (size_t)b * m;
-  const double *As = d.As + (size_t)b * d.nnzA, *Ps = d.Ps + (size_t)b * d.nnzP, *qs = d.qs + (size_t)b * n;
-  const int *w = d.w + (size_t)b * m;
-  double v[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int i = tid; i < m; i += SCO_BLOCK) {
-    double ax = 0.0;
-    for (int t = d.Rp[i]; t < d.Rp[i + 1]; t++) ax += As[d.Rpos[t]] * x[d.Rj[t]];
-    v[0] = fmax(v[0], fabs(ax - z[i])); v[1] = fmax(v[1], fabs(z[i])); v[2] = fmax(v[2], fabs(ax));
-  }
-  for (int j = tid; j < n; j += SCO_BLOCK) {
-    double px = 0.0, aty = 0.0;
-    for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * x[d.Fi[t]];
-    for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) aty += As[t] * ((double)w[d.Ai[t]] * y[d.Ai[t]]);
-    v[3] = fmax(v[3], fabs(px + qs[j] + aty)); v[4] = fmax(v[4], fabs(qs[j]));
-    v[5] = fmax(v[5], fabs(aty)); v[6] = fmax(v[6], fabs(px));
-  }
-  block_reduce<7, true>(v, red);
-  if (tid == 0) {
-    const double rho = d.rho_b[b];
-    const double pri = v[0] / (fmax(v[1], v[2]) + 1e-10);
-    const double dua = v[3] / (fmax(v[4], fmax(v[5], v[6])) + 1e-10);
-    double est = rho * sqrt(pri / (dua + 1e-10));
-    est = fmin(fmax(est, SCO_RHO_MIN), 1e6);
-    const int changed = (est > rho * a.tol || est < rho / a.tol) ? 1 : 0;
-    if (changed) { d.rho_b[b] = est; d.nupd[b] += 1; }
-    d.smask[b] = changed; d.rflag[b] = changed;
-  }
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= d.batch) return;
+  if (d.active && !d.active[b]) { d.smask[b] = 0; d.rflag[b] = 0; return; }
+  if (a.mode == 1 || a.newqp[b]) { d.rho_b[b] = a.rho0; d.smask[b] = 1; d.rflag[b] = 0; d.nupd[b] = 0; }
 }
 
 // --------------------------------------------------------------------------
@@ -832,19 +825,25 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
       sco_set_error("adaptive_rho: the global-memory tier cannot park a solve (pattern too large for the on-chip tiers)");
       return SCO_ERR_CAPACITY;
     }
-    if (!(st->adaptive_rho_tolerance > 1.0)) { sco_set_error("adaptive_rho_tolerance must be > 1"); return SCO_ERR_ARG; }
-    slice = sco_qp_adaptive_interval(st);       // every launch ends on a rho update
-  } else if ((!qp->use_rl && (qp->use_reg || qp->use_fast)) || qp->use_big || st->check_termination <= 0 || slice <= 0) {
+    if (!(st->adaptive_rho_tolerance > 1.0) || st->check_termination <= 0) {
+      sco_set_error("adaptive_rho needs adaptive_rho_tolerance > 1 and check_termination > 0"); return SCO_ERR_ARG;
+    }
+  }
+  const bool can_park = !qp->use_big && (qp->use_rl || adaptive || !(qp->use_reg || qp->use_fast));
+  if (!can_park || st->check_termination <= 0 || (slice <= 0 && !adaptive)) {
     slice = 0;                                  // the register / sliced-ELL / global-memory kernels run to the end
   } else {
-    slice = std::max(1, slice / st->check_termination) * st->check_termination;   // slices end on a termination check
+    // slices end on a termination check; adaptive rho without time slicing parks only when rho changes
+    if (slice <= 0) slice = st->max_iter;
+    slice = std::max(1, (slice + st->check_termination - 1) / st->check_termination) * st->check_termination;
   }
   if (sliced) *sliced = slice;
   QpDev d = qp->d; d.active = active_dev;
   QpDev dsetup = qp->d; dsetup.active = adaptive ? qp->d.smask : setup_mask;
   SetupArgs sa{dsetup, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling, adaptive ? 1 : 0};
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
-              st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0, slice, adaptive ? 1 : 0};
+              st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0, slice,
+              adaptive ? 1 : 0, adaptive ? sco_qp_adaptive_interval(st) : 0, st->adaptive_rho_tolerance};
   qp->solved_once = true;
   SCO_HIP(hipEventRecord(qp->ev[0], qp->stream));
   if (qp->use_big) {
@@ -854,12 +853,11 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
     SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
     return SCO_OK;
   }
-  if (adaptive) {
-    // rho of the problems that start a QP / of the parked ones that reached an update point; sets d.smask, d.rflag
-    RhoArgs ra{d, setup_mask, setup_mask == SCO_MASK_ALL ? 1 : (setup_mask == SCO_MASK_NONE ? 2 : 0),
-               slice, st->rho, st->adaptive_rho_tolerance};
-    if (ra.mode) ra.newqp = nullptr;
-    hipLaunchKernelGGL(qp_rho_update_kernel, dim3(d.batch), dim3(SCO_BLOCK), 0, qp->stream, ra);
+  if (adaptive && setup_mask != SCO_MASK_NONE) {
+    // the problems that start a QP get the initial rho and their setup flag (the parked ones keep what the ADMM
+    // kernel left when it parked them)
+    RhoInitArgs ra{d, setup_mask == SCO_MASK_ALL ? nullptr : setup_mask, setup_mask == SCO_MASK_ALL ? 1 : 0, st->rho};
+    hipLaunchKernelGGL(qp_rho_init_kernel, dim3((d.batch + 255) / 256), dim3(256), 0, qp->stream, ra);
     SCO_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(qp_setup_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_setup, qp->stream, sa);
@@ -897,7 +895,7 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
     // one launch per rho-update interval; a problem that has not ended stays parked and is resumed by the next one
     SCO_HIP(hipMemsetAsync(d.prog, 0, B * sizeof(int), qp->stream));
     std::vector<int> prog(B);
-    const long long cap = (long long)settings->max_iter / sco_qp_adaptive_interval(settings) + 2;
+    const long long cap = (long long)settings->max_iter / sco_qp_adaptive_interval(settings) + 2;   // a launch per rho change at most
     float ms_setup = 0, ms_admm = 0;
     for (long long round = 0; round < cap; round++) {
       // from the second launch on only the parked problems run (a finished one would start over)
@@ -936,6 +934,15 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
   SCO_HIP(hipEventElapsedTime(&ms0, qp->ev[0], qp->ev[1]));
   SCO_HIP(hipEventElapsedTime(&ms1, qp->ev[1], qp->ev[2]));
   qp->last_ms[0] = ms0; qp->last_ms[1] = ms1;
+  return SCO_OK;
+}
+
+extern "C" int sco_qp_adaptive_info(sco_qp *qp, double *rho, int *updates) {
+  if (!qp) return SCO_ERR_ARG;
+  SCO_HIP(hipSetDevice(qp->device));
+  const QpDev &d = qp->d;
+  if (rho) SCO_HIP(hipMemcpy(rho, d.rho_b, (size_t)d.batch * sizeof(double), hipMemcpyDeviceToHost));
+  if (updates) SCO_HIP(hipMemcpy(updates, d.nupd, (size_t)d.batch * sizeof(int), hipMemcpyDeviceToHost));
   return SCO_OK;
 }
 

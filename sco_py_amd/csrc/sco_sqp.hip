@@ -990,10 +990,12 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   }
   // time slicing (scheduling only): every launch advances each active QP by at most `slice` ADMM iterations; a
   // problem whose QP ended goes through post / pre / setup and joins the next launch with its next QP
-  int slice_req = params->admm_slice < 0 ? 0 : (params->admm_slice > 0 ? params->admm_slice : 6250);
-  if (qsl.adaptive_rho) slice_req = sco_qp_adaptive_interval(&qsl);     // one launch per rho-update interval
+  // default slice: 6250 iterations (7-DOF x 20: 964 ms per 1024-batch step against 1106 unsliced); with adaptive rho
+  // the QPs are short and every rho change costs its problem a relaunch, so the slice is shorter (scripts/gpu_adaptive_slice_sweep.py)
+  const int slice_req = params->admm_slice < 0 ? 0 : (params->admm_slice > 0 ? params->admm_slice : (qs->adaptive_rho ? 2000 : 6250));
   SCO_HIP(hipMemsetAsync(h->qp1->d.prog, 0, (size_t)s.batch * sizeof(int), h->stream));
-  const long long slices_per_qp = slice_req > 0 ? (qsl.max_iter + slice_req - 1) / slice_req : 1;
+  long long slices_per_qp = slice_req > 0 ? (qsl.max_iter + slice_req - 1) / slice_req : 1;
+  if (qsl.adaptive_rho) slices_per_qp += qsl.max_iter / sco_qp_adaptive_interval(&qsl) + 1;    // a launch per rho change at most
   const long long round_cap = ((long long)p.max_qp_solves + 8) * slices_per_qp;
   while (n_active > 0 && h->rounds < round_cap) {
     SCO_HIP(hipMemsetAsync(s.n_active, 0, sizeof(int), h->stream));

@@ -33,12 +33,15 @@ def _check(probs, w=None, settings=None, check=None, resid_tol=1e-9, **okw):
         qp.load(Pval, q, Aval, l, u, w)
         x, y, st, it, res = qp.solve(settings)
         info = qp.info()
+        rho, nupd = qp.adaptive_info()
     finally:
         qp.close()
     for b in (range(len(probs)) if check is None else check):
         ref = o.solve(*probs[b], w=None if w is None else w[b], **okw)
         assert st[b] == ref.info.status_val, (b, st[b], ref.info.status_val)
         assert it[b] == ref.info.iter, (b, it[b], ref.info.iter)
+        if okw.get("adaptive_rho"):
+            assert nupd[b] == ref.info.rho_updates and abs(rho[b] - ref.info.rho_estimate) < 1e-6 * ref.info.rho_estimate
         if ref.info.status_val in (1, 2, -2):
             assert np.abs(x[b] - ref.x).max() < TOL, (b, np.abs(x[b] - ref.x).max())
             assert np.abs(y[b] - ref.y).max() < 1e-5 * (1 + np.abs(ref.y).max())
