@@ -82,3 +82,27 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "osqp_ref" not in src.replace("oracle/osqp_ref.c", ""), f
+
+
+def test_integration_stub_declares_the_same_settings_struct():
+    """INTEGRATION.md shows a ctypes stub a maintainer would paste into the reference: its struct must be the
+    library's (a shorter one would let sco_qp_default_settings write past its end)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = text[text.index("class _Settings"):text.index("def _hip_solve")]
+    names = re.findall(r'"([a-z_]+)"', stub)
+    assert names == [f[0] for f in _lib.QpSettings._fields_]
+    header = open(os.path.join(ROOT, "include", "sco_hip.h")).read()
+    body = header[header.index("typedef struct sco_qp_settings {"):header.index("} sco_qp_settings;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    assert re.findall(r"\b(?:double|int)\s+([a-z_]+);", body) == names
+
+
+def test_python_struct_fields_follow_the_header():
+    header = open(os.path.join(ROOT, "include", "sco_hip.h")).read()
+    for cname, cls in (("sco_sqp_params", _lib.SqpParams), ("sco_trajopt_desc", _lib.TrajoptDesc)):
+        body = header[header.index("typedef struct %s {" % cname):header.index("} %s;" % cname)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in re.findall(r"\b(?:double|int)\s+([a-z_, \n]+);", body):
+            names += [v.strip() for v in decl.split(",")]
+        assert names == [f[0] for f in cls._fields_], cname
