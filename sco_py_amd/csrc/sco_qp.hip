@@ -112,10 +112,25 @@ struct SetupArgs {
   int per_problem_rho;      // adaptive rho: the problem's current rho is d.rho_b[b]
 };
 
+#ifdef SCO_STAMP
+// diagnostic build only: cycles per phase of the setup of problem 0 (never compiled into the product)
+__device__ double g_setup_stamp[16];
+extern "C" int sco_debug_setup_stamps(double *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_setup_stamp), 16 * sizeof(double)) == hipSuccess ? 0 : -2;
+}
+#define SSTAMP(k) { if (b == 0 && tid == 0) { const long long now_ = __builtin_readcyclecounter(); g_setup_stamp[k] += (double)(now_ - sst_t); sst_t = now_; } }
+#else
+#define SSTAMP(k)
+#endif
+
 __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
   const QpDev &d = a.d;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (d.active && !d.active[b]) return;
+#ifdef SCO_STAMP
+  long long sst_t = __builtin_readcyclecounter();
+  if (b == 0 && tid == 0) g_setup_stamp[15] += 1.0;
+#endif
   const double rho0 = a.per_problem_rho ? d.rho_b[b] : a.rho;
   const int n = d.n, m = d.m, nnzP = d.nnzP, nnzA = d.nnzA, n_e = d.n_e, n_c = d.n_c, ncpl = d.ncpl;
 
@@ -129,7 +144,6 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
   double *Et = Dt + n;              // m   (later: rw[m])
   double *cpl = Et + m;             // ncpl
   double *red = cpl + ncpl;         // NWAVE * 2
-  double *Lp = red + NWAVE * 2;     // n_c (n_c + 1) / 2
 
   const double *Pval = d.Pval + (size_t)b * nnzP;
   const double *Aval = d.Aval + (size_t)b * nnzA;
@@ -139,6 +153,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
   for (int i = tid; i < m; i += SCO_BLOCK) E[i] = 1.0;
   double c = 1.0;
   __syncthreads();
+  SSTAMP(0)
 
   for (int it = 0; it < a.scaling; it++) {
     // inf-norms of the columns of [[P, A'], [A, 0]]
@@ -189,6 +204,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
     __syncthreads();
   }
 
+  SSTAMP(1)
   // scaled bounds, rho vector; Et becomes rw = w * rho
   {
     double *ls = d.ls + (size_t)b * m, *us = d.us + (size_t)b * m, *rho = d.rho + (size_t)b * m;
@@ -216,6 +232,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
   }
   __syncthreads();
 
+  SSTAMP(2)
   // ---- K_EE^-1 (diagonal) and the coupling block K_CE ----------------------
   double *kinv = Dt;
   for (int e = tid; e < n_e; e += SCO_BLOCK) {
@@ -231,70 +248,126 @@ __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
     for (int t = d.cp_ptr[k]; t < d.cp_ptr[k + 1]; t++) v += Et[d.cp_row[t]] * As[d.cp_pa[t]] * As[d.cp_pe[t]];
     cpl[k] = v; d.cpl[(size_t)b * ncpl + k] = v;
   }
+  // ---- S = K_CC - K_CE K_EE^-1 K_EC, packed lower triangle, into the problem's W buffer (qp_factor_kernel
+  //      turns it into W = S^-1 in place) ---------------------------------------------------------------
   const size_t ntri = (size_t)n_c * (n_c + 1) / 2;
-  for (size_t t = tid; t < ntri; t += SCO_BLOCK) Lp[t] = 0.0;
+  double *Sg = d.W + (size_t)b * n_c * n_c;
+  for (size_t t = tid; t < ntri; t += SCO_BLOCK) Sg[t] = 0.0;
   __syncthreads();
-
-  // ---- S = K_CC - K_CE K_EE^-1 K_EC, structurally non-zero entries ----------
+  SSTAMP(3)
   for (int id = tid; id < d.nS; id += SCO_BLOCK) {
     const int sa = d.s_a[id], sb = d.s_b[id];
     double v = (sa == sb) ? a.sigma : 0.0;
     if (d.s_ppos[id] >= 0) v += Ps[d.s_ppos[id]];
     for (int t = d.sa_ptr[id]; t < d.sa_ptr[id + 1]; t++) v += Et[d.sa_row[t]] * As[d.sa_pa[t]] * As[d.sa_pb[t]];
     for (int t = d.ss_ptr[id]; t < d.ss_ptr[id + 1]; t++) v -= cpl[d.ss_k1[t]] * cpl[d.ss_k2[t]] * kinv[d.ss_e[t]];
-    Lp[tri_idx(sa, sb)] = v;
+    Sg[tri_idx(sa, sb)] = v;
   }
+  SSTAMP(4)
+}
+
+// --------------------------------------------------------------------------
+// factor kernel: W = S^-1 of the dense core (order n_c <= 256), one workgroup of 1024 threads per problem.
+// S arrives as a packed lower triangle in the problem's W buffer and lives in LDS from then on:
+//   Cholesky S = L L' (left-looking), M = L^-1 in place (last column first), W = M' M -> global.
+// Both triangular loops are LDS-latency bound (one dependent load-multiply-add chain per row), so a row's
+// k-range is split over LPR adjacent lanes (LPR = the power of two that fills the workgroup: few rows are left
+// exactly when the chains are long) and added with lane shuffles in a fixed order; 16 wavefronts hide the rest.
+// (The 256-thread single-chain version took 2.9 M cycles per 140 x 140 core, profiles/r01_setup_stamps.txt.)
+// --------------------------------------------------------------------------
+#define SCO_FACTOR_BLOCK 1024
+
+__device__ __forceinline__ int lanes_per_row(int rows) {
+  int l = 64;
+  while (l > 1 && l * rows > SCO_FACTOR_BLOCK) l >>= 1;
+  return l;
+}
+
+__global__ __launch_bounds__(SCO_FACTOR_BLOCK) void qp_factor_kernel(QpDev d) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (d.active && !d.active[b]) return;
+  const int n_c = d.n_c;
+  if (n_c == 0) return;
+#ifdef SCO_STAMP
+  long long sst_t = __builtin_readcyclecounter();
+#endif
+  extern __shared__ double lds[];
+  double *Lp = lds;                                   // n_c (n_c + 1) / 2
+  double *dg = Lp + (size_t)n_c * (n_c + 1) / 2;      // n_c: diagonal of L (Lp keeps S_jj there until the inverse)
+  const size_t ntri = (size_t)n_c * (n_c + 1) / 2;
+  double *W = d.W + (size_t)b * n_c * n_c;
+  for (size_t t = tid; t < ntri; t += SCO_FACTOR_BLOCK) Lp[t] = W[t];
   __syncthreads();
 
-  // ---- dense Cholesky S = L L' (left-looking; every thread recomputes the
-  //      pivot of the current column so one barrier per column suffices) -------
+  // ---- Cholesky: one barrier per column (a row's owner lane reads S_ij and writes L_ij itself; the pivot goes to dg)
   for (int j = 0; j < n_c; j++) {
-    double piv = Lp[tri_idx(j, j)];
+    const int rows = n_c - j, lpr = lanes_per_row(rows);
+    const int r = tid / lpr, part = tid - r * lpr, i = j + r;
+    const bool act = r < rows;
     const double *rj = Lp + tri_idx(j, 0);
-    for (int k = 0; k < j; k++) piv -= rj[k] * rj[k];
-    piv = sqrt(piv);
-    for (int i = j + tid; i < n_c; i += SCO_BLOCK) {
-      if (i == j) continue;
-      const double *ri = Lp + tri_idx(i, 0);
-      double s = ri[j];
-      for (int k = 0; k < j; k++) s -= ri[k] * rj[k];
-      Lp[tri_idx(i, j)] = s / piv;
+    const double *ri = Lp + tri_idx(act ? i : j, 0);
+    double p0 = 0.0, p1 = 0.0, s0 = 0.0, s1 = 0.0;
+    int k = part;
+    for (; k + lpr < j; k += 2 * lpr) {
+      const double a0 = rj[k], a1 = rj[k + lpr], b0 = ri[k], b1 = ri[k + lpr];
+      p0 += a0 * a0; p1 += a1 * a1; s0 += b0 * a0; s1 += b1 * a1;
     }
-    __syncthreads();          // all reads of the old (j, j) entry are done
-    if (tid == 0) Lp[tri_idx(j, j)] = piv;
+    if (k < j) { const double a0 = rj[k]; p0 += a0 * a0; s0 += ri[k] * a0; }
+    double p = p0 + p1, sm = s0 + s1;
+    for (int o = lpr >> 1; o > 0; o >>= 1) { p += __shfl_xor(p, o); sm += __shfl_xor(sm, o); }
+    if (act && part == 0) {
+      const double piv = sqrt(rj[j] - p);
+      if (i == j) dg[j] = piv; else Lp[tri_idx(i, j)] = (ri[j] - sm) / piv;
+    }
     __syncthreads();
   }
+  SSTAMP(5)
 
-  // ---- M = L^-1 in place, last column first ---------------------------------
+  // ---- M = L^-1 in place, last column first:  M_ij = -(sum_{k=j+1..i} M_ik L_kj) / L_jj
   for (int j = n_c - 1; j >= 0; j--) {
-    const double ljj = Lp[tri_idx(j, j)];
-    double acc[4];   // up to 4 rows per thread (n_c <= 4 * SCO_BLOCK enforced on the host)
-    int cnt = 0;
-    for (int i = j + 1 + tid; i < n_c; i += SCO_BLOCK, cnt++) {
+    const int rows = n_c - 1 - j, lpr = lanes_per_row(rows > 0 ? rows : 1);
+    const int r = tid / lpr, part = tid - r * lpr, i = j + 1 + r;
+    const bool act = r < rows;
+    const double ljj = dg[j];
+    double s0 = 0.0, s1 = 0.0;
+    if (act) {
       const double *ri = Lp + tri_idx(i, 0);
-      double s = 0.0;
-      for (int k = j + 1; k <= i; k++) s += ri[k] * Lp[tri_idx(k, j)];
-      acc[cnt] = s;
+      int k = j + 1 + part;
+      for (; k + lpr <= i; k += 2 * lpr) {
+        s0 += ri[k] * Lp[tri_idx(k, j)]; s1 += ri[k + lpr] * Lp[tri_idx(k + lpr, j)];
+      }
+      if (k <= i) s0 += ri[k] * Lp[tri_idx(k, j)];
     }
-    __syncthreads();
-    cnt = 0;
-    for (int i = j + 1 + tid; i < n_c; i += SCO_BLOCK, cnt++) Lp[tri_idx(i, j)] = -acc[cnt] / ljj;
+    double sm = s0 + s1;
+    for (int o = lpr >> 1; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+    __syncthreads();                              // every read of column j of L is done
+    if (act && part == 0) Lp[tri_idx(i, j)] = -sm / ljj;
     if (tid == 0) Lp[tri_idx(j, j)] = 1.0 / ljj;
     __syncthreads();
   }
+  SSTAMP(6)
 
-  // ---- W = M' M (dense, symmetric) -> global ---------------------------------
-  double *W = d.W + (size_t)b * n_c * n_c;
-  for (size_t p = tid; p < ntri; p += SCO_BLOCK) {
+  // ---- W = M' M (dense, symmetric) -> global
+  for (size_t p = tid; p < ntri; p += SCO_FACTOR_BLOCK) {
     int ia = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
     while (tri_idx(ia + 1, 0) <= p) ia++;
     while (tri_idx(ia, 0) > p) ia--;
     const int ib = (int)(p - tri_idx(ia, 0));
-    double s = 0.0;
-    for (int k = ia; k < n_c; k++) s += Lp[tri_idx(k, ia)] * Lp[tri_idx(k, ib)];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int k = ia;
+    size_t c = tri_idx(k, 0);                     // row k of M
+    for (; k + 3 < n_c; k += 4) {
+      const size_t c1 = c + k + 1, c2 = c1 + k + 2, c3 = c2 + k + 3;
+      s0 += Lp[c + ia] * Lp[c + ib]; s1 += Lp[c1 + ia] * Lp[c1 + ib];
+      s2 += Lp[c2 + ia] * Lp[c2 + ib]; s3 += Lp[c3 + ia] * Lp[c3 + ib];
+      c = c3 + k + 4;
+    }
+    for (; k < n_c; k++) { s0 += Lp[c + ia] * Lp[c + ib]; c += k + 1; }
+    const double s = (s0 + s1) + (s2 + s3);
     W[(size_t)ia * n_c + ib] = s;
     W[(size_t)ib * n_c + ia] = s;
   }
+  SSTAMP(7)
 }
 
 // --------------------------------------------------------------------------
@@ -716,6 +789,7 @@ static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const
   AL(rho_b, B) AL(rflag, B) AL(smask, B) AL(nupd, B) AL(amask, B)
 #undef AL
   SCO_HIP(hipFuncSetAttribute((const void *)qp_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+  SCO_HIP(hipFuncSetAttribute((const void *)qp_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
   if (qp->use_big) {
     int r_ = big_upload(qp->big, qp->use_bt ? 1 : batch, qp->allocs, qp->bigd);   // dense workspace unused by bt
@@ -860,8 +934,14 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
     hipLaunchKernelGGL(qp_rho_init_kernel, dim3((d.batch + 255) / 256), dim3(256), 0, qp->stream, ra);
     SCO_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(qp_setup_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_setup, qp->stream, sa);
-  SCO_HIP(hipGetLastError());
+  {
+    // scaling + reduced matrix (256 threads, S into the W buffer), then factor + inverse (1024 threads)
+    const size_t ntri = (size_t)d.n_c * (d.n_c + 1) / 2;
+    hipLaunchKernelGGL(qp_setup_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_setup - ntri * sizeof(double), qp->stream, sa);
+    SCO_HIP(hipGetLastError());
+    hipLaunchKernelGGL(qp_factor_kernel, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), (ntri + d.n_c) * sizeof(double), qp->stream, dsetup);
+    SCO_HIP(hipGetLastError());
+  }
   SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
   if (mid) SCO_HIP(hipEventRecord(mid, qp->stream));
   if (qp->use_rl) {
