@@ -8,8 +8,9 @@
 //
 // Mapping to the hardware
 //   * one workgroup (256 threads = 4 wavefronts) per problem, grid = batch;
-//   * qp_setup_kernel: Ruiz equilibration, rho vector, reduced matrix assembly,
-//     dense Cholesky + inverse of the core Schur complement -- all in LDS;
+//   * qp_setup_kernel: Ruiz equilibration, rho vector, reduced matrix assembly
+//     (scaled data in LDS, the core Schur complement S into the W buffer);
+//   * qp_factor_kernel (1024 threads): dense Cholesky + inverse of S in LDS -> W;
 //   * qp_admm_kernel: the whole ADMM loop of one problem inside one launch with
 //     every iterate (x, z, y), the scaled A values and the coupling block held
 //     in LDS; HBM is touched once to load the problem, once per iteration for
