@@ -130,12 +130,14 @@ struct BtHost {
   size_t blk_doubles = 0, ws_doubles = 0, lds_bytes = 0;
   std::vector<int> ch_desc, it;     // it: 8 ints per chunk slot (e, j, r0, r1, ep0, ep1, core idx, core pos)
 };
-struct BtDev { const int *ch_desc, *it, *cent; double *blk, *ws; };
+struct BtDev { const int *ch_desc, *it, *cent; double *blk, *ws, *park_part; };   // park_part: [batch][npart] of a parked solve
 bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th);
 int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &td);
 // th/td null = dense route
-int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, const BigHost &bh, const BigDev &bd,
-               const BtHost *th, const BtDev *td, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2);
+// setup_mask: the problems whose setup + factorisation run (a.d.active: the ones whose ADMM runs); the structured
+// form honours a.slice / a.adaptive (park and resume), the dense form runs every solve to the end
+int big_launch(const AdmmArgs &a, const int *setup_mask, int scaling, const int *Pp, const int *Pi, const BigHost &bh,
+               const BigDev &bd, const BtHost *th, const BtDev *td, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2);
 
 struct sco_qp {
   int device = 0;

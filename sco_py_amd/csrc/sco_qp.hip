@@ -896,15 +896,15 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
                          int slice, hipEvent_t mid, int *sliced) {
   const bool adaptive = st->adaptive_rho != 0;
   if (adaptive) {
-    if (qp->use_big) {
-      sco_set_error("adaptive_rho: the global-memory tier cannot park a solve (pattern too large for the on-chip tiers)");
+    if (qp->use_big && !qp->use_bt) {
+      sco_set_error("adaptive_rho: the dense form of the global-memory tier cannot park a solve");
       return SCO_ERR_CAPACITY;
     }
     if (!(st->adaptive_rho_tolerance > 1.0) || st->check_termination <= 0) {
       sco_set_error("adaptive_rho needs adaptive_rho_tolerance > 1 and check_termination > 0"); return SCO_ERR_ARG;
     }
   }
-  const bool can_park = !qp->use_big && (qp->use_rl || adaptive || !(qp->use_reg || qp->use_fast));
+  const bool can_park = qp->use_big ? qp->use_bt : (qp->use_rl || adaptive || !(qp->use_reg || qp->use_fast));
   if (!can_park || st->check_termination <= 0 || (slice <= 0 && !adaptive)) {
     slice = 0;                                  // the register / sliced-ELL / global-memory kernels run to the end
   } else {
@@ -921,19 +921,19 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
               adaptive ? 1 : 0, adaptive ? sco_qp_adaptive_interval(st) : 0, st->adaptive_rho_tolerance};
   qp->solved_once = true;
   SCO_HIP(hipEventRecord(qp->ev[0], qp->stream));
-  if (qp->use_big) {
-    int r_ = big_launch(aa, st->scaling, qp->Pp_dev, qp->Pi_dev, qp->big, qp->bigd, qp->use_bt ? &qp->bt : nullptr,
-                        qp->use_bt ? &qp->btd : nullptr, qp->stream, qp->ev[1], mid);
-    if (r_) return r_;
-    SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
-    return SCO_OK;
-  }
   if (adaptive && setup_mask != SCO_MASK_NONE) {
     // the problems that start a QP get the initial rho and their setup flag (the parked ones keep what the ADMM
     // kernel left when it parked them)
     RhoInitArgs ra{d, setup_mask == SCO_MASK_ALL ? nullptr : setup_mask, setup_mask == SCO_MASK_ALL ? 1 : 0, st->rho};
     hipLaunchKernelGGL(qp_rho_init_kernel, dim3((d.batch + 255) / 256), dim3(256), 0, qp->stream, ra);
     SCO_HIP(hipGetLastError());
+  }
+  if (qp->use_big) {
+    int r_ = big_launch(aa, dsetup.active, st->scaling, qp->Pp_dev, qp->Pi_dev, qp->big, qp->bigd,
+                        qp->use_bt ? &qp->bt : nullptr, qp->use_bt ? &qp->btd : nullptr, qp->stream, qp->ev[1], mid);
+    if (r_) return r_;
+    SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
+    return SCO_OK;
   }
   {
     // scaling + reduced matrix (256 threads, S into the W buffer), then factor + inverse (1024 threads)

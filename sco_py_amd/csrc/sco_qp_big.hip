@@ -105,6 +105,10 @@ struct BigArgs {
   double *bt_blk; size_t bt_stride;
   const int *ch_desc, *it, *cent;
   int nchunks, npart, use_part;
+  // park / resume of the structured kernel (time slicing, adaptive rho; see RlArgs in sco_admm_rl.hip)
+  int slice, adaptive, ad_interval, per_problem_rho;
+  double ad_tol;
+  double *park_part;
   double *stamp;     // diagnostic build only (SCO_STAMP)
 };
 
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(BT) void qp_setup_big_kernel(BigArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (d.active && !d.active[b]) return;
   const int n = d.n, m = d.m, nnzP = d.nnzP, nnzA = d.nnzA, n_e = d.n_e, n_c = d.n_c, ncpl = d.ncpl;
+  const double rho0 = a.per_problem_rho ? d.rho_b[b] : a.rho;
   __shared__ double red[BWV * 2];
   double *Ps = d.Ps + (size_t)b * nnzP, *As = d.As + (size_t)b * nnzA, *qs = d.qs + (size_t)b * n;
   double *D = d.D + (size_t)b * n, *E = d.E + (size_t)b * m;
@@ -176,8 +181,8 @@ __global__ __launch_bounds__(BT) void qp_setup_big_kernel(BigArgs a) {
       ls[i] = li; us[i] = ui;
       double r;
       if (li < -SCO_INFTY * SCO_MIN_SCALING && ui > SCO_INFTY * SCO_MIN_SCALING) r = SCO_RHO_MIN;
-      else if (ui - li < SCO_RHO_TOL) r = SCO_RHO_EQ_OVER_RHO_INEQ * a.rho;
-      else r = a.rho;
+      else if (ui - li < SCO_RHO_TOL) r = SCO_RHO_EQ_OVER_RHO_INEQ * rho0;
+      else r = rho0;
       rho[i] = r; Et[i] = r * (double)w[i];
     }
     if (tid == 0) d.cscale[b] = c;
@@ -391,6 +396,30 @@ __device__ int big_check(const BigArgs &a, const BigChk &k, int iter, double *re
     }
   }
   return status;
+}
+
+// OSQP's rho estimate from the SCALED iterates (same rule as admm_rho_estimate in sco_qp.hip)
+template <int NT>
+__device__ double big_rho_estimate(const BigArgs &a, const BigChk &k, double *red, double rho) {
+  const QpDev &d = a.d;
+  const int tid = threadIdx.x, n = d.n, m = d.m;
+  double v[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < m; i += NT) {
+    double ax = 0.0;
+    for (int s = d.Rp[i]; s < d.Rp[i + 1]; s++) ax += k.As[d.Rpos[s]] * k.x[d.Rj[s]];
+    v[0] = fmax(v[0], fabs(ax - k.z[i])); v[1] = fmax(v[1], fabs(k.z[i])); v[2] = fmax(v[2], fabs(ax));
+  }
+  for (int j = tid; j < n; j += NT) {
+    double px = 0.0, aty = 0.0;
+    for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += k.Ps[d.Fpos[t]] * k.x[d.Fi[t]];
+    for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) { const int i = d.Ai[t]; aty += k.As[t] * ((double)k.w[i] * k.y[i]); }
+    v[3] = fmax(v[3], fabs(px + k.qs[j] + aty)); v[4] = fmax(v[4], fabs(k.qs[j]));
+    v[5] = fmax(v[5], fabs(aty)); v[6] = fmax(v[6], fabs(px));
+  }
+  bblock_reduce<7, true, NT>(v, red);
+  const double pri = v[0] / (fmax(v[1], v[2]) + 1e-10);
+  const double dua = v[3] / (fmax(v[4], fmax(v[5], v[6])) + 1e-10);
+  return fmin(fmax(rho * sqrt(pri / (dua + 1e-10)), SCO_RHO_MIN), 1e6);
 }
 
 __global__ __launch_bounds__(BT) void qp_admm_big_kernel(BigArgs a) {
@@ -1091,16 +1120,32 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
     }
     for (int t = tid; t < a.nchunks * CH_STRIDE; t += BTT) s_dsc[t] = a.ch_desc[t];
   }
-  if (a.warm) {
+  // a parked solve (time slicing, adaptive rho) resumes from its scaled x, y (left in place) and z, t', g_e and the
+  // partial column sums (save area); when rho has changed meanwhile only x, y, z carry over and t, g_e, t' are
+  // rebuilt with the new rho, exactly as a warm start does from its x, y
+  const int it0 = a.slice > 0 ? d.prog[b] : 0;
+  const bool rederive = it0 > 0 && a.adaptive && d.rflag[b] != 0;
+  const bool restore = it0 > 0 && !rederive;
+  const double *pz = d.sz + (size_t)b * m;
+  if (restore) {
+    // nothing ran on this problem's workspace since it parked (setup only runs when rho changes): z, g_e and the
+    // products are where the loop left them; only the LDS state comes back
+    for (int c = tid; c < n_c; c += BTT) { s_q[c] = qs[d.core_var[c]]; s_x[c] = x[d.core_var[c]]; }
+  } else if (rederive || a.warm) {
     // OSQP-style warm start from the handle's previous (unscaled) solution in x / y:
     //   x_s = x / D,  y_s = c y / (E w),  z = A_s x_s,  t = w (rho z - y)
-    for (int j = tid; j < n; j += BTT) { x[j] = x[j] / Dg[j]; sdx[j] = 0.0; }
-    for (int i = tid; i < m; i += BTT) { y[i] = y[i] * cscale / (Eg[i] * (double)w[i]); sdy[i] = 0.0; }
+    if (!rederive) {
+      for (int j = tid; j < n; j += BTT) x[j] = x[j] / Dg[j];
+      for (int i = tid; i < m; i += BTT) y[i] = y[i] * cscale / (Eg[i] * (double)w[i]);
+    }
+    for (int j = tid; j < n; j += BTT) sdx[j] = 0.0;
+    for (int i = tid; i < m; i += BTT) sdy[i] = 0.0;
     __syncthreads();
     for (int c = tid; c < n_c; c += BTT) { s_q[c] = qs[d.core_var[c]]; s_x[c] = x[d.core_var[c]]; }
     for (int i = tid; i < m; i += BTT) {
       double ax = 0.0;
-      for (int s2 = d.Rp[i]; s2 < d.Rp[i + 1]; s2++) ax += As[d.Rpos[s2]] * x[d.Rj[s2]];
+      if (rederive) ax = pz[i];
+      else for (int s2 = d.Rp[i]; s2 < d.Rp[i + 1]; s2++) ax += As[d.Rpos[s2]] * x[d.Rj[s2]];
       z[i] = ax;
       tp[i] = (double)w[i] * (rho[i] * ax - y[i]);
     }
@@ -1132,9 +1177,14 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
     }
   }
   __syncthreads();
-  for (int j = tid; j < n; j += BTT)
-    for (int p = d.Ap[j]; p < d.Ap[j + 1]; p++) prod[p] = As[p] * tp[d.Ai[p]];
-  if (use_part) {
+  if (a.adaptive && tid == 0) { d.smask[b] = 0; d.rflag[b] = 0; }
+  if (!restore)
+    for (int j = tid; j < n; j += BTT)
+      for (int p = d.Ap[j]; p < d.Ap[j + 1]; p++) prod[p] = As[p] * tp[d.Ai[p]];
+  if (use_part && restore) {
+    const double *pp = a.park_part + (size_t)b * a.npart;
+    for (int t = tid; t < a.npart; t += BTT) s_part[t] = pp[t];
+  } else if (use_part) {
     // partial sums of the start point: one dense chunk per wavefront pass
     for (int ch = wave; ch < a.nchunks; ch += BTWV) {
       const int *dsc = s_dsc + ch * CH_STRIDE;
@@ -1157,7 +1207,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
 #else
 #define BSTAMP(k)
 #endif
-  for (iter = 1; iter <= a.max_iter; iter++) {
+  for (iter = it0 + 1; iter <= a.max_iter; iter++) {
     const bool chk = (a.check > 0 && iter % a.check == 0) || iter == a.max_iter;
     BSTAMP(11)
     // (1) core right-hand side r_c = sigma x_c - q_c + (A' t)_c
@@ -1261,14 +1311,36 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
     __syncthreads();
     BSTAMP(9)
     if (!chk) continue;
+    double rho_new = 0.0;
     {
       BigChk ck{As, Ps, qs, ls, us, Dg, Eg, x, y, z, sdx, sdy, w, cscale};
       status = big_check<BTT>(a, ck, iter, red, pri, dua);
+      if (!status && a.adaptive && iter % a.ad_interval == 0 && iter < a.max_iter) {
+        const double rho_b = d.rho_b[b], est = big_rho_estimate<BTT>(a, ck, red, rho_b);
+        if (est > rho_b * a.ad_tol || est < rho_b / a.ad_tol) rho_new = est;
+      }
     }
     __syncthreads();
     BSTAMP(10)
     if (status) break;
+    if (iter < a.max_iter && (rho_new > 0.0 || (a.slice > 0 && iter == it0 + a.slice))) {
+      // rho must change (setup + factorisation run again, then the solve resumes) or the slice is used up: park.
+      // x, y stay in place (scaled) and so does the workspace (z, g_e, products) unless rho changes: then setup
+      // uses the front of the workspace as scratch, so z goes to the save area; the LDS partial sums always do
+      double *qz = d.sz + (size_t)b * m;
+      for (int i = tid; i < m; i += BTT) qz[i] = z[i];
+      if (use_part) {
+        double *pp = a.park_part + (size_t)b * a.npart;
+        for (int t = tid; t < a.npart; t += BTT) pp[t] = s_part[t];
+      }
+      if (tid == 0) {
+        d.prog[b] = iter; d.status[b] = 0; d.iters[b] = iter;
+        if (rho_new > 0.0) { d.rho_b[b] = rho_new; d.rflag[b] = 1; d.smask[b] = 1; d.nupd[b] += 1; }
+      }
+      return;
+    }
   }
+  if (a.slice > 0 && tid == 0) d.prog[b] = 0;
   if (!status) status = SCO_QP_MAX_ITER_REACHED;
   if (iter > a.max_iter) iter = a.max_iter;
 #ifdef SCO_STAMP
@@ -1341,11 +1413,14 @@ int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &t
   SCO_HIP(hipMemset(p, 0, (size_t)batch * th.ws_doubles * sizeof(double)));
   allocs.push_back(p);
   td.ws = (double *)p;
+  SCO_HIP(hipMalloc(&p, (size_t)batch * std::max(th.npart, 1) * sizeof(double)));
+  allocs.push_back(p);
+  td.park_part = (double *)p;
   return SCO_OK;
 }
 
 template <int BS>
-static int bt_launch_bs(const BigArgs &ba, int batch, size_t lds, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2) {
+static int bt_launch_bs(const BigArgs &bs, const BigArgs &ba, int batch, size_t lds, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2) {
   // hipFuncSetAttribute applies to the current device only
   static bool attr_done[64] = {};
   int dev_ = 0;
@@ -1355,7 +1430,7 @@ static int bt_launch_bs(const BigArgs &ba, int batch, size_t lds, hipStream_t st
     SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_bt_kernel<BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     attr_done[dev_] = true;
   }
-  hipLaunchKernelGGL(qp_bt_factor_kernel<BS>, dim3(batch), dim3(256), 0, st, ba);
+  hipLaunchKernelGGL(qp_bt_factor_kernel<BS>, dim3(batch), dim3(256), 0, st, bs);
   SCO_HIP(hipGetLastError());
   if (ev_mid) SCO_HIP(hipEventRecord(ev_mid, st));
   if (mid2) SCO_HIP(hipEventRecord(mid2, st));
@@ -1364,8 +1439,8 @@ static int bt_launch_bs(const BigArgs &ba, int batch, size_t lds, hipStream_t st
   return SCO_OK;
 }
 
-int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, const BigHost &bh, const BigDev &bd,
-               const BtHost *th, const BtDev *td, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2) {
+int big_launch(const AdmmArgs &a, const int *setup_mask, int scaling, const int *Pp, const int *Pi, const BigHost &bh,
+               const BigDev &bd, const BtHost *th, const BtDev *td, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2) {
   BigArgs ba;
   ba.stamp = nullptr;
 #ifdef SCO_STAMP
@@ -1391,14 +1466,17 @@ int big_launch(const AdmmArgs &a, int scaling, const int *Pp, const int *Pi, con
     ba.npart = th->npart; ba.use_part = th->use_part ? 1 : 0;
     ba.ws = td->ws; ba.ws_stride = th->ws_doubles;
   }
-  hipLaunchKernelGGL(qp_setup_big_kernel, dim3(a.d.batch), dim3(BT), 0, st, ba);
+  ba.slice = th ? a.slice : 0; ba.adaptive = th ? a.adaptive : 0; ba.ad_interval = a.ad_interval; ba.ad_tol = a.ad_tol;
+  ba.per_problem_rho = ba.adaptive; ba.park_part = th ? td->park_part : nullptr;
+  BigArgs bs = ba; bs.d.active = setup_mask;          // setup + factorisation: the problems that need them
+  hipLaunchKernelGGL(qp_setup_big_kernel, dim3(a.d.batch), dim3(BT), 0, st, bs);
   SCO_HIP(hipGetLastError());
   if (th) {
     switch (th->bs) {
-      case 4: return bt_launch_bs<4>(ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
-      case 8: return bt_launch_bs<8>(ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
-      case 12: return bt_launch_bs<12>(ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
-      default: return bt_launch_bs<16>(ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
+      case 4: return bt_launch_bs<4>(bs, ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
+      case 8: return bt_launch_bs<8>(bs, ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
+      case 12: return bt_launch_bs<12>(bs, ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
+      default: return bt_launch_bs<16>(bs, ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
     }
   }
   if (ev_mid) SCO_HIP(hipEventRecord(ev_mid, st));

@@ -422,12 +422,20 @@ def test_diagnostic_flags(gpu):
     assert np.all(res.qp_solves[~capped] <= 3)
 
 
-def test_time_slicing_changes_the_schedule_not_the_results(gpu):
+@pytest.mark.parametrize("tier", ["row-local", "generic", "structured"])
+def test_time_slicing_changes_the_schedule_not_the_results(gpu, monkeypatch, tier):
     """sco_sqp_params.admm_slice: parked and resumed ADMM solves continue bit-exactly, so any slice length
-    gives the same trajectories, decisions and iteration counts as one launch per QP."""
-    arrays, _ = af.make_batch(48)
+    gives the same trajectories, decisions and iteration counts as one launch per QP (row-local kernel, generic
+    kernel, structured global-memory kernel)."""
+    if tier == "generic":
+        for k in ("SCO_QP_NO_RL", "SCO_QP_NO_REG", "SCO_QP_NO_FAST"):
+            monkeypatch.setenv(k, "1")
+    if tier == "structured":
+        monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    nb, dims = (48, (7, 20, 5, 2)) if tier == "row-local" else (6, (4, 8, 8, 3))      # 24 rows per block: dense chunks
+    arrays, _ = af.make_batch(nb, d=dims[0], T=dims[1], K=dims[2], O=dims[3])
     outs = []
-    with sb.TrajOptBatch(48, 7, 20, 5, 2) as tb:
+    with sb.TrajOptBatch(nb, *dims) as tb:
         tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
                 arrays["point_frac"], arrays["obstacles"])
         for sl in (-1, 0, 1000, 30, 77777):
@@ -469,3 +477,19 @@ def test_adaptive_rho_in_the_device_loop(gpu):
     assert np.all(res.trace[b][1, 7] < 0.2 * fixed.trace[b][1, 7] for b in range(3))   # first penalty QP: 2275 vs 21625 ...
     again = sb.solve_batch(arrays, qp_settings=st)
     assert np.array_equal(again.x, res.x) and np.array_equal(again.admm_iters, res.admm_iters)    # deterministic
+
+
+def test_12dof_50step_with_adaptive_rho_follows_the_oracle(gpu):
+    """BASELINE configs[4] shape with the quirks off and adaptive rho: the structured global-memory kernel parks at
+    every rho change, setup + block factorisation run again, the solve resumes.  Same decisions, statuses and ADMM
+    iteration counts as the oracle with the same rule (10 650 iterations in all, against > 200 000 with the fixed rho)."""
+    arrays, probs = af.make_batch(1, d=12, T=50, K=10, O=10)
+    p = _lib.default_sqp_params(compound_penalty=0, duplicate_rows=0)
+    res = sb.solve_batch(arrays, params=p, qp_settings=_lib.default_qp_settings(adaptive_rho=1), analytic_jac=True)
+    ref = sr.penalty_sqp(sr.trajopt_flat(probs[0], analytic_jac=True),
+                         sr.SolverParams(compound_penalty=False, duplicate_rows=False), qp_settings=dict(adaptive_rho=1))
+    tr, rt = res.trace[0], ref.trace[:64]
+    assert tr.shape == rt.shape and np.array_equal(tr[:, 0], rt[:, 0])
+    assert np.array_equal(tr[:, 6:8], rt[:, 6:8]), (tr[:, 6:8], rt[:, 6:8])
+    assert bool(res.success[0]) == ref.success and np.abs(res.x[0] - ref.x).max() < 1e-5
+    assert res.admm_iters[0] < 20000
