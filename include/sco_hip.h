@@ -81,9 +81,9 @@ typedef struct sco_qp_settings {
                                1: OSQP's rho update -- every adaptive_rho_interval iterations, after the termination
                                test, rho <- rho sqrt(normalised primal / normalised dual residual) clipped to
                                [1e-6, 1e6], taken when it leaves [rho / tol, rho tol]; the reduced system is then
-                               refactored and the solve resumes from its iterates.  Runs on the on-chip tiers (the
-                               solve is parked and resumed around every update); the global-memory tier answers
-                               SCO_ERR_CAPACITY.  Not part of parity mode.  */
+                               refactored and the solve resumes from its iterates (the solve is parked and resumed
+                               around every update).  Runs on the on-chip tiers and on the structured form of the
+                               global-memory tier; its dense form answers SCO_ERR_CAPACITY.  Not part of parity mode.  */
   int adaptive_rho_interval;/* 0 = 4 x check_termination (OSQP's value when it does not time itself: 100)         */
   double adaptive_rho_tolerance; /* OSQP default 5                                                                  */
 } sco_qp_settings;
@@ -171,7 +171,8 @@ typedef struct sco_sqp_params {
                                the solution of its previous one (sco_qp_settings.warm_start); beyond parity   */
   int admm_slice;           /* scheduling only, results are bit-identical: ADMM iterations per device launch.
                                Problems whose QP ends inside a slice go on to their next QP while the others
-                               continue (no waiting for the slowest QP of a round).  0 = default (6250),
+                               continue (no waiting for the slowest QP of a round).  0 = default (6250; 2000
+                               with adaptive rho; off when the batch has at most one problem per CU),
                                < 0 = off (one launch per QP, lock-step rounds)                               */
 } sco_sqp_params;
 

@@ -992,7 +992,12 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   // problem whose QP ended goes through post / pre / setup and joins the next launch with its next QP
   // default slice: 6250 iterations (7-DOF x 20: 964 ms per 1024-batch step against 1106 unsliced); with adaptive rho
   // the QPs are short and every rho change costs its problem a relaunch, so the slice is shorter (scripts/gpu_adaptive_slice_sweep.py)
-  const int slice_req = params->admm_slice < 0 ? 0 : (params->admm_slice > 0 ? params->admm_slice : (qs->adaptive_rho ? 2000 : 6250));
+  int slice_req = params->admm_slice < 0 ? 0 : (params->admm_slice > 0 ? params->admm_slice : (qs->adaptive_rho ? 2000 : 6250));
+  if (params->admm_slice == 0) {
+    // with at most one problem per CU there is nobody to hand a CU to: slicing would only add relaunches
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && s.batch <= cus) slice_req = 0;
+  }
   SCO_HIP(hipMemsetAsync(h->qp1->d.prog, 0, (size_t)s.batch * sizeof(int), h->stream));
   long long slices_per_qp = slice_req > 0 ? (qsl.max_iter + slice_req - 1) / slice_req : 1;
   if (qsl.adaptive_rho) slices_per_qp += qsl.max_iter / sco_qp_adaptive_interval(&qsl) + 1;    // a launch per rho change at most
