@@ -140,3 +140,49 @@ if __name__ == "__main__":
     for base in (6250, 12500):
         for mult, lpt in ((2, False), (2, True), (3, True), (4, True), (4, False)):
             print("catch-up base", base, "mult", mult, "lpt", lpt, "-> %.0f ms, %d rounds" % simulate_catchup(chains, base, mult, lpt))
+
+
+def simulate_queue(chains, base, K):
+    """Device-side queue inside a launch: every active problem may run up to K slices per launch; a CU that becomes
+    free takes the next ready slice (a problem's next slice is ready when its previous one has finished); a problem
+    whose QP ends leaves the launch (post / pre / setup happen between launches)."""
+    B = len(chains)
+    qi = [0] * B
+    left = [c[0] for c in chains]
+    active = set(range(B))
+    t = 0.0; rounds = 0
+    while active:
+        # event simulation of one launch
+        ready = [(0.0, b) for b in sorted(active)]          # (time the problem becomes ready, problem)
+        heapq.heapify(ready)
+        cus = [0.0] * CUS
+        heapq.heapify(cus)
+        done_slices = {b: 0 for b in active}
+        end = 0.0
+        finished_qp = []
+        while ready:
+            rt, b = heapq.heappop(ready)
+            cu = heapq.heappop(cus)
+            start = max(rt, cu)
+            it = min(base, left[b])
+            fin = start + it * US_PER_IT
+            heapq.heappush(cus, fin)
+            end = max(end, fin)
+            left[b] -= it; done_slices[b] += 1
+            if left[b] <= 0:
+                finished_qp.append(b)
+            elif done_slices[b] < K:
+                heapq.heappush(ready, (fin, b))
+        t += end + ROUND_OVERHEAD
+        rounds += 1
+        for b in finished_qp:
+            qi[b] += 1
+            if qi[b] >= len(chains[b]): active.discard(b)
+            else: left[b] = chains[b][qi[b]]
+    return t, rounds
+
+
+if __name__ == "__main__":
+    for base in (6250, 3125, 1500):
+        for K in (1, 2, 4, 8, 16):
+            print("queue base", base, "K", K, "-> %.0f ms, %d rounds" % simulate_queue(chains, base, K))
