@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="problems per GPU (default 1024; 256 for 12x50)")
     ap.add_argument("--workload", choices=["7x20", "12x50"], default="7x20",
                     help="7x20 = BASELINE configs[2] (headline); 12x50 = configs[4] shape (structured global-memory tier)")
-    ap.add_argument("--cpu-problems", type=int, default=8, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-problems", type=int, default=16, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--intended", action="store_true",
                     help="disable reference quirks Q1/Q2 (NOT the headline number)")
     ap.add_argument("--beyond", action="store_true",
@@ -141,7 +141,7 @@ def main():
     big = args.workload == "12x50"
     dims = dict(d=12, T=50, K=10, O=10) if big else dict(d=7, T=20, K=5, O=2)
     B = args.batch if args.batch is not None else (256 if big else 1024)
-    if big and args.cpu_problems == 8:
+    if big and args.cpu_problems == 16:
         args.cpu_problems = 0          # one 12x50 oracle solve takes minutes (tests/golden/make_big_oracle.py)
     total = B * world
     lo, hi = sd.shard_range(total, rank, world)
