@@ -197,6 +197,9 @@ void sco_sqp_default_params(sco_sqp_params *p);
                                   |theta[t+1][j] - theta[t][j]| <= vmax as LINEAR inequality rows
                                   (LEqExpr on an AffExpr: they go straight into every QP, the projection
                                   QP included, prob.py:126-131, 317-346); vmax via sco_sqp_load_vel_limit */
+#define SCO_FAM_FLAG_JOINT_LIMITS 32 /* OR-ed into `family`: joint limits lo_j <= theta[t][j] <= hi_j at every
+                                  timestep as two more LINEAR inequality blocks (theta <= hi, then -theta <= -lo,
+                                  after the velocity rows); lo, hi via sco_sqp_load_joint_limits */
 
 typedef struct sco_trajopt_desc {
   int batch;
@@ -231,6 +234,8 @@ int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, const double
 int sco_sqp_load_target(sco_sqp *h, const double *target);
 /* SCO_FAM_FLAG_VEL_LIMITS only, after sco_sqp_load: vmax[batch] > 0, one limit per problem. */
 int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax);
+/* SCO_FAM_FLAG_JOINT_LIMITS only, after sco_sqp_load: lo[batch][dof] < hi[batch][dof]. */
+int sco_sqp_load_joint_limits(sco_sqp *h, const double *lo, const double *hi);
 
 /* Constraint groups (prob.add_cnt_expr(bound_expr, group_ids), prob.py:112-142): n_groups <= 32 group ids
  * in SORTED order (the reference sorts them, prob.py:538, 559); block_mask[n_blocks], n_blocks = horizon

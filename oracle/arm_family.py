@@ -94,6 +94,12 @@ def velocity_rows(d, T):
     return np.vstack([D, -D])
 
 
+def joint_limit_rows(d, T):
+    """(2 d T, d T): +I (theta <= hi), then -I (-theta <= -lo)."""
+    eye = np.eye(d * T)
+    return np.vstack([eye, -eye])
+
+
 def default_points(d, K):
     """K link points spread over the links: point k sits at the END of link
     (k * d) // K ... evenly, fraction 1.0 for the last point of a link."""
@@ -123,7 +129,7 @@ def block_groups(T, reach, scheme):
     return g
 
 
-def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None):
+def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None):
     """Seeded problem i of the batch.  reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
@@ -150,6 +156,12 @@ def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, v
         # joint-velocity limits |theta[t+1][j] - theta[t][j]| <= vmax: LINEAR inequalities, i.e.
         # LEqExpr(AffExpr) rows that go straight into every QP (prob.py:126-131, 317-346)
         out["vmax"] = float(vel_limit)
+    if joint_limit is not None:
+        # joint limits lo_j <= theta[t][j] <= hi_j for every timestep: two more LEqExpr(AffExpr) blocks.  The box
+        # hugs the straight line between start and goal (margin `joint_limit`), so that avoiding the obstacles
+        # runs into it.
+        out["jlo"] = np.minimum(start, goal) - float(joint_limit)
+        out["jhi"] = np.maximum(start, goal) + float(joint_limit)
     return out
 
 
@@ -162,6 +174,8 @@ def make_batch(B, first=0, **kw):
         extra["groups"] = p0["groups"]
     if p0.get("vmax") is not None:
         extra["vmax"] = np.array([p["vmax"] for p in probs])
+    if p0.get("jlo") is not None:
+        extra["jlo"] = np.stack([p["jlo"] for p in probs]); extra["jhi"] = np.stack([p["jhi"] for p in probs])
     return dict(
         d=p0["d"], T=p0["T"], K=p0["K"], O=p0["O"], B=B, **extra,
         x0=np.stack([p["x0"] for p in probs]),

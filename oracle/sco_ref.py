@@ -386,6 +386,10 @@ def trajopt_flat(prob, analytic_jac=False):
         lin = sp.vstack([lin.tocsr(), sp.csr_matrix(V)]).tolil()
         lin_lo = np.concatenate([rhs, np.full(V.shape[0], -np.inf)])
         lin_hi = np.concatenate([rhs, np.full(V.shape[0], prob["vmax"])])
+    if prob.get("jlo") is not None:                # joint limits: theta <= hi, then -theta <= -lo, every timestep
+        lin = sp.vstack([lin.tocsr(), sp.csr_matrix(af.joint_limit_rows(d, T))]).tolil()
+        lin_lo = np.concatenate([lin_lo, np.full(2 * n_x, -np.inf)])
+        lin_hi = np.concatenate([lin_hi, np.tile(prob["jhi"], T), -np.tile(prob["jlo"], T)])
     blocks = []
     R = prob["K"] * prob["O"]
     for t in range(T):

@@ -52,10 +52,12 @@ struct SqpDev {
   // SCO_FAM_ARM_REACH: NE = 2 equality rows (end-effector x, y) on the last timestep, block index T;
   // NB = number of constraint blocks (T or T + 1), RM = widest block (history strides)
   int NE, NB, RM;
-  // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows
-  int m_pin, m_vel;
+  // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows, then m_jl joint-limit
+  // rows (theta <= hi for every trajectory variable, then -theta <= -lo)
+  int m_pin, m_vel, m_jl;
   const double *a0c, *a1c;      // constant parts of the A values of the projection / penalty QP (shared)
   double *vmax;                 // [B]
+  double *jlo, *jhi;            // [B][d]
   // problem data
   double *x0, *start, *goal, *link_len, *obstacles, *target;   // [B][...]
   const int *point_link; const double *point_frac;    // [K]
@@ -90,7 +92,7 @@ struct sco_sqp {
   hipStream_t stream = nullptr;
   std::vector<void *> allocs;
   std::vector<hipEvent_t> events;
-  bool loaded = false, solved = false, target_loaded = false, vel_loaded = false;
+  bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   int rounds = 0;
 };
@@ -241,6 +243,15 @@ __device__ __forceinline__ double traj_obj_partial(const double *x, int d, int T
   return s;
 }
 
+// upper bound of linear inequality row i (m_pin <= i < m_lin): velocity rows, then theta <= hi, then -theta <= -lo
+// (prob.py:329-338: lb = -inf, ub = val - b)
+__device__ __forceinline__ double lin_ineq_hi(const SqpDev &s, int b, int i) {
+  const int v = i - s.m_pin;
+  if (v < s.m_vel) return s.vmax[b];
+  const int k = v - s.m_vel;
+  return k < s.n_x ? s.jhi[(size_t)b * s.d + k % s.d] : -s.jlo[(size_t)b * s.d + (k - s.n_x) % s.d];
+}
+
 // --------------------------------------------------------------------------
 // round 0: projection QP values  (prob.py:369-412)
 //   P_ii = 2 c, q_i = -2 c x0_i  (c = number of Variables holding atom i),
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
     double lo, hi;
     if (i < d) lo = hi = s.start[(size_t)b * d + i];
     else if (i < s.m_pin) lo = hi = s.goal[(size_t)b * d + (i - d)];
-    else if (i < s.m_lin) { lo = -INFINITY; hi = s.vmax[b]; }      // prob.py:329-338: lb = -inf, ub = val - b
+    else if (i < s.m_lin) { lo = -INFINITY; hi = lin_ineq_hi(s, b, i); }
     else { lo = -INFINITY; hi = INFINITY; }
     q0.l[(size_t)b * m0 + i] = lo; q0.u[(size_t)b * m0 + i] = hi;
     q0.w[(size_t)b * m0 + i] = 1;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
       double lo, hi;
       if (i < d) lo = hi = s.start[(size_t)b * d + i];
       else if (i < s.m_pin) lo = hi = s.goal[(size_t)b * d + (i - d)];
-      else if (i < s.m_lin) { lo = -INFINITY; hi = s.vmax[b]; }
+      else if (i < s.m_lin) { lo = -INFINITY; hi = lin_ineq_hi(s, b, i); }
       else if (i < s.m_lin + s.T * s.R) { lo = -INFINITY; hi = 0.0; }
       else if (i < s.m_lin + s.m_nl) { lo = 0.0; hi = 0.0; }              // equality rows: set by convexify
       else if (i < s.m_lin + s.m_nl + n_x) { lo = -INFINITY; hi = INFINITY; }
@@ -707,7 +718,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
 extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
   if (!desc || !out) { sco_set_error("sco_sqp_create: null pointer"); return SCO_ERR_ARG; }
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
-      desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS)) ||
+      desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS)) ||
       ((desc->family & 15) != SCO_FAM_ARM_CIRCLES && (desc->family & 15) != SCO_FAM_ARM_REACH)) {
     sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
   }
@@ -731,9 +742,11 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   SCO_HIP(hipStreamCreate(&h->stream));
   const int B = desc->batch, d = desc->dof, T = desc->horizon, K = desc->n_points, O = desc->n_obstacles;
   const bool reach = (desc->family & 15) == SCO_FAM_ARM_REACH, vel = (desc->family & SCO_FAM_FLAG_VEL_LIMITS) != 0;
+  const bool jl = (desc->family & SCO_FAM_FLAG_JOINT_LIMITS) != 0;
   const int NE = reach ? 2 : 0;                  // equality rows (end-effector x, y) on the last timestep
   const int m_pin = reach ? d : 2 * d, dT1 = d * (T - 1), m_vel = vel ? 2 * dT1 : 0;
-  const int R = K * O, n_x = d * T, n_slack = T * R + 2 * NE, n = n_x + n_slack, m_lin = m_pin + m_vel;
+  const int m_jl = jl ? 2 * d * T : 0;
+  const int R = K * O, n_x = d * T, n_slack = T * R + 2 * NE, n = n_x + n_slack, m_lin = m_pin + m_vel + m_jl;
   const int m_nl = T * R + NE, m = m_lin + m_nl + n;
   // linear rows of column (t, j), ascending: pin, velocity rows "theta[t] - theta[t-1] <= vmax" (+1),
   // "theta[t+1] - theta[t] <= vmax" (-1), then the two negated rows
@@ -745,6 +758,10 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
       if (t <= T - 2) { Ai.push_back(m_pin + t * d + j); Av.push_back(-1.0); }
       if (t >= 1) { Ai.push_back(m_pin + dT1 + (t - 1) * d + j); Av.push_back(-1.0); }
       if (t <= T - 2) { Ai.push_back(m_pin + dT1 + t * d + j); Av.push_back(1.0); }
+    }
+    if (jl) {
+      Ai.push_back(m_pin + m_vel + t * d + j); Av.push_back(1.0);
+      Ai.push_back(m_pin + m_vel + d * T + t * d + j); Av.push_back(-1.0);
     }
   };
   std::vector<double> a0c, a1c;
@@ -803,11 +820,11 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   s.batch = B; s.d = d; s.T = T; s.K = K; s.O = O; s.R = R; s.n_x = n_x; s.n_slack = n_slack; s.n = n;
   s.m_lin = m_lin; s.m_nl = m_nl; s.m = m; s.prox_count = desc->prox_count > 0 ? desc->prox_count : 1;
   s.analytic_jac = desc->analytic_jac; s.trace_cap = 64;
-  s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE); s.m_pin = m_pin; s.m_vel = m_vel;
+  s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE); s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl;
   int rc = 0;
 #define AL(f, cnt) if ((rc = sq_alloc(h, (cnt), &s.f))) return rc;
   AL(x0, (size_t)B * n_x) AL(start, (size_t)B * d) AL(goal, (size_t)B * d) AL(link_len, (size_t)B * d)
-  AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2) AL(vmax, (size_t)B)
+  AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2) AL(vmax, (size_t)B) AL(jlo, (size_t)B * d) AL(jhi, (size_t)B * d)
   AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
   AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
   AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, 1) AL(newqp, (size_t)B)
@@ -895,6 +912,21 @@ extern "C" int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax) {
   return SCO_OK;
 }
 
+extern "C" int sco_sqp_load_joint_limits(sco_sqp *h, const double *lo, const double *hi) {
+  if (!h || !lo || !hi) { sco_set_error("sco_sqp_load_joint_limits: null pointer"); return SCO_ERR_ARG; }
+  if (!(h->desc.family & SCO_FAM_FLAG_JOINT_LIMITS)) { sco_set_error("sco_sqp_load_joint_limits: family has no joint limits"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_load_joint_limits: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  const size_t cnt = (size_t)h->d.batch * h->d.d;
+  for (size_t k = 0; k < cnt; k++)
+    if (!(lo[k] < hi[k])) { sco_set_error("sco_sqp_load_joint_limits: need lo < hi"); return SCO_ERR_ARG; }
+  SCO_HIP(hipSetDevice(h->device));
+  SCO_HIP(hipMemcpyAsync(h->d.jlo, lo, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync(h->d.jhi, hi, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipStreamSynchronize(h->stream));
+  h->jl_loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
 extern "C" int sco_sqp_set_groups(sco_sqp *h, int n_groups, const unsigned int *block_mask) {
   if (!h || !block_mask) { sco_set_error("sco_sqp_set_groups: null pointer"); return SCO_ERR_ARG; }
   if (n_groups < 1 || n_groups > 32) { sco_set_error("sco_sqp_set_groups: 1..32 groups"); return SCO_ERR_ARG; }
@@ -948,6 +980,9 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   }
   if ((h->desc.family & SCO_FAM_FLAG_VEL_LIMITS) && !h->vel_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_vel_limit first"); return SCO_ERR_STATE;
+  }
+  if ((h->desc.family & SCO_FAM_FLAG_JOINT_LIMITS) && !h->jl_loaded) {
+    sco_set_error("sco_sqp_solve: call sco_sqp_load_joint_limits first"); return SCO_ERR_STATE;
   }
   SCO_HIP(hipSetDevice(h->device));
   SqpDev &s = h->d;

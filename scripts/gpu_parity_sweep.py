@@ -7,10 +7,11 @@ from oracle import arm_family as af, sco_ref as sr
 
 MODE = sys.argv[3] if len(sys.argv) > 3 else "parity"          # parity | intended (quirks off, at most 20 QPs)
 KW = {}
-for tok in sys.argv[4:]:                                         # reach, vel, groups
+for tok in sys.argv[4:]:                                         # reach, vel, groups, jl
     if tok == "reach": KW["reach"] = True
     if tok == "vel": KW["vel_limit"] = 0.4
     if tok == "groups": KW["groups"] = "split"
+    if tok == "jl": KW["joint_limit"] = 0.2
 
 
 def ref_one(i):

@@ -20,7 +20,7 @@ def _declared_functions():
 def test_header_declares_the_expected_entry_points():
     names = _declared_functions()
     for must in ("sco_qp_create", "sco_qp_load", "sco_qp_set_bounds", "sco_qp_solve", "sco_qp_adaptive_info", "sco_sqp_create",
-                 "sco_sqp_load", "sco_sqp_load_target", "sco_sqp_load_vel_limit", "sco_sqp_set_groups", "sco_sqp_fetch_groups", "sco_sqp_fetch_flags", "sco_sqp_last_rounds", "sco_sqp_solve", "sco_sqp_fetch", "sco_sqp_trace"):
+                 "sco_sqp_load", "sco_sqp_load_target", "sco_sqp_load_vel_limit", "sco_sqp_load_joint_limits", "sco_sqp_set_groups", "sco_sqp_fetch_groups", "sco_sqp_fetch_flags", "sco_sqp_last_rounds", "sco_sqp_solve", "sco_sqp_fetch", "sco_sqp_trace"):
         assert must in names
 
 

@@ -241,3 +241,51 @@ def test_mirror_api_reproduces_reference_with_linear_inequality_rows(oracle_qp_b
         assert [a["status"] for a in gold] == [r["status"] for r in oracle_qp_backend]
         assert ok == bool(g[prefix + "success"])
         assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 1e-9
+
+
+def _jl_cases():
+    import sys
+    sys.path.insert(0, GOLD)
+    from jl_cases import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("case", _jl_cases(), ids=lambda c: c[0])
+def test_flat_oracle_reproduces_reference_with_joint_limits(case):
+    """Joint limits lo <= theta[t] <= hi as two LEqExpr(AffExpr) blocks (theta <= hi, -theta <= -lo), alone, with
+    velocity limits and with the reach equality: every QP the reference assembled, its statuses, iteration
+    counts and answer."""
+    prefix, kw, i = case
+    g = np.load(os.path.join(GOLD, "trajopt_jl.npz"))
+    pr = af.make_problem(i, **kw)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr), record_qps=True)
+    _compare_sequence(ct.load_golden_qps(g, prefix), out.qps, prefix)
+    assert out.success == bool(g[prefix + "success"])
+    assert np.abs(out.x - g[prefix + "x"]).max() < 1e-9
+    assert abs(out.max_violation - float(g[prefix + "max_violation"])) < 1e-9
+    x = np.asarray(g[prefix + "x"]).reshape(kw["T"], kw["d"])
+    assert np.all(x <= pr["jhi"] + 1e-5) and np.all(x >= pr["jlo"] - 1e-5)          # the answer respects the box
+
+
+def test_joint_limits_are_active_in_the_golden_runs():
+    g = np.load(os.path.join(GOLD, "trajopt_jl.npz"))
+    active = 0
+    for prefix, kw, i in _jl_cases():
+        pr = af.make_problem(i, **kw)
+        x = np.asarray(g[prefix + "x"]).reshape(kw["T"], kw["d"])
+        active += int(np.sum(np.minimum(pr["jhi"] - x, x - pr["jlo"]) < 1e-4))
+    assert active >= 8                     # 9 entries sit on their limit
+
+
+def test_mirror_api_reproduces_reference_with_joint_limits(oracle_qp_backend):
+    g = np.load(os.path.join(GOLD, "trajopt_jl.npz"))
+    for prefix, kw, i in _jl_cases()[:2] + _jl_cases()[5:6]:
+        del oracle_qp_backend[:]
+        mods = ct.mirror_mods()
+        prob, traj, _, _ = tb.build_prob(mods, af.make_problem(i, **kw))
+        ok = mods.Solver().solve(prob, method="penalty_sqp")
+        gold = ct.load_golden_qps(g, prefix)
+        assert [a["iters"] for a in gold] == [r["iters"] for r in oracle_qp_backend]
+        assert [a["status"] for a in gold] == [r["status"] for r in oracle_qp_backend]
+        assert ok == bool(g[prefix + "success"])
+        assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 1e-9

@@ -493,3 +493,70 @@ def test_12dof_50step_with_adaptive_rho_follows_the_oracle(gpu):
     assert np.array_equal(tr[:, 6:8], rt[:, 6:8]), (tr[:, 6:8], rt[:, 6:8])
     assert bool(res.success[0]) == ref.success and np.abs(res.x[0] - ref.x).max() < 1e-5
     assert res.admm_iters[0] < 20000
+
+
+def test_joint_limits_match_oracle(gpu):
+    """SCO_FAM_FLAG_JOINT_LIMITS: lo <= theta[t] <= hi as linear inequality rows in every QP (the projection QP
+    included), alone and together with velocity limits, the reach equality and constraint groups."""
+    for kw in (dict(joint_limit=0.3), dict(joint_limit=0.05), dict(joint_limit=0.3, vel_limit=0.6),
+               dict(joint_limit=0.3, reach=True, groups="split")):
+        arrays, probs = af.make_batch(6, d=3, T=6, K=2, O=2, **kw)
+        res = sb.solve_batch(arrays)
+        _compare(res, probs, range(6))
+        x = res.x.reshape(6, 6, 3)
+        ok = res.qp_solves > 1                      # problems whose projection QP was feasible
+        assert np.all(x[ok] <= arrays["jhi"][ok][:, None, :] + 1e-4) and np.all(x[ok] >= arrays["jlo"][ok][:, None, :] - 1e-4)
+
+
+def test_joint_limits_match_reference_golden_runs(gpu):
+    import sys
+    sys.path.insert(0, GOLD)
+    from jl_cases import CASES
+    g = np.load(os.path.join(GOLD, "trajopt_jl.npz"))
+    for prefix, kw, i in CASES:
+        arrays, _ = af.make_batch(1, first=i, **kw)
+        res = sb.solve_batch(arrays)
+        assert np.abs(res.x[0] - g[prefix + "x"]).max() < TOL, prefix
+        assert bool(res.success[0]) == bool(g[prefix + "success"]), prefix
+        nq = int(g[prefix + "n_qp"])
+        assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix
+        assert [int(v) for v in res.trace[0][:, 7]] == [int(g["%sqp%d_iters" % (prefix, k)]) for k in range(nq)], prefix
+
+
+def test_joint_limits_7x20_batch_and_validation(gpu):
+    arrays, probs = af.make_batch(4, joint_limit=0.2)
+    res = sb.solve_batch(arrays)
+    _compare(res, probs, range(2))
+    arrays, probs = af.make_batch(2, joint_limit=0.2, vel_limit=0.3)        # 18 rows per column: beyond the row-local tier
+    _compare(sb.solve_batch(arrays), probs, range(1))
+    with sb.TrajOptBatch(1, 3, 6, 2, 2, joint_limits=True) as tb:
+        a = af.make_batch(1, d=3, T=6, K=2, O=2, joint_limit=0.5)[0]
+        with pytest.raises(ValueError):
+            tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"])
+        tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
+                jlo=a["jlo"], jhi=a["jhi"])
+        with pytest.raises(_lib.ScoHipError) as e:
+            tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
+                    jlo=a["jhi"], jhi=a["jlo"])                           # lo >= hi
+        assert e.value.code == -1
+    with sb.TrajOptBatch(1, 3, 6, 2, 2) as tb:
+        with pytest.raises(_lib.ScoHipError) as e:                           # no joint limits in this family
+            _lib.check(_lib.load().sco_sqp_load_joint_limits(tb._h, _lib.dptr(np.zeros((1, 3))), _lib.dptr(np.ones((1, 3)))))
+        assert e.value.code == -1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_feature_mixes_with_joint_limits(gpu, seed):
+    rng = np.random.default_rng(5000 + seed)
+    d, T, K, O = int(rng.integers(1, 6)), int(rng.integers(2, 9)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    kw = dict(d=d, T=T, K=K, O=O, reach=bool(rng.integers(2)), joint_limit=float(rng.uniform(0.05, 0.6)))
+    if rng.integers(2):
+        kw["vel_limit"] = float(rng.uniform(0.4, 1.5))
+    if rng.integers(2):
+        kw["groups"] = ["halves", "split"][int(rng.integers(2))]
+    knobs = dict(compound_penalty=int(rng.integers(2)), duplicate_rows=int(rng.integers(2)))
+    arrays, probs = af.make_batch(3, first=int(rng.integers(0, 50)), **kw)
+    res = sb.solve_batch(arrays, params=_lib.default_sqp_params(max_sqp_iters=40, **knobs))
+    op = sr.SolverParams(compound_penalty=bool(knobs["compound_penalty"]), duplicate_rows=bool(knobs["duplicate_rows"]),
+                         max_qp_solves=40)
+    _compare(res, probs, range(3), op)

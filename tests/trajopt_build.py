@@ -46,6 +46,13 @@ def build_prob(mods, pr, analytic_jac=False):
         prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(mods.AffExpr(V, np.zeros((V.shape[0], 1))),
                                                       np.full((V.shape[0], 1), pr["vmax"])), traj))
 
+    if pr.get("jlo") is not None:
+        eye = np.eye(n_x)
+        prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(mods.AffExpr(eye, np.zeros((n_x, 1))),
+                                                      np.tile(pr["jhi"], T).reshape(-1, 1)), traj))
+        prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(mods.AffExpr(-eye, np.zeros((n_x, 1))),
+                                                      -np.tile(pr["jlo"], T).reshape(-1, 1)), traj))
+
     R = pr["K"] * pr["O"]
     step_vars = []
     for t in range(T):
