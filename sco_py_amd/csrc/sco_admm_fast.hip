@@ -57,7 +57,7 @@ void build_sell(int nitems, const std::vector<int> &ptr, const std::vector<int> 
 }
 
 bool fast_plan_build(const QpPlan &pl, FastHost &fh) {
-  if (pl.n > FT || pl.m > 2 * FT || pl.nnzA >= 65536 || pl.n_c > 32 * 5) return false;
+  if (pl.n > FT || pl.m > 3 * FT || pl.nnzA >= 65536 || pl.n_c > 32 * 5) return false;
   std::vector<int> ident(std::max(pl.nnzA, pl.ncpl) + 1);
   for (size_t i = 0; i < ident.size(); i++) ident[i] = (int)i;
   build_sell(pl.n, pl.Ap, pl.Ai, ident, fh.Ac);                       // A by column: idx = row, src = CSC position
@@ -148,7 +148,7 @@ __device__ __forceinline__ double sell_dot(const SellLds &s, const double *vec) 
 
 struct FastRow { double ls, us, rho, z, y, w; SellLds ar; int i; bool on; };
 
-template <int TR, int TC, int CW, int RW, int PA, int PE>
+template <int TR, int TC, int CW, int RW, int PA, int PE, int NQ>
 __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f) {
   constexpr int PS = GI * TR + 1;            // padded row stride of the partial-sum slab
   const QpDev &d = a.d;
@@ -214,10 +214,10 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
   int cvar = 0;
   SellLds ca{VCa, ICa, 0, 0};
   if (coreon) { cvar = d.core_var[tid]; ca.off = f.Ca.base[tid >> 6] + lane; ca.width = f.Ca.width[tid >> 6]; }
-  // ---- private row state (rows tid and tid + FT) -------------------------------------
-  FastRow R[2];
+  // ---- private row state (rows tid, tid + FT and, NQ = 3, tid + 2 FT) ----------------
+  FastRow R[NQ];
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
+  for (int q = 0; q < NQ; q++) {
     const int i = tid + q * FT;
     R[q].on = i < m; R[q].i = R[q].on ? i : 0;
     R[q].ls = R[q].us = R[q].z = R[q].y = 0.0; R[q].rho = 1.0; R[q].w = 1.0;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
     __syncthreads();
     // (5) z~ = A x~, then z / y / x updates and next iteration's t
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < NQ; q++) {
       if (R[q].on) {
         const double zt = sell_dot<RW>(R[q].ar, xt);
         const double rho = R[q].rho, rinv = 1.0 / rho;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
       if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
       double v[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int q = 0; q < 2; q++)
+      for (int q = 0; q < NQ; q++)
         if (R[q].on) {
           const double ax = sell_dot<RW>(R[q].ar, sx);
           const double ei = 1.0 / Eg[R[q].i];
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
       if (!prim_ok) {           // primal infeasibility certificate from delta_y
         double r1[1] = {0.0};
 #pragma unroll
-        for (int q = 0; q < 2; q++)
+        for (int q = 0; q < NQ; q++)
           if (R[q].on) {
             double dy = sdy[R[q].i];
             if (R[q].us > SCO_INFTY * SCO_MIN_SCALING) {
@@ -345,21 +345,21 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
         if (ndy > epi) {
           double lhs[1] = {0.0};
 #pragma unroll
-          for (int q = 0; q < 2; q++)
+          for (int q = 0; q < NQ; q++)
             if (R[q].on) { const double dy = sdy[R[q].i]; lhs[0] += R[q].w * (R[q].us * fmax(dy, 0.0) + R[q].ls * fmin(dy, 0.0)); }
           fblock_reduce<1, false>(lhs, red);
           if (lhs[0] < -epi * ndy) {
             // A'(w dy): reuse swy as the weighted vector
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 2; q++) if (R[q].on) swy[R[q].i] = R[q].w * sdy[R[q].i];
+            for (int q = 0; q < NQ; q++) if (R[q].on) swy[R[q].i] = R[q].w * sdy[R[q].i];
             __syncthreads();
             double nat[1] = {0.0};
             if (colon) nat[0] = fabs(sell_dot<CW>(ac, swy) / Dg[j]);
             fblock_reduce<1, true>(nat, red);
             // restore w*y for a possible second (approximate) pass
 #pragma unroll
-            for (int q = 0; q < 2; q++) if (R[q].on) swy[R[q].i] = R[q].w * R[q].y;
+            for (int q = 0; q < NQ; q++) if (R[q].on) swy[R[q].i] = R[q].w * R[q].y;
             __syncthreads();
             if (nat[0] < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
           }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
             if (npx[0] < cscale * edi * ndx) {
               double bad[1] = {0.0};
 #pragma unroll
-              for (int q = 0; q < 2; q++)
+              for (int q = 0; q < NQ; q++)
                 if (R[q].on) {
                   const double adx = sell_dot<RW>(R[q].ar, sdx) / Eg[R[q].i];
                   if ((R[q].us < SCO_INFTY * SCO_MIN_SCALING && adx > edi * ndx) ||
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
     const double cinv = 1.0 / cscale;
     if (colon) d.x[(size_t)b * n + j] = Dg[j] * xj;
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NQ; q++)
       if (R[q].on) d.y[(size_t)b * m + R[q].i] = cinv * Eg[R[q].i] * R[q].y * R[q].w;
     if (tid == 0) {
       d.status[b] = status; d.iters[b] = iter;
@@ -451,7 +451,7 @@ int fast_upload(const FastHost &fh, std::vector<void *> &allocs, FastDev &fd) {
   return SCO_OK;
 }
 
-template <int TR, int TC, int CW, int RW, int PA, int PE>
+template <int TR, int TC, int CW, int RW, int PA, int PE, int NQ>
 static int launch_one(const AdmmArgs &a, const FastDev &fd, size_t lds, hipStream_t st) {
   // hipFuncSetAttribute applies to the current device only
   static bool attr_done[64] = {};
@@ -459,19 +459,21 @@ static int launch_one(const AdmmArgs &a, const FastDev &fd, size_t lds, hipStrea
   (void)hipGetDevice(&dev_);
   dev_ &= 63;
   if (!attr_done[dev_]) {
-    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_fast_kernel<TR, TC, CW, RW, PA, PE>,
+    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_fast_kernel<TR, TC, CW, RW, PA, PE, NQ>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev_] = true;
   }
-  hipLaunchKernelGGL((qp_admm_fast_kernel<TR, TC, CW, RW, PA, PE>), dim3(a.d.batch), dim3(FT), lds, st, a, fd);
+  hipLaunchKernelGGL((qp_admm_fast_kernel<TR, TC, CW, RW, PA, PE, NQ>), dim3(a.d.batch), dim3(FT), lds, st, a, fd);
   SCO_HIP(hipGetLastError());
   return SCO_OK;
 }
 
 template <int TR, int TC>
 static int launch_tile(const AdmmArgs &a, const FastHost &fh, const FastDev &fd, hipStream_t st) {
-  if (fh.capped) return launch_one<TR, TC, 12, 8, 12, 8>(a, fd, fh.lds_bytes, st);
-  return launch_one<TR, TC, 0, 0, 0, 0>(a, fd, fh.lds_bytes, st);
+  // more than 2 x 512 rows: three rows per thread (looping dots only: patterns this large have wide columns anyway)
+  if (a.d.m > 2 * FT) return launch_one<TR, TC, 0, 0, 0, 0, 3>(a, fd, fh.lds_bytes, st);
+  if (fh.capped) return launch_one<TR, TC, 12, 8, 12, 8, 2>(a, fd, fh.lds_bytes, st);
+  return launch_one<TR, TC, 0, 0, 0, 0, 2>(a, fd, fh.lds_bytes, st);
 }
 
 int fast_launch(const AdmmArgs &a, const FastHost &fh, const FastDev &fd, hipStream_t st) {

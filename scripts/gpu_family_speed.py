@@ -1,0 +1,20 @@
+"""7x20, B = 1024, parity mode: SCO it/s of the device families / flags (which ADMM tier each pattern lands on)."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import arm_family as af
+from sco_py_amd import batch as sb, _lib
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+import os as _os
+ONLY = _os.environ.get("FAMILIES")
+for name, kw in (("circles", {}), ("reach", dict(reach=True)), ("vel", dict(vel_limit=0.3)), ("jl", dict(joint_limit=0.2)),
+                 ("vel+jl", dict(vel_limit=0.3, joint_limit=0.2)), ("reach+vel+jl", dict(reach=True, vel_limit=0.3, joint_limit=0.2))):
+    if ONLY and name not in ONLY.split(','):
+        continue
+    arrays, _ = af.make_batch(B, **kw)
+    res = sb.solve_batch(arrays)
+    t = time.time(); res = sb.solve_batch(arrays); dt = time.time() - t
+    tm = res.timing
+    print("%-14s wall %.2fs sco_it/s %.0f success %.3f admm iters/problem %.0f -> %.2f us per problem-iteration (admm %.0f ms, setup %.0f ms)" % (
+        name, dt, res.sqp_iters.sum() / dt, res.success.mean(), res.admm_iters.mean(),
+        1e3 * tm["admm_ms"] / (res.admm_iters.sum() / 256.0), tm["admm_ms"], tm["qp_setup_ms"]), flush=True)
