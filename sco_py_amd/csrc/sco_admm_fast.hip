@@ -155,6 +155,9 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (d.active && !d.active[b]) return;
   const int n = d.n, m = d.m, n_e = d.n_e, n_c = d.n_c;
+  // park / resume (time slicing, adaptive rho; see RlArgs in sco_admm_rl.hip): the loop carries x, z, y and
+  // t = w (rho z - y); a resumed solve reloads the first three and rebuilds t with the rho in force now
+  const int it0 = a.slice > 0 ? d.prog[b] : 0;
 
   extern __shared__ double lds[];
   double *VAc = lds;                    double *VAr = VAc + f.Ac.total;
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
   SellLds ac{VAc, IAc, 0, 0}, ce{VCe, ICe, 0, 0};
   if (colon) {
     qj = d.qs[(size_t)b * n + j];
+    if (it0 > 0) xj = d.sx[(size_t)b * n + j];
     ej = d.elim_of[j]; cj = d.core_of[j];
     if (ej >= 0) {
       kinv = d.kee_inv[(size_t)b * n_e + ej];
@@ -226,15 +230,23 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
       R[q].ls = d.ls[(size_t)b * m + i]; R[q].us = d.us[(size_t)b * m + i];
       R[q].rho = d.rho[(size_t)b * m + i]; R[q].w = (double)d.w[(size_t)b * m + i];
       R[q].ar.off = f.Ar.base[i >> 6] + lane; R[q].ar.width = f.Ar.width[i >> 6];
+      if (it0 > 0) { R[q].z = d.sz[(size_t)b * m + i]; R[q].y = d.sy[(size_t)b * m + i]; }
     }
   }
   const double cscale = d.cscale[b];
   const double alpha = a.alpha, sigma = a.sigma;
+  if (a.adaptive && tid == 0) { d.smask[b] = 0; d.rflag[b] = 0; }
   __syncthreads();
+  if (it0 > 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+      if (R[q].on) tv[R[q].i] = R[q].w * (R[q].rho * R[q].z - R[q].y);
+    __syncthreads();
+  }
 
   int status = 0, iter = 0;
   double pri = 0.0, dua = 0.0;
-  for (iter = 1; iter <= a.max_iter; iter++) {
+  for (iter = it0 + 1; iter <= a.max_iter; iter++) {
     const bool chk = (a.check > 0 && iter % a.check == 0) || iter == a.max_iter;
     // (1) rhs_j = sigma x_j - q_j + sum_i A_ij t_i ; eliminated part pre-scaled by 1/K_ee
     double gev = 0.0;
@@ -297,6 +309,8 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
     if (!chk) continue;
 
     // ---- termination test (same formulas as admm_check in sco_qp.hip) ----------------
+    const bool adapt_pt = a.adaptive && iter % a.ad_interval == 0 && iter < a.max_iter;
+    double vs[7] = {0, 0, 0, 0, 0, 0, 0};         // adaptive rho: the same norms of the SCALED iterates
     for (int approximate = 0; approximate < 2 && !status; approximate++) {
       if (approximate && iter < a.max_iter) break;
       const double *Ps = d.Ps + (size_t)b * d.nnzP;
@@ -313,6 +327,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
           v[0] = fmax(v[0], fabs(ei * (ax - R[q].z)));
           v[1] = fmax(v[1], fabs(ei * R[q].z));
           v[2] = fmax(v[2], fabs(ei * ax));
+          if (adapt_pt) { vs[0] = fmax(vs[0], fabs(ax - R[q].z)); vs[1] = fmax(vs[1], fabs(R[q].z)); vs[2] = fmax(vs[2], fabs(ax)); }
         }
       if (colon) {
         double px = 0.0;
@@ -320,6 +335,7 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
         const double aty = sell_dot<CW>(ac, swy);
         const double dj = 1.0 / Dg[j];
         v[3] = fabs(dj * (qj + px + aty)); v[4] = fabs(dj * qj); v[5] = fabs(dj * aty); v[6] = fabs(dj * px);
+        if (adapt_pt) { vs[3] = fabs(qj + px + aty); vs[4] = fabs(qj); vs[5] = fabs(aty); vs[6] = fabs(px); }
       }
       fblock_reduce<7, true>(v, red);
       pri = v[0]; dua = cinv * v[3];
@@ -400,7 +416,30 @@ __global__ __launch_bounds__(FT) void qp_admm_fast_kernel(AdmmArgs a, FastDev f)
     }
     __syncthreads();     // the scratch slab is reused by the next iteration's partial sums
     if (status) break;
+    double rho_new = 0.0;
+    if (adapt_pt) {
+      // OSQP's rho estimate (same rule as admm_rho_estimate in sco_qp.hip)
+      fblock_reduce<7, true>(vs, red);
+      const double rho = d.rho_b[b];
+      const double pn = vs[0] / (fmax(vs[1], vs[2]) + 1e-10);
+      const double dn = vs[3] / (fmax(vs[4], fmax(vs[5], vs[6])) + 1e-10);
+      const double est = fmin(fmax(rho * sqrt(pn / (dn + 1e-10)), SCO_RHO_MIN), 1e6);
+      if (est > rho * a.ad_tol || est < rho / a.ad_tol) rho_new = est;
+    }
+    if (iter < a.max_iter && (rho_new > 0.0 || (a.slice > 0 && iter == it0 + a.slice))) {
+      // rho must change or the slice is used up: park the solve
+      if (colon) d.sx[(size_t)b * n + j] = xj;
+#pragma unroll
+      for (int q = 0; q < NQ; q++)
+        if (R[q].on) { d.sz[(size_t)b * m + R[q].i] = R[q].z; d.sy[(size_t)b * m + R[q].i] = R[q].y; }
+      if (tid == 0) {
+        d.prog[b] = iter; d.status[b] = 0; d.iters[b] = iter;
+        if (rho_new > 0.0) { d.rho_b[b] = rho_new; d.rflag[b] = 1; d.smask[b] = 1; d.nupd[b] += 1; }
+      }
+      return;
+    }
   }
+  if (a.slice > 0 && tid == 0) d.prog[b] = 0;
   if (!status) { status = SCO_QP_MAX_ITER_REACHED; iter = a.max_iter; }
   if (iter > a.max_iter) iter = a.max_iter;
   // ---- unscale and store ------------------------------------------------------------

@@ -904,7 +904,10 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
       sco_set_error("adaptive_rho needs adaptive_rho_tolerance > 1 and check_termination > 0"); return SCO_ERR_ARG;
     }
   }
-  const bool can_park = qp->use_big ? qp->use_bt : (qp->use_rl || adaptive || !(qp->use_reg || qp->use_fast));
+  // kernel of the on-chip tiers: the register-offset kernel cannot park a solve; adaptive rho skips it
+  enum { K_RL, K_REG, K_FAST, K_GENERIC };
+  const int kern = qp->use_rl ? K_RL : (qp->use_reg && !adaptive) ? K_REG : qp->use_fast ? K_FAST : K_GENERIC;
+  const bool can_park = qp->use_big ? qp->use_bt : kern != K_REG;
   if (!can_park || st->check_termination <= 0 || (slice <= 0 && !adaptive)) {
     slice = 0;                                  // the register / sliced-ELL / global-memory kernels run to the end
   } else {
@@ -945,13 +948,13 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
   }
   SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
   if (mid) SCO_HIP(hipEventRecord(mid, qp->stream));
-  if (qp->use_rl) {
+  if (kern == K_RL) {
     int r_ = rl_launch(aa, qp->rl, qp->rld, qp->stream);
     if (r_) return r_;
-  } else if (qp->use_reg && !adaptive) {
+  } else if (kern == K_REG) {
     int r_ = reg_launch(aa, qp->reg, qp->regd, qp->stream);
     if (r_) return r_;
-  } else if (qp->use_fast && !adaptive) {
+  } else if (kern == K_FAST) {
     int r_ = fast_launch(aa, qp->fast, qp->fastd, qp->stream);
     if (r_) return r_;
   } else {

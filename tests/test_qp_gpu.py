@@ -374,7 +374,7 @@ def test_a_qp_that_needs_the_global_memory_tier_by_itself(gpu):
     assert info["n_core"] > 256 and info["lds_admm"] == 0
 
 
-@pytest.mark.parametrize("tier", ["row-local", "generic", "generic-instead-of-register", "structured"])
+@pytest.mark.parametrize("tier", ["row-local", "generic", "sliced-ELL-instead-of-register", "structured"])
 def test_adaptive_rho_matches_the_oracle_rule(gpu, monkeypatch, tier):
     """adaptive_rho=True (solver.py:39 / osqp_utils.py:13; off in the reference's defaults): OSQP's rho update
     every 4 x check_termination iterations.  The solve is parked at each update point, rho re-estimated from the
