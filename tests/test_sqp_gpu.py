@@ -563,3 +563,27 @@ def test_random_feature_mixes_with_joint_limits(gpu, seed):
     op = sr.SolverParams(compound_penalty=bool(knobs["compound_penalty"]), duplicate_rows=bool(knobs["duplicate_rows"]),
                          max_qp_solves=40)
     _compare(res, probs, range(3), op)
+
+
+def test_handles_are_independent_also_across_host_threads(gpu):
+    """Two handles alive at once, solved from two host threads at the same time (ctypes releases the GIL; every
+    handle has its own stream and its own device buffers): same results as one after the other."""
+    import threading
+    a1, _ = af.make_batch(24, **SMALL)
+    a2, _ = af.make_batch(5)
+    want1, want2 = sb.solve_batch(a1), sb.solve_batch(a2)
+    got = {}
+    with sb.TrajOptBatch(24, 3, 6, 2, 2) as t1, sb.TrajOptBatch(5, 7, 20, 5, 2) as t2:
+        t1.load(a1["x0"], a1["start"], a1["goal"], a1["link_len"], a1["point_link"], a1["point_frac"], a1["obstacles"])
+        t2.load(a2["x0"], a2["start"], a2["goal"], a2["link_len"], a2["point_link"], a2["point_frac"], a2["obstacles"])
+
+        def run(key, tb):
+            for _ in range(3):
+                tb.solve()
+            got[key] = tb.fetch()
+        th = [threading.Thread(target=run, args=(1, t1)), threading.Thread(target=run, args=(2, t2))]
+        for t in th: t.start()
+        for t in th: t.join()
+    for want, res in ((want1, got[1]), (want2, got[2])):
+        assert np.array_equal(want.x, res.x) and np.array_equal(want.admm_iters, res.admm_iters)
+        assert np.array_equal(want.success, res.success)
