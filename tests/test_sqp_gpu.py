@@ -587,3 +587,14 @@ def test_handles_are_independent_also_across_host_threads(gpu):
     for want, res in ((want1, got[1]), (want2, got[2])):
         assert np.array_equal(want.x, res.x) and np.array_equal(want.admm_iters, res.admm_iters)
         assert np.array_equal(want.success, res.success)
+
+
+def test_non_finite_problem_data_fails_that_problem_only(gpu):
+    """A NaN obstacle makes every constraint value of its problem NaN: its QPs are reported non-convex / unsolved,
+    the problem ends unsuccessful, the other problems of the batch are not touched and nothing hangs."""
+    arrays, probs = af.make_batch(4, **SMALL)
+    arrays["obstacles"] = arrays["obstacles"].copy()
+    arrays["obstacles"][2, 0, 0] = np.nan
+    res = sb.solve_batch(arrays, params=_lib.default_sqp_params(max_sqp_iters=30))
+    assert not bool(res.success[2])
+    _compare(res, probs, [0, 1, 3])
