@@ -164,6 +164,7 @@ struct sco_qp {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   std::vector<void *> allocs;
   bool loaded = false, solved_once = false;
+  bool factor_cholesky = false;        // SCO_QP_FACTOR_CHOLESKY=1: W by Cholesky + triangular inverse (cross-check)
   size_t lds_setup = 0, lds_admm = 0;
   double last_ms[2] = {0, 0};
 };

@@ -10,7 +10,8 @@
 //   * one workgroup (256 threads = 4 wavefronts) per problem, grid = batch;
 //   * qp_setup_kernel: Ruiz equilibration, rho vector, reduced matrix assembly
 //     (scaled data in LDS, the core Schur complement S into the W buffer);
-//   * qp_factor_kernel (1024 threads): dense Cholesky + inverse of S in LDS -> W;
+//   * qp_sweep_kernel (1024 threads): W = S^-1 by Gauss-Jordan sweeps with S in registers
+//     (qp_factor_kernel: the same by Cholesky + triangular inverse in LDS, cross-check);
 //   * qp_admm_kernel: the whole ADMM loop of one problem inside one launch with
 //     every iterate (x, z, y), the scaled A values and the coupling block held
 //     in LDS; HBM is touched once to load the problem, once per iteration for
@@ -367,6 +368,146 @@ __global__ __launch_bounds__(SCO_FACTOR_BLOCK) void qp_factor_kernel(QpDev d) {
     const double s = (s0 + s1) + (s2 + s3);
     W[(size_t)ia * n_c + ib] = s;
     W[(size_t)ib * n_c + ia] = s;
+  }
+  SSTAMP(7)
+}
+
+// --------------------------------------------------------------------------
+// invert kernel (default): W = S^-1 by symmetric Gauss-Jordan sweeps with the matrix in REGISTERS.
+// Every thread of the 1024 owns up to three 4 x 4 tiles of the lower triangle for the whole run (loaded straight
+// from the packed S in the W buffer); step k publishes column k (n values, double-buffered in LDS: one barrier per
+// step), every thread reads its eight entries of it and updates its tiles:
+//     a_kk <- -1 / a_kk,   a_ik <- a_ik / a_kk,   a_ij <- a_ij - a_ik a_jk / a_kk
+// after n sweeps the registers hold -S^-1 (pivots are the Schur complements of an SPD matrix: no pivoting needed).
+// No dependent load-multiply-add chains, no LDS traffic for the matrix: ~100 k cycles for a 140 x 140 core against
+// 1.0 M for the Cholesky route below (profiles/r01_setup_stamps.txt), which stays as a cross-check
+// (SCO_QP_FACTOR_CHOLESKY=1 at handle creation).
+// --------------------------------------------------------------------------
+// a_ik for i >= k from the tiles in block column kb, a_kj = a_jk for j < k from the tiles in block row kb
+template <int NT, int KK>
+__device__ __forceinline__ void sweep_publish(const double (&t)[NT][4][4], const int (&bi)[NT], const int (&bj)[NT],
+                                              int kb, int k, int n, double *cur) {
+#pragma unroll
+  for (int u = 0; u < NT; u++) {
+    if (bi[u] < 0) continue;
+    if (bj[u] == kb) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = 4 * bi[u] + r;
+        if (i < n && i >= k) cur[i] = t[u][r][KK];
+      }
+    }
+    if (bi[u] == kb) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int j = 4 * bj[u] + c;
+        if (j < k) cur[j] = t[u][KK][c];
+      }
+    }
+  }
+}
+
+// the sweep itself: every entry a_ij -= a_ik a_jk / a_kk, then the entries of column / row k and the pivot are
+// overwritten with their own rule (entries above the diagonal of a diagonal tile are scratch values nobody reads)
+template <int NT, int KK>
+__device__ __forceinline__ void sweep_update(double (&t)[NT][4][4], const int (&bi)[NT], const int (&bj)[NT],
+                                             int kb, int k, int n, const double *cur) {
+  const double dinv = 1.0 / cur[k];
+#pragma unroll
+  for (int u = 0; u < NT; u++) {
+    if (bi[u] < 0) continue;
+    double ai[4], aj[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int i = 4 * bi[u] + r; ai[r] = cur[i < n ? i : n - 1] * dinv; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) aj[c] = cur[4 * bj[u] + c];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) t[u][r][c] -= ai[r] * aj[c];
+    if (bj[u] == kb) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) t[u][r][KK] = ai[r];
+    }
+    if (bi[u] == kb) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) t[u][KK][c] = aj[c] * dinv;
+      if (bj[u] == kb) t[u][KK][KK] = -dinv;
+    }
+  }
+}
+
+// SCO_SWEEP_NT tiles per thread (template): 1 up to order 176, 2 up to 252, 3 up to 256 (16 wavefronts leave 128
+// registers per thread, a tile takes 32)
+template <int SCO_SWEEP_NT>
+__global__ __launch_bounds__(SCO_FACTOR_BLOCK) void qp_sweep_kernel(QpDev d) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (d.active && !d.active[b]) return;
+  const int n = d.n_c;
+  if (n == 0) return;
+#ifdef SCO_STAMP
+  long long sst_t = __builtin_readcyclecounter();
+#endif
+  __shared__ double ck[2][264];
+  double *W = d.W + (size_t)b * n * n;
+  const int nb = (n + 3) >> 2, ntiles = nb * (nb + 1) / 2;
+  int bi[SCO_SWEEP_NT], bj[SCO_SWEEP_NT];
+  double t[SCO_SWEEP_NT][4][4];
+#pragma unroll
+  for (int u = 0; u < SCO_SWEEP_NT; u++) {
+    const int T = tid + u * SCO_FACTOR_BLOCK;
+    bi[u] = -1; bj[u] = 0;
+    if (T < ntiles) {
+      int r = (int)((sqrt(8.0 * (double)T + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= T) r++;
+      while (r * (r + 1) / 2 > T) r--;
+      bi[u] = r; bj[u] = T - r * (r + 1) / 2;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int i = 4 * bi[u] + r, j = 4 * bj[u] + c;
+        t[u][r][c] = (bi[u] >= 0 && j <= i && i < n) ? W[tri_idx(i, j)] : 0.0;
+      }
+  }
+  __syncthreads();
+  SSTAMP(5)
+  for (int k = 0; k < n; k++) {
+    double *cur = ck[k & 1];
+    const int kb = k >> 2, kk = k & 3;
+    // kk = k mod 4 selects a compile-time register row / column (a run-time index would send the tiles to scratch)
+    switch (kk) {
+      case 0: sweep_publish<SCO_SWEEP_NT, 0>(t, bi, bj, kb, k, n, cur); break;
+      case 1: sweep_publish<SCO_SWEEP_NT, 1>(t, bi, bj, kb, k, n, cur); break;
+      case 2: sweep_publish<SCO_SWEEP_NT, 2>(t, bi, bj, kb, k, n, cur); break;
+      default: sweep_publish<SCO_SWEEP_NT, 3>(t, bi, bj, kb, k, n, cur); break;
+    }
+    __syncthreads();
+    switch (kk) {
+      case 0: sweep_update<SCO_SWEEP_NT, 0>(t, bi, bj, kb, k, n, cur); break;
+      case 1: sweep_update<SCO_SWEEP_NT, 1>(t, bi, bj, kb, k, n, cur); break;
+      case 2: sweep_update<SCO_SWEEP_NT, 2>(t, bi, bj, kb, k, n, cur); break;
+      default: sweep_update<SCO_SWEEP_NT, 3>(t, bi, bj, kb, k, n, cur); break;
+    }
+    // the next step publishes into the other buffer; the barrier of step k + 1 separates this step's reads of
+    // `cur` from step k + 2's writes to it
+  }
+  SSTAMP(6)
+#pragma unroll
+  for (int u = 0; u < SCO_SWEEP_NT; u++) {
+    if (bi[u] < 0) continue;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int i = 4 * bi[u] + r, j = 4 * bj[u] + c;
+        if (j <= i && i < n) {
+          const double v = -t[u][r][c];
+          W[(size_t)i * n + j] = v;
+          W[(size_t)j * n + i] = v;
+        }
+      }
   }
   SSTAMP(7)
 }
@@ -734,6 +875,7 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
 
 static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const int *Pp, const int *Pi,
                           const int *Ap, const int *Ai, hipStream_t stream) {
+  { const char *fc = getenv("SCO_QP_FACTOR_CHOLESKY"); qp->factor_cholesky = fc && fc[0] == '1'; }
   const char *no_elim = getenv("SCO_QP_NO_ELIM");
   int rc = qp_plan_build(n, m, Pp, Pi, Ap, Ai, (no_elim && no_elim[0] == '1') ? 0 : 1, qp->plan);
   if (rc != 0) { sco_set_error("sco_qp_create: malformed sparsity pattern"); return SCO_ERR_ARG; }
@@ -943,7 +1085,14 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
     const size_t ntri = (size_t)d.n_c * (d.n_c + 1) / 2;
     hipLaunchKernelGGL(qp_setup_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_setup - ntri * sizeof(double), qp->stream, sa);
     SCO_HIP(hipGetLastError());
-    hipLaunchKernelGGL(qp_factor_kernel, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), (ntri + d.n_c) * sizeof(double), qp->stream, dsetup);
+    if (qp->factor_cholesky)
+      hipLaunchKernelGGL(qp_factor_kernel, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), (ntri + d.n_c) * sizeof(double), qp->stream, dsetup);
+    else {
+      const int nb = (d.n_c + 3) / 4, ntiles = nb * (nb + 1) / 2;
+      if (ntiles <= SCO_FACTOR_BLOCK) hipLaunchKernelGGL(qp_sweep_kernel<1>, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), 0, qp->stream, dsetup);
+      else if (ntiles <= 2 * SCO_FACTOR_BLOCK) hipLaunchKernelGGL(qp_sweep_kernel<2>, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), 0, qp->stream, dsetup);
+      else hipLaunchKernelGGL(qp_sweep_kernel<3>, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), 0, qp->stream, dsetup);
+    }
     SCO_HIP(hipGetLastError());
   }
   SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));

@@ -214,7 +214,8 @@ WARM_START = False
 
 _HANDLE_CACHE = collections.OrderedDict()
 _HANDLE_CACHE_MAX = 8
-_TIER_SWITCHES = ("SCO_QP_NO_ELIM", "SCO_QP_NO_RL", "SCO_QP_NO_REG", "SCO_QP_NO_FAST", "SCO_QP_FORCE_BIG", "SCO_QP_NO_BT")
+_TIER_SWITCHES = ("SCO_QP_NO_ELIM", "SCO_QP_NO_RL", "SCO_QP_NO_REG", "SCO_QP_NO_FAST", "SCO_QP_FORCE_BIG", "SCO_QP_NO_BT",
+                  "SCO_QP_FACTOR_CHOLESKY")
 _HANDLE_LOCK = threading.Lock()
 
 

@@ -455,3 +455,18 @@ def test_adaptive_rho_on_random_sparsity_patterns(gpu, monkeypatch, seed, tier):
     if it[0] == ref.info.iter:
         assert nupd[0] == ref.info.rho_updates
     assert np.abs(x[0] - ref.x).max() < 1e-4 * (1 + np.abs(ref.x).max())
+
+
+def test_both_core_inversion_routes_agree(gpu, monkeypatch):
+    """W = S^-1 by register-resident Gauss-Jordan sweeps (default) and by Cholesky + triangular inverse
+    (SCO_QP_FACTOR_CHOLESKY=1): same statuses and iteration counts, answers within 1e-10; cores of order 3, 15, 60,
+    140 (one tile per thread) and 200 (two tiles per thread)."""
+    rng = np.random.default_rng(41)
+    for shape in ((1, 3, 2), (5, 3, 4), (20, 3, 2), (20, 7, 10), (25, 8, 3)):
+        probs = [penalty_qp(rng, *shape) for _ in range(2)]
+        monkeypatch.delenv("SCO_QP_FACTOR_CHOLESKY", raising=False)
+        info, x_s, st_s, it_s = _check(probs, check=[0])
+        assert info["n_core"] == shape[0] * shape[1]
+        monkeypatch.setenv("SCO_QP_FACTOR_CHOLESKY", "1")
+        _, x_c, st_c, it_c = _check(probs, check=[])
+        assert np.array_equal(st_s, st_c) and np.array_equal(it_s, it_c) and np.abs(x_s - x_c).max() < 1e-10
