@@ -65,7 +65,7 @@ static void build_sell2(int nitems, const std::vector<int> &ptr, const std::vect
 // --------------------------------------------------------------------------
 bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
   if (pl.n_c >= LCAP_NC || pl.m >= LCAP_M || pl.n_e > LT || pl.n_c > LT || pl.nnzA >= 65536 || pl.n > 2 * LT) return false;
-  const int n = pl.n, m = pl.m;
+  const int m = pl.m;
   // rows of every eliminated variable; every row's eliminated variable
   std::vector<int> row_elim(m, -1), row_epos(m, -1);
   std::vector<std::vector<int>> erows(pl.n_e);
