@@ -186,20 +186,22 @@ def main():
     for _ in range(args.steps):
         res, allrec = step()
         sco_iters += int(allrec["sqp_iters"].sum())
-        tm = tb.last_timing()
+        tm = tb.last_timing()                                  # HIP-event sums of the step just finished (five floats)
         stage_ms += [tm["convexify_ms"], tm["qp_setup_ms"], tm["admm_ms"], tm["decide_ms"], tm["total_ms"]]
-        traces = tb.trace()
-        # algorithmic bytes of the ADMM kernel: every QP solve of every problem, iterations x (5n + 9m) x 8
-        it_proj = sum(int(t[0, 7]) for t in traces)
-        it_pen = sum(int(t[1:, 7].sum()) for t in traces)
-        admm_bytes += it_proj * algorithmic_bytes_per_iter(n0, m0) + it_pen * algorithmic_bytes_per_iter(n, m)
         admm_ms += tm["admm_ms"]
         admm_launches += tm["rounds"]
         qp_launches += tm["rounds"] - 1                       # penalty-QP launches (the projection launch is tiny)
-        admm_iters_total += it_proj + it_pen
-        qp_solves_total += int(res.qp_solves.sum())
     sync()
     elapsed = time.perf_counter() - t0
+    # bookkeeping for the roofline figure, outside the timed region: every step solves the same loaded problems and
+    # the solve is deterministic (tests/test_sqp_gpu.py), so the per-QP iteration counts of the last step are those
+    # of every step.  Algorithmic bytes of the ADMM kernel: iterations x (5n + 9m) x 8 over every QP of every problem.
+    traces = tb.trace()
+    it_proj = sum(int(t[0, 7]) for t in traces)
+    it_pen = sum(int(t[1:, 7].sum()) for t in traces)
+    admm_bytes = args.steps * (it_proj * algorithmic_bytes_per_iter(n0, m0) + it_pen * algorithmic_bytes_per_iter(n, m))
+    admm_iters_total = args.steps * (it_proj + it_pen)
+    qp_solves_total = args.steps * int(res.qp_solves.sum())
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
