@@ -127,7 +127,7 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
     }
     build_sell2(LT, ptr, src, q == 0 ? rh.Ar0 : rh.Ar1);
   }
-  rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rh.Ar0.total + rh.Ar1.total + 64 * 16);
+  rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rh.Ar0.total + rh.Ar1.total + 64 * 16 + 5 * LT) + 12 * 4 * LCAP_NC;   // + check constants
   // ---- per-thread tables: packed gather offsets and roles
   const int CWv = rh.CW;
   const int slots = CWv + 2 * LRW;
@@ -181,6 +181,7 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
       rh.pc_pos.push_back(pl.Fpos[p]); rh.pc_core.push_back(c2);
     }
     rh.pc_ptr[c + 1] = (int)rh.pc_pos.size();
+    rh.pcw = std::max(rh.pcw, rh.pc_ptr[c + 1] - rh.pc_ptr[c]);
   }
   rh.TR = std::max(1, (pl.n_c + LGI - 1) / LGI);
   rh.TC = 2 * rh.TR;
@@ -197,6 +198,7 @@ struct RlArgs {
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   const unsigned short *off; const int *role;
   const int *srcAc, *srcAr0, *srcAr1, *pc_ptr, *pc_pos, *pc_core;
+  int pcw;           // most P entries in a core column; <= 4: the termination test reads them from LDS
   int totAc, totAr0, totAr1;
   const double *As, *W, *qs, *kee_inv, *ls, *us, *rho, *cscale, *Ps, *D, *E;
   const int *w, *active;
@@ -230,13 +232,29 @@ __device__ __forceinline__ double lwsum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// maximum over the wavefront, valid in lane 63: DPP row shifts and row broadcasts (VALU only; the shuffle version
+// goes through the LDS permute path six dependent times per value and made the termination test's reductions cost
+// 3.7 k cycles each, profiles/r01_check_stamps.txt).  A lane without a source keeps its own value, so a NaN
+// survives exactly when every lane holds one, as with the shuffles.
+__device__ __forceinline__ double lwmax63(double v) {
+  int lo, hi, lo2, hi2;
+#define RL_DPP_MAX(ctrl, rmask)                                                              \
+  lo = __double2loint(v); hi = __double2hiint(v);                                            \
+  lo2 = __builtin_amdgcn_update_dpp(lo, lo, ctrl, rmask, 0xf, false);                        \
+  hi2 = __builtin_amdgcn_update_dpp(hi, hi, ctrl, rmask, 0xf, false);                        \
+  v = fmax(v, __hiloint2double(hi2, lo2));
+  RL_DPP_MAX(0x111, 0xf) RL_DPP_MAX(0x112, 0xf) RL_DPP_MAX(0x114, 0xf) RL_DPP_MAX(0x118, 0xf)
+  RL_DPP_MAX(0x142, 0xa) RL_DPP_MAX(0x143, 0xc)
+#undef RL_DPP_MAX
+  return v;
+}
 template <int NR, bool IS_MAX>
 __device__ __forceinline__ void lblock_reduce(double (&v)[NR], double *red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < NR; k++) v[k] = IS_MAX ? lwmax(v[k]) : lwsum(v[k]);
+  for (int k = 0; k < NR; k++) v[k] = IS_MAX ? lwmax63(v[k]) : lwsum(v[k]);
   __syncthreads();
-  if (lane == 0) {
+  if (lane == (IS_MAX ? 63 : 0)) {
 #pragma unroll
     for (int k = 0; k < NR; k++) red[wv * NR + k] = v[k];
   }
@@ -391,6 +409,32 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       if (ep >= 0) r_ae[q] = gAs[ep];
     }
   }
+  // per-thread constants of the termination test, parked in LDS (slot k of thread t at [k * LT + t]): the scalings
+  // E of its two rows, D of its core / eliminated variable, the eliminated variable's P_ee.  Read back by the
+  // same thread only; from global memory they cost the test ~2 us of exposed L2 latency every 25 iterations.
+  double *s_cst = s_val + a.totAc + a.totAr0 + a.totAr1 + 64 * 16;
+  {
+    const double *Dg0 = a.D + (size_t)b * n, *Eg0 = a.E + (size_t)b * m;
+    s_cst[tid] = r_i[0] >= 0 ? Eg0[r_i[0]] : 1.0;
+    s_cst[LT + tid] = r_i[1] >= 0 ? Eg0[r_i[1]] : 1.0;
+    s_cst[2 * LT + tid] = cown >= 0 ? Dg0[cvar] : 1.0;
+    s_cst[3 * LT + tid] = eown >= 0 ? Dg0[evar] : 1.0;
+    const int pd0 = eown >= 0 ? a.role[(size_t)12 * LT + tid] : -1;
+    s_cst[4 * LT + tid] = pd0 >= 0 ? (a.Ps + (size_t)b * a.nnzP)[pd0] : 0.0;
+  }
+  // ... and the P entries of a core variable's column (value, core index; padded with 0 * x_C[n_c] = 0)
+  double *s_pcv = s_cst + 5 * LT;
+  int *s_pci = (int *)(s_pcv + 4 * LCAP_NC);
+  if (a.pcw <= 4 && cown >= 0) {
+    const double *Ps0 = a.Ps + (size_t)b * a.nnzP;
+    const int t0 = a.pc_ptr[cown], t1 = a.pc_ptr[cown + 1];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool on = t0 + k < t1;
+      s_pcv[k * LCAP_NC + cown] = on ? Ps0[a.pc_pos[t0 + k]] : 0.0;
+      s_pci[k * LCAP_NC + cown] = on ? a.pc_core[t0 + k] : n_c;
+    }
+  }
   for (int i = tid; i < LCAP_M; i += LT) s_tv[i] = 0.0;
   for (int i = tid; i < LCAP_NC; i += LT) { s_rv[i] = 0.0; s_xc[i] = 0.0; }
   __syncthreads();
@@ -455,8 +499,13 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   // diagnostic build only: cycles per phase per wavefront (never compiled into the product)
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_readcyclecounter();
 #define STAMP(k) { const long long now_ = __builtin_readcyclecounter(); st_acc[k] += now_ - st_t; st_t = now_; }
+  long long ck_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck_t = 0;     // segments of the termination test
+#define CSTAMP0 { ck_t = __builtin_readcyclecounter(); ck_acc[7] += 1; }
+#define CSTAMP(k) { const long long now_ = __builtin_readcyclecounter(); ck_acc[k] += now_ - ck_t; ck_t = now_; }
 #else
 #define STAMP(k)
+#define CSTAMP0
+#define CSTAMP(k)
 #endif
   // One ADMM iteration.  `chk` is a compile-time constant at both call sites: the
   // unchecked copy forms a tight inner loop with its latch right behind it (the
@@ -543,6 +592,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     iter++; step(true);
     {
       // ---- termination test (formulas of admm_check in sco_qp.hip) ---------------------
+      CSTAMP0
       const bool adapt_pt = ADAPT && iter % a.ad_interval == 0 && iter < a.max_iter;
       double vs[7] = {0, 0, 0, 0, 0, 0, 0};       // ADAPT: the same norms of the SCALED iterates
       for (int approximate = 0; approximate < 2 && !status; approximate++) {
@@ -560,7 +610,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           for (int q = 0; q < 2; q++)
             if (r_i[q] >= 0) {
               const double ax = axc[q] + r_ae[q] * xe;
-              const double ei = 1.0 / Eg[r_i[q]];
+              const double ei = 1.0 / s_cst[q * LT + tid];
               v[0] = fmax(v[0], fabs(ei * (ax - r_z[q])));
               v[1] = fmax(v[1], fabs(ei * r_z[q]));
               v[2] = fmax(v[2], fabs(ei * ax));
@@ -573,16 +623,20 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         if (cown >= 0) {
           const double aty = aty_c;
           double px = 0.0;
-          for (int t = a.pc_ptr[cown]; t < a.pc_ptr[cown + 1]; t++) px += Ps[a.pc_pos[t]] * sxc[a.pc_core[t]];
-          const double dj = 1.0 / Dg[cvar];
+          if (a.pcw <= 4) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) px += s_pcv[k * LCAP_NC + cown] * sxc[s_pci[k * LCAP_NC + cown]];
+          } else {
+            for (int t = a.pc_ptr[cown]; t < a.pc_ptr[cown + 1]; t++) px += Ps[a.pc_pos[t]] * sxc[a.pc_core[t]];
+          }
+          const double dj = 1.0 / s_cst[2 * LT + tid];
           v[3] = fabs(dj * (qc + px + aty)); v[4] = fabs(dj * qc); v[5] = fabs(dj * aty); v[6] = fabs(dj * px);
           if (ADAPT && adapt_pt) { vs[3] = fabs(qc + px + aty); vs[4] = fabs(qc); vs[5] = fabs(aty); vs[6] = fabs(px); }
         }
         if (eown >= 0) {
-          const int pd = a.role[(size_t)12 * LT + tid];
-          const double px = pd >= 0 ? Ps[pd] * xe : 0.0;
+          const double px = s_cst[4 * LT + tid] * xe;
           const double aty = r_ae[0] * (r_w[0] * r_y[0]) + r_ae[1] * (r_w[1] * r_y[1]);
-          const double dj = 1.0 / Dg[evar];
+          const double dj = 1.0 / s_cst[3 * LT + tid];
           v[3] = fmax(v[3], fabs(dj * (qe + px + aty))); v[4] = fmax(v[4], fabs(dj * qe));
           v[5] = fmax(v[5], fabs(dj * aty)); v[6] = fmax(v[6], fabs(dj * px));
           if (ADAPT && adapt_pt) {
@@ -590,7 +644,9 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
             vs[5] = fmax(vs[5], fabs(aty)); vs[6] = fmax(vs[6], fabs(px));
           }
         }
+        CSTAMP(0)
         lblock_reduce<7, true>(v, s_red);
+        CSTAMP(1)
         pri = v[0]; dua = cinv * v[3];
         if (!(pri <= SCO_INFTY) || !(dua <= SCO_INFTY)) { status = SCO_QP_NON_CVX; break; }
         const double eps_p = ea + er * fmax(v[1], v[2]);
@@ -608,7 +664,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
                 if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
               } else if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
               sdy[r_i[q]] = dy; dyp[q] = dy;
-              r1[0] = fmax(r1[0], fabs(Eg[r_i[q]] * dy));
+              r1[0] = fmax(r1[0], fabs(s_cst[q * LT + tid] * dy));
             }
           lblock_reduce<1, true>(r1, s_red);
           const double ndy = r1[0];
@@ -637,10 +693,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
             }
           }
         }
+        CSTAMP(2)
         if (!dual_ok) {            // dual infeasibility certificate from delta_x
           double r1[1] = {0.0};
-          if (cown >= 0) r1[0] = fabs(Dg[cvar] * dxc);
-          if (eown >= 0) r1[0] = fmax(r1[0], fabs(Dg[evar] * dxe));
+          if (cown >= 0) r1[0] = fabs(s_cst[2 * LT + tid] * dxc);
+          if (eown >= 0) r1[0] = fmax(r1[0], fabs(s_cst[3 * LT + tid] * dxe));
           lblock_reduce<1, true>(r1, s_red);
           const double ndx = r1[0];
           if (ndx > edi) {
@@ -678,7 +735,9 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           }
         }
       }
+      CSTAMP(3)
       __syncthreads();
+      CSTAMP(4)
       if (ADAPT && adapt_pt && !status) {
         // OSQP's rho estimate (compute_rho_estimate / adapt_rho of osqp 0.6, as recalled; oracle/osqp_ref.c)
         lblock_reduce<7, true>(vs, s_red);
@@ -710,6 +769,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
 #ifdef SCO_STAMP
   if ((tid & 63) == 0 && b == 0 && a.stamp) {
     for (int k = 0; k < 7; k++) a.stamp[(tid >> 6) * 8 + k] = (double)st_acc[k];
+    for (int k = 0; k < 8; k++) a.stamp[64 + (tid >> 6) * 8 + k] = (double)ck_acc[k];
     a.stamp[(tid >> 6) * 8 + 7] = (double)iter;
   }
 #endif
@@ -735,7 +795,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
 double *sco_debug_stamp_ptr = nullptr;
 extern "C" int sco_debug_stamps(double *out) {      // diagnostic build only
   if (!sco_debug_stamp_ptr) return -1;
-  return hipMemcpy(out, sco_debug_stamp_ptr, 64 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+  return hipMemcpy(out, sco_debug_stamp_ptr, 128 * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 #endif
 template <typename T>
@@ -792,7 +852,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.sigma = a.sigma; ra.alpha = a.alpha; ra.eps_abs = a.eps_abs; ra.eps_rel = a.eps_rel;
   ra.eps_prim_inf = a.eps_prim_inf; ra.eps_dual_inf = a.eps_dual_inf;
   ra.off = rd.off; ra.role = rd.role; ra.srcAc = rd.srcAc; ra.srcAr0 = rd.srcAr0; ra.srcAr1 = rd.srcAr1;
-  ra.pc_ptr = rd.pc_ptr; ra.pc_pos = rd.pc_pos; ra.pc_core = rd.pc_core;
+  ra.pc_ptr = rd.pc_ptr; ra.pc_pos = rd.pc_pos; ra.pc_core = rd.pc_core; ra.pcw = rh.pcw;
   ra.totAc = rh.Ac.total; ra.totAr0 = rh.Ar0.total; ra.totAr1 = rh.Ar1.total;
   ra.As = d.As; ra.W = d.W; ra.qs = d.qs; ra.kee_inv = d.kee_inv; ra.ls = d.ls; ra.us = d.us; ra.rho = d.rho;
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
@@ -805,7 +865,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
 #ifdef SCO_STAMP
   {
     static double *g_stamp = nullptr;
-    if (!g_stamp) { SCO_HIP(hipMalloc((void **)&g_stamp, 64 * sizeof(double))); SCO_HIP(hipMemset(g_stamp, 0, 64 * sizeof(double))); }
+    if (!g_stamp) { SCO_HIP(hipMalloc((void **)&g_stamp, 128 * sizeof(double))); SCO_HIP(hipMemset(g_stamp, 0, 128 * sizeof(double))); }
     ra.stamp = g_stamp;
     extern double *sco_debug_stamp_ptr; sco_debug_stamp_ptr = g_stamp;
   }

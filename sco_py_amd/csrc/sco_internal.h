@@ -103,6 +103,7 @@ int reg_launch(const AdmmArgs &a, const RegHost &rh, const RegDev &rd, hipStream
 // ---- row-local ADMM path (sco_admm_rl.hip): the coupling block never materialises
 struct RlHost {
   int TR = 1, TC = 2, CW = 12;     // CW: slots for a core variable's column entries (12 or 16)
+  int pcw = 0;                     // most P entries in a core variable's column (<= 4: cached in LDS for the termination test)
   SellHost Ac, Ar0, Ar1;
   size_t lds_bytes = 0;
   std::vector<unsigned short> off;

@@ -4,13 +4,19 @@ import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from sco_py_amd import _build
+if os.environ.get("SCO_LIB_OVERRIDE"):
+    _build.LIB = os.environ["SCO_LIB_OVERRIDE"]; print("library", _build.LIB)
 from sco_py_amd import _lib
 from test_qp_plan import penalty_qp
 from test_qp_gpu import _stack
 rng = np.random.default_rng(9)
 pr = penalty_qp(rng, 20, 7, 10)
-st = _lib.default_qp_settings(max_iter=20000, eps_abs=1e-30, eps_rel=1e-30)     # never converges: 20000 iterations each
-for B in (1, 16, 64, 128, 256, 512, 1024):
+import os
+CHK = int(os.environ.get("CHECK", "25"))
+st = _lib.default_qp_settings(max_iter=20000, eps_abs=1e-30, eps_rel=1e-30, check_termination=CHK)     # never converges: 20000 iterations each
+print("check_termination", CHK)
+for B in (1, 256, 1024):
     n, m, Pp, Pi, Ap, Ai, Pval, q, Aval, l, u = _stack([pr] * B)
     qp = _lib.BatchedQP(B, n, m, Pp, Pi, Ap, Ai)
     qp.load(Pval, q, Aval, l, u)

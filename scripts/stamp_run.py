@@ -10,8 +10,8 @@ with sb.TrajOptBatch(256, 7, 20, 5, 2) as tb:
     tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"], arrays["point_frac"], arrays["obstacles"])
     tb.solve()
     lib = _lib.load(); lib.sco_debug_stamps.argtypes = [C.POINTER(C.c_double)]
-    out = np.zeros(64); print("rc", lib.sco_debug_stamps(out.ctypes.data_as(C.POINTER(C.c_double))))
-    st = out.reshape(8, 8)
+    out = np.zeros(128); print("rc", lib.sco_debug_stamps(out.ctypes.data_as(C.POINTER(C.c_double))))
+    st = out[:64].reshape(8, 8); ck = out[64:].reshape(8, 8)
     names = ["(1) rhs", "barrier1", "(3) W+dpp", "barrier3", "(Y) rows", "barrierY", "looptop"]
     it = st[0, 7]
     print("problem 0, last launch: iterations", it, " timing:", tb.last_timing())
@@ -19,3 +19,6 @@ with sb.TrajOptBatch(256, 7, 20, 5, 2) as tb:
     np.set_printoptions(linewidth=200, precision=0, suppress=True)
     print(st[:, :7] / it)
     print("sum per wave", (st[:, :7].sum(axis=1) / it))
+    print("termination test, cycles per test by wave: [rows+cols norms, first reduction, primal-infeasibility branch, dual branch, closing barrier], tests:", ck[0, 7])
+    print(ck[:, :5] / np.maximum(ck[:, 7:8], 1))
+    print("sum per test", (ck[:, :5].sum(axis=1) / np.maximum(ck[:, 7], 1)))
