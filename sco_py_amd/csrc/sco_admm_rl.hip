@@ -586,7 +586,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   while (!status && iter < stop && !(ADAPT && rho_new > 0.0)) {
     int next = stop;
     if (a.check > 0) { next = (iter / a.check + 1) * a.check; if (next > stop) next = stop; }
-    // four iterations per trip: a loop trip costs several hundred cycles of refetch (profiles/r01_v6_stamps.txt)
+    // twelve iterations per trip (two trips between termination tests at the default cadence of 25): a loop trip
+    // costs several hundred cycles of instruction refetch (profiles/r01_v6_stamps.txt); 24 copies overflow the
+    // instruction cache and are slower (1.33 against 1.26 us per iteration)
+    while (iter + 12 < next) { iter += 12; step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); }
+    while (iter + 8 < next) { iter += 8; step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); }
     while (iter + 4 < next) { iter += 4; step(false); step(false); step(false); step(false); }
     while (iter + 1 < next) { iter++; step(false); }
     iter++; step(true);
