@@ -95,13 +95,26 @@ __device__ __forceinline__ double fwsum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// maximum over the wavefront, valid in lane 63, by DPP row shifts / row broadcasts (see lwmax63 in sco_admm_rl.hip)
+__device__ __forceinline__ double fwmax63(double v) {
+  int lo, hi, lo2, hi2;
+#define FAST_DPP_MAX(ctrl, rmask)                                                            \
+  lo = __double2loint(v); hi = __double2hiint(v);                                            \
+  lo2 = __builtin_amdgcn_update_dpp(lo, lo, ctrl, rmask, 0xf, false);                        \
+  hi2 = __builtin_amdgcn_update_dpp(hi, hi, ctrl, rmask, 0xf, false);                        \
+  v = fmax(v, __hiloint2double(hi2, lo2));
+  FAST_DPP_MAX(0x111, 0xf) FAST_DPP_MAX(0x112, 0xf) FAST_DPP_MAX(0x114, 0xf) FAST_DPP_MAX(0x118, 0xf)
+  FAST_DPP_MAX(0x142, 0xa) FAST_DPP_MAX(0x143, 0xc)
+#undef FAST_DPP_MAX
+  return v;
+}
 template <int NR, bool IS_MAX>
 __device__ __forceinline__ void fblock_reduce(double (&v)[NR], double *red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < NR; k++) v[k] = IS_MAX ? fwmax(v[k]) : fwsum(v[k]);
+  for (int k = 0; k < NR; k++) v[k] = IS_MAX ? fwmax63(v[k]) : fwsum(v[k]);
   __syncthreads();
-  if (lane == 0) {
+  if (lane == (IS_MAX ? 63 : 0)) {
 #pragma unroll
     for (int k = 0; k < NR; k++) red[wv * NR + k] = v[k];
   }
