@@ -33,62 +33,108 @@ def algorithmic_bytes_per_iter(n, m):
 
 
 def cpu_baseline(n_problems, first, dims):
-    """The oracle (CPU restatement of the same path) timed on this host, 1 thread."""
+    """The oracle (CPU restatement of the same path) timed on this host, ONE thread (BLAS pools limited to 1)."""
     from oracle import arm_family as af
     from oracle import sco_ref as sr
-    iters = 0
-    t0 = time.perf_counter()
-    for i in range(n_problems):
-        out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(first + i, **dims)), emulate_memo=True)
-        iters += out.sqp_iters
-    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                      # pragma: no cover - threadpoolctl ships with the image
+        import contextlib
+        threadpool_limits = lambda limits: contextlib.nullcontext()     # noqa: E731
+    with threadpool_limits(limits=1):
+        sr.penalty_sqp(sr.trajopt_flat(af.make_problem(first, d=3, T=6, K=2, O=2)), emulate_memo=True)   # loads the C library
+        iters = 0
+        t0 = time.perf_counter()
+        for i in range(n_problems):
+            out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(first + i, **dims)), emulate_memo=True)
+            iters += out.sqp_iters
+        dt = time.perf_counter() - t0
     return iters / dt, dt, iters
 
 
+# One worker per host core.  It imports everything and solves a tiny problem first (start-up and the C library load stay
+# outside the timer), reports "ready", waits for "go", then solves its share and prints its SCO iteration count.
 _CPU_WORKER = """
 import sys
 sys.path.insert(0, sys.argv[1])
 from oracle import arm_family as af
 from oracle import sco_ref as sr
 dims = dict(d=int(sys.argv[2]), T=int(sys.argv[3]), K=int(sys.argv[4]), O=int(sys.argv[5]))
+sr.penalty_sqp(sr.trajopt_flat(af.make_problem(0, d=3, T=6, K=2, O=2)), emulate_memo=True)
+print("ready", flush=True)
+sys.stdin.readline()
 it = 0
 for i in sys.argv[6:]:
     it += sr.penalty_sqp(sr.trajopt_flat(af.make_problem(int(i), **dims)), emulate_memo=True).sqp_iters
-print(it)
+print(it, flush=True)
 """
 
 
-def cpu_baseline_all_cores(dims, per_core=2, timeout=240):
-    """One oracle process per host core of this box, each solving `per_core` problems (the generous
-    CPU baseline of SURVEY 8(d); the reference itself is single-threaded).  Plain child processes,
-    started before anything touches the GPU; returns None if a worker fails or overruns."""
+def cpu_baseline_all_cores(dims, per_core=8, timeout=240):
+    """One single-threaded oracle process per host core of this box, each solving `per_core` problems of the same
+    batch (the generous CPU baseline of SURVEY 8(d); the reference itself is single-threaded).  The timer runs from
+    the moment every worker has reported ready to the last result.  Plain child processes, started before anything
+    touches the GPU; returns None if a worker fails or overruns."""
     import subprocess
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nproc = cores
     cores = max(1, min(cores, 64))
     # children never touch the GPU: drop any profiler preload / tool hooks from their environment
     env = {k: v for k, v in os.environ.items()
            if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER"))}
-    t0 = time.perf_counter()
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        env[k] = "1"
+    t_start = time.perf_counter()
     procs = []
     for c in range(cores):
         ids = [str(c * per_core + k) for k in range(per_core)]
         procs.append(subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT] +
                                       [str(dims[k]) for k in ("d", "T", "K", "O")] + ids,
-                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env))
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env))
     iters, ok = 0, True
-    for pr in procs:
-        try:
-            out, _ = pr.communicate(timeout=max(1.0, timeout - (time.perf_counter() - t0)))
-            iters += int(out.decode().strip())
-        except Exception:
-            ok = False
-            pr.kill()
-    dt = time.perf_counter() - t0
+    try:
+        for pr in procs:                                  # ready handshake
+            if pr.stdout.readline().decode().strip() != "ready":
+                ok = False
+        if ok:
+            t0 = time.perf_counter()
+            for pr in procs:
+                pr.stdin.write(b"go\n"); pr.stdin.flush()
+            for pr in procs:
+                out, _ = pr.communicate(timeout=max(1.0, timeout - (time.perf_counter() - t_start)))
+                iters += int(out.decode().strip())
+            dt = time.perf_counter() - t0
+    except Exception:
+        ok = False
     if not ok:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
         return None
-    return {"value": iters / dt, "unit": "sco_iters/s", "cores": cores, "kind": "port",
-            "sample": "problems 0..%d of the same batch, one oracle process per core, %.1f s incl. start-up"
-                      % (cores * per_core - 1, dt)}
+    return {"value": iters / dt, "unit": "sco_iters/s", "cores": cores, "nproc": nproc, "kind": "port",
+            "threads_per_process": 1,
+            "sample": "problems 0..%d of the same batch, %d per single-threaded oracle process, one process per core, "
+                      "%.1f s after the ready handshake (start-up excluded)" % (cores * per_core - 1, per_core, dt)}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv, script=None):
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes (torch.distributed.run as a child
+    process, never an exec) BEFORE this process makes any GPU call, and return its exit code.  Rank 0 of the child
+    job prints the one JSON line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script or os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -107,6 +153,8 @@ def main():
                          "per problem (NOT the headline number, NOT parity mode)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))          # nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -130,11 +178,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE %d; launch with torch.distributed.run" % (args.gpus, world),
+            print("bench.py: --gpus %d but WORLD_SIZE %d: the launcher and the flag disagree" % (args.gpus, world),
                   file=sys.stderr)
         sys.exit(2)
 
-    from oracle import arm_family as af            # workload generator only (inputs), not the solver
+    from sco_py_amd import workloads as af       # seeded inputs (shared with tests and oracle)
     from sco_py_amd import _lib, batch as sb
     from sco_py_amd import dist as sd
 
@@ -170,11 +218,7 @@ def main():
             torch.cuda.synchronize()
 
     def step():
-        tb.solve(params, qs)
-        res = tb.fetch(with_merit=True)
-        rec = sd.pack_results(res.merit, res.max_violation, res.success, res.sqp_iters)
-        allrec = sd.gather_results(rec, total)      # RCCL all-gather of 24 B/problem (no-op at N = 1)
-        return res, allrec
+        return sd.solve_sharded(tb, total, params, qs)     # solve the shard + RCCL all-gather of 24 B/problem (no-op at N = 1)
 
     for _ in range(args.warmup):
         step()

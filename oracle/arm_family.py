@@ -1,187 +1,8 @@
-"""Synthetic trajectory-optimisation workload -- TEST INFRASTRUCTURE.
+"""Planar-arm workload as the oracle sees it -- TEST INFRASTRUCTURE.
 
-The reference ships no benchmark problems; this module defines the
-seeded planar-arm workload of SURVEY.md 8(d) in NumPy so that the oracle, the
-golden-vector generator and bench.py's CPU baseline all use the same inputs the
-device kernels receive.
-
-Problem i (``make_problem(i, ...)``):
-  variables   joint angles theta[t][j], t < T, j < d, flattened time-major
-  objective   sum_t || theta[t+1] - theta[t] ||^2            (QuadExpr)
-  linear      theta[0] = start, theta[T-1] = goal            (EqExpr(AffExpr))
-              (reach variant: only the start pin; ee(theta[T-1]) = target as EqExpr(Expr))
-  nonlinear   per timestep, K link points x O circular obstacles (LEqExpr, val = 0):
-                g[k*O + o](theta_t) = r_o - || p_k(theta_t) - c_o ||
-              p_k = planar forward kinematics of a serial arm (cumulative angles)
-"""
-import numpy as np
-
-
-def link_points(theta, link_len, point_link, point_frac):
-    """Positions (K, 2) of the K link points for joint angles theta (d,)."""
-    phi = np.cumsum(theta)
-    cx, cy = np.cos(phi), np.sin(phi)
-    jx = np.concatenate(([0.0], np.cumsum(link_len * cx)))   # joint positions
-    jy = np.concatenate(([0.0], np.cumsum(link_len * cy)))
-    pl = np.asarray(point_link)
-    px = jx[pl] + point_frac * link_len[pl] * cx[pl]
-    py = jy[pl] + point_frac * link_len[pl] * cy[pl]
-    return np.stack([px, py], axis=1)
-
-
-def arm_dist(theta, link_len, point_link, point_frac, obstacles):
-    """g (K*O,) with g[k*O + o] = r_o - ||p_k - c_o||."""
-    p = link_points(np.asarray(theta, dtype=np.float64).ravel(), link_len, point_link, point_frac)
-    diff = p[:, None, :] - obstacles[None, :, :2]
-    dist = np.sqrt(diff[..., 0] ** 2 + diff[..., 1] ** 2)
-    return (obstacles[None, :, 2] - dist).ravel()
-
-
-def arm_dist_jac(theta, link_len, point_link, point_frac, obstacles):
-    """Analytic Jacobian (K*O, d) of arm_dist."""
-    theta = np.asarray(theta, dtype=np.float64).ravel()
-    d = theta.shape[0]
-    phi = np.cumsum(theta)
-    cx, cy = np.cos(phi), np.sin(phi)
-    p = link_points(theta, link_len, point_link, point_frac)
-    K, O = p.shape[0], obstacles.shape[0]
-    # d p_k / d theta_j = sum over links i >= j (up to the point's link) of the
-    # rotated link vector
-    dp = np.zeros((K, d, 2))
-    for k in range(K):
-        lk = point_link[k]
-        for j in range(lk + 1):
-            sx = sy = 0.0
-            for i in range(j, lk + 1):
-                L = link_len[i] * (point_frac[k] if i == lk else 1.0)
-                sx += -L * cy[i]
-                sy += L * cx[i]
-            dp[k, j, 0], dp[k, j, 1] = sx, sy
-    J = np.zeros((K * O, d))
-    for k in range(K):
-        for o in range(O):
-            dx = p[k, 0] - obstacles[o, 0]
-            dy = p[k, 1] - obstacles[o, 1]
-            dist = np.sqrt(dx * dx + dy * dy)
-            J[k * O + o, :] = -(dx * dp[k, :, 0] + dy * dp[k, :, 1]) / dist
-    return J
-
-
-def ee_pos(theta, link_len):
-    """End-effector position (2,) of the arm."""
-    phi = np.cumsum(np.asarray(theta, dtype=np.float64).ravel())
-    return np.array([np.sum(link_len * np.cos(phi)), np.sum(link_len * np.sin(phi))])
-
-
-def ee_jac(theta, link_len):
-    """Analytic Jacobian (2, d) of ee_pos."""
-    phi = np.cumsum(np.asarray(theta, dtype=np.float64).ravel())
-    d = phi.shape[0]
-    J = np.zeros((2, d))
-    for j in range(d):
-        J[0, j] = -np.sum(link_len[j:] * np.sin(phi[j:]))
-        J[1, j] = np.sum(link_len[j:] * np.cos(phi[j:]))
-    return J
-
-
-def velocity_rows(d, T):
-    """V (2 d (T-1), d T): rows theta[t+1][j] - theta[t][j] (t-major), then their negatives."""
-    D = np.zeros((d * (T - 1), d * T))
-    for t in range(T - 1):
-        for j in range(d):
-            D[t * d + j, t * d + j] = -1.0
-            D[t * d + j, (t + 1) * d + j] = 1.0
-    return np.vstack([D, -D])
-
-
-def joint_limit_rows(d, T):
-    """(2 d T, d T): +I (theta <= hi), then -I (-theta <= -lo)."""
-    eye = np.eye(d * T)
-    return np.vstack([eye, -eye])
-
-
-def default_points(d, K):
-    """K link points spread over the links: point k sits at the END of link
-    (k * d) // K ... evenly, fraction 1.0 for the last point of a link."""
-    link = np.array([min(d - 1, ((k + 1) * d - 1) // K) for k in range(K)], dtype=np.int32)
-    frac = np.ones(K)
-    # several points on the same link are spread along it
-    for l in range(d):
-        idx = np.where(link == l)[0]
-        for r, k in enumerate(idx):
-            frac[k] = (r + 1) / len(idx)
-    return link, frac
-
-
-def block_groups(T, reach, scheme):
-    """Constraint-group ids per non-linear block (T timestep blocks, then the reach block):
-    scheme "halves" puts every block in "all" and the first / second half of the horizon in
-    "head" / "tail" (so "all" overlaps both), the reach block in "all" and "reach"; scheme
-    "split" uses the disjoint groups "head", "tail" (and "reach") only."""
-    if scheme is None:
-        return None
-    assert scheme in ("halves", "split")
-    if scheme == "split":            # disjoint groups, no "all": one stalled half ends the minimisation
-        return [["head"] if t < T // 2 else ["tail"] for t in range(T)] + ([["reach"]] if reach else [])
-    g = [["all", "head"] if t < T // 2 else ["all", "tail"] for t in range(T)]
-    if reach:
-        g.append(["all", "reach"])
-    return g
-
-
-def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None):
-    """Seeded problem i of the batch.  reach=True: the goal pin
-    theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
-    (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
-    is_reach = bool(reach)
-    rng = np.random.default_rng(1000 + i)
-    start = rng.uniform(-np.pi / 2, np.pi / 2, size=d)
-    goal = rng.uniform(-np.pi / 2, np.pi / 2, size=d)
-    s = np.linspace(0.0, 1.0, T)[:, None]
-    x0 = (1 - s) * start[None, :] + s * goal[None, :] + noise * rng.standard_normal((T, d))
-    link_len = np.full(d, 1.0 / d)
-    reach = float(link_len.sum())
-    ang = rng.uniform(0.0, 2 * np.pi, size=O)
-    rad = reach * np.sqrt(rng.uniform(0.15 ** 2, 1.0, size=O))     # uniform on the annulus
-    radius = rng.uniform(0.05, 0.15, size=O) * reach
-    obstacles = np.stack([rad * np.cos(ang), rad * np.sin(ang), radius], axis=1)
-    point_link, point_frac = default_points(d, K)
-    out = dict(d=d, T=T, K=K, O=O, x0=x0.ravel(), start=start, goal=goal, link_len=link_len,
-               point_link=point_link, point_frac=point_frac, obstacles=obstacles, reach=is_reach)
-    if is_reach:
-        out["target"] = ee_pos(goal, link_len)
-    if groups is not None:
-        out["groups"] = block_groups(T, is_reach, groups)      # prob.add_cnt_expr(..., group_ids=...)
-    if vel_limit is not None:
-        # joint-velocity limits |theta[t+1][j] - theta[t][j]| <= vmax: LINEAR inequalities, i.e.
-        # LEqExpr(AffExpr) rows that go straight into every QP (prob.py:126-131, 317-346)
-        out["vmax"] = float(vel_limit)
-    if joint_limit is not None:
-        # joint limits lo_j <= theta[t][j] <= hi_j for every timestep: two more LEqExpr(AffExpr) blocks.  The box
-        # hugs the straight line between start and goal (margin `joint_limit`), so that avoiding the obstacles
-        # runs into it.
-        out["jlo"] = np.minimum(start, goal) - float(joint_limit)
-        out["jhi"] = np.maximum(start, goal) + float(joint_limit)
-    return out
-
-
-def make_batch(B, first=0, **kw):
-    """Stacked arrays of problems first .. first+B-1 in the layout sco_sqp_load takes."""
-    probs = [make_problem(first + i, **kw) for i in range(B)]
-    p0 = probs[0]
-    extra = dict(reach=True, target=np.stack([p["target"] for p in probs])) if p0.get("reach") else {}
-    if p0.get("groups") is not None:
-        extra["groups"] = p0["groups"]
-    if p0.get("vmax") is not None:
-        extra["vmax"] = np.array([p["vmax"] for p in probs])
-    if p0.get("jlo") is not None:
-        extra["jlo"] = np.stack([p["jlo"] for p in probs]); extra["jhi"] = np.stack([p["jhi"] for p in probs])
-    return dict(
-        d=p0["d"], T=p0["T"], K=p0["K"], O=p0["O"], B=B, **extra,
-        x0=np.stack([p["x0"] for p in probs]),
-        start=np.stack([p["start"] for p in probs]),
-        goal=np.stack([p["goal"] for p in probs]),
-        link_len=np.stack([p["link_len"] for p in probs]),
-        point_link=p0["point_link"].astype(np.int32), point_frac=p0["point_frac"].copy(),
-        obstacles=np.stack([p["obstacles"] for p in probs]),
-    ), probs
+The seeded generator and the NumPy definition of the constraint family live in
+sco_py_amd/workloads.py (shared by bench.py, the tests and this oracle: the product
+never imports oracle/, the oracle may import the product's input generator).  This
+module only re-exports them under the name the oracle and the golden generators use."""
+from sco_py_amd.workloads import (arm_dist, arm_dist_jac, block_groups, default_points, ee_jac, ee_pos,  # noqa: F401
+                                  joint_limit_rows, link_points, make_batch, make_problem, velocity_rows)

@@ -27,6 +27,23 @@ int sco_hip_fail(hipError_t e, const char *what);
     if (_e != hipSuccess) return sco_hip_fail(_e, #call);                     \
   } while (0)
 
+// Every ABI entry point runs on its handle's device and puts the caller's current device back on return
+// (a process that shares HIP with PyTorch or another library on a different device must not find its
+// current device changed by a call into this one).
+struct ScoDeviceGuard {
+  int prev = -1; bool ok = false;
+  explicit ScoDeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~ScoDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  ScoDeviceGuard(const ScoDeviceGuard &) = delete;
+  ScoDeviceGuard &operator=(const ScoDeviceGuard &) = delete;
+};
+#define SCO_ON_DEVICE(dev)                                                    \
+  ScoDeviceGuard sco_guard_(dev);                                             \
+  if (!sco_guard_.ok) return sco_hip_fail(hipGetLastError(), "hipSetDevice")
+
 // Device-side view of one batched QP: plans (shared) + per-problem value arrays.
 struct QpDev {
   int n, m, nnzP, nnzA, n_e, n_c, ncpl, nS, batch;
@@ -188,3 +205,4 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
 int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
                          int slice, hipEvent_t mid, int *sliced);
 int sco_qp_adaptive_interval(const sco_qp_settings *st);
+bool sco_qp_can_adapt(const sco_qp *qp);   // false: this handle sits on the dense global-memory tier, which cannot park a solve

@@ -857,6 +857,7 @@ static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const
 int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, const int *Pi,
                             const int *Ap, const int *Ai, hipStream_t stream, sco_qp **out) {
   if (!out || batch <= 0 || n <= 0 || m < 0 || !Pp || !Ap) { sco_set_error("sco_qp_create: bad argument"); return SCO_ERR_ARG; }
+  if ((Pp[n] > 0 && !Pi) || (Ap[n] > 0 && !Ai)) { sco_set_error("sco_qp_create: null row-index array for a non-empty pattern"); return SCO_ERR_ARG; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -864,7 +865,7 @@ int sco_qp_create_on_stream(int device, int batch, int n, int m, const int *Pp, 
     return SCO_ERR_NO_GPU;
   }
   if (device < 0 || device >= ndev) { sco_set_error("sco_qp_create: bad device index"); return SCO_ERR_ARG; }
-  SCO_HIP(hipSetDevice(device));
+  SCO_ON_DEVICE(device);
   sco_qp *qp = new sco_qp();
   qp->device = device;
   const int rc = qp_create_impl(qp, device, batch, n, m, Pp, Pi, Ap, Ai, stream);
@@ -975,7 +976,7 @@ extern "C" int sco_qp_create(int device, int batch, int n, int m, const int *Pp,
 
 extern "C" int sco_qp_destroy(sco_qp *qp) {
   if (!qp) return SCO_OK;
-  (void)hipSetDevice(qp->device);
+  ScoDeviceGuard sco_guard_(qp->device);
   if (qp->stream) (void)hipStreamSynchronize(qp->stream);
   for (void *p : qp->allocs) (void)hipFree(p);
   for (auto &e : qp->ev) if (e) (void)hipEventDestroy(e);
@@ -989,7 +990,7 @@ extern "C" int sco_qp_load(sco_qp *qp, const double *P_val, const double *q, con
   if (!qp || !q || (qp->d.nnzP && !P_val) || (qp->d.nnzA && !A_val) || (qp->d.m && (!l || !u))) {
     sco_set_error("sco_qp_load: null pointer"); return SCO_ERR_ARG;
   }
-  SCO_HIP(hipSetDevice(qp->device));
+  SCO_ON_DEVICE(qp->device);
   const QpDev &d = qp->d; const size_t B = d.batch;
   if (d.nnzP) SCO_HIP(hipMemcpyAsync(d.Pval, P_val, B * d.nnzP * sizeof(double), hipMemcpyHostToDevice, qp->stream));
   SCO_HIP(hipMemcpyAsync(d.q, q, B * d.n * sizeof(double), hipMemcpyHostToDevice, qp->stream));
@@ -1012,7 +1013,7 @@ extern "C" int sco_qp_load(sco_qp *qp, const double *P_val, const double *q, con
 extern "C" int sco_qp_set_bounds(sco_qp *qp, const double *l, const double *u) {
   if (!qp || !l || !u) { sco_set_error("sco_qp_set_bounds: null pointer"); return SCO_ERR_ARG; }
   if (!qp->loaded) { sco_set_error("sco_qp_set_bounds: call sco_qp_load first"); return SCO_ERR_STATE; }
-  SCO_HIP(hipSetDevice(qp->device));
+  SCO_ON_DEVICE(qp->device);
   const QpDev &d = qp->d; const size_t B = d.batch;
   SCO_HIP(hipMemcpyAsync(d.l, l, B * d.m * sizeof(double), hipMemcpyHostToDevice, qp->stream));
   SCO_HIP(hipMemcpyAsync(d.u, u, B * d.m * sizeof(double), hipMemcpyHostToDevice, qp->stream));
@@ -1033,6 +1034,8 @@ int sco_qp_adaptive_interval(const sco_qp_settings *st) {
   }
   return st->check_termination > 0 ? 4 * st->check_termination : 100;
 }
+
+bool sco_qp_can_adapt(const sco_qp *qp) { return !(qp->use_big && !qp->use_bt); }
 
 int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
                          int slice, hipEvent_t mid, int *sliced) {
@@ -1121,7 +1124,7 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
   if (settings->max_iter <= 0 || !(settings->rho > 0) || !(settings->sigma > 0) || settings->scaling < 0) {
     sco_set_error("sco_qp_solve: bad settings"); return SCO_ERR_ARG;
   }
-  SCO_HIP(hipSetDevice(qp->device));
+  SCO_ON_DEVICE(qp->device);
   const QpDev &d = qp->d; const size_t B = d.batch;
   int rc;
   if (settings->adaptive_rho) {
@@ -1172,7 +1175,7 @@ extern "C" int sco_qp_solve(sco_qp *qp, const sco_qp_settings *settings, double 
 
 extern "C" int sco_qp_adaptive_info(sco_qp *qp, double *rho, int *updates) {
   if (!qp) return SCO_ERR_ARG;
-  SCO_HIP(hipSetDevice(qp->device));
+  SCO_ON_DEVICE(qp->device);
   const QpDev &d = qp->d;
   if (rho) SCO_HIP(hipMemcpy(rho, d.rho_b, (size_t)d.batch * sizeof(double), hipMemcpyDeviceToHost));
   if (updates) SCO_HIP(hipMemcpy(updates, d.nupd, (size_t)d.batch * sizeof(int), hipMemcpyDeviceToHost));

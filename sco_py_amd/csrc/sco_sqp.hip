@@ -729,7 +729,7 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
     return SCO_ERR_NO_GPU;
   }
   if (device < 0 || device >= ndev) { sco_set_error("sco_sqp_create: bad device index"); return SCO_ERR_ARG; }
-  SCO_HIP(hipSetDevice(device));
+  SCO_ON_DEVICE(device);
   sco_sqp *h = new sco_sqp();
   h->device = device; h->desc = *desc;
   const int rc = sqp_create_impl(h, device, desc);
@@ -854,7 +854,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
 
 extern "C" int sco_sqp_destroy(sco_sqp *h) {
   if (!h) return SCO_OK;
-  (void)hipSetDevice(h->device);
+  ScoDeviceGuard sco_guard_(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->qp0) sco_qp_destroy(h->qp0);
   if (h->qp1) sco_qp_destroy(h->qp1);
@@ -874,7 +874,7 @@ extern "C" int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, c
   const SqpDev &s = h->d;
   for (int k = 0; k < s.K; k++)
     if (point_link[k] < 0 || point_link[k] >= s.d) { sco_set_error("sco_sqp_load: point_link out of range"); return SCO_ERR_ARG; }
-  SCO_HIP(hipSetDevice(h->device));
+  SCO_ON_DEVICE(h->device);
   const size_t B = s.batch;
   SCO_HIP(hipMemcpyAsync(s.x0, x0, B * s.n_x * sizeof(double), hipMemcpyHostToDevice, h->stream));
   SCO_HIP(hipMemcpyAsync(s.start, start, B * s.d * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -892,7 +892,7 @@ extern "C" int sco_sqp_load_target(sco_sqp *h, const double *target) {
   if (!h || !target) { sco_set_error("sco_sqp_load_target: null pointer"); return SCO_ERR_ARG; }
   if ((h->desc.family & 15) != SCO_FAM_ARM_REACH) { sco_set_error("sco_sqp_load_target: family has no target"); return SCO_ERR_ARG; }
   if (!h->loaded) { sco_set_error("sco_sqp_load_target: call sco_sqp_load first"); return SCO_ERR_STATE; }
-  SCO_HIP(hipSetDevice(h->device));
+  SCO_ON_DEVICE(h->device);
   SCO_HIP(hipMemcpyAsync(h->d.target, target, (size_t)h->d.batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   SCO_HIP(hipStreamSynchronize(h->stream));
   h->target_loaded = true; h->solved = false;
@@ -905,7 +905,7 @@ extern "C" int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax) {
   if (!h->loaded) { sco_set_error("sco_sqp_load_vel_limit: call sco_sqp_load first"); return SCO_ERR_STATE; }
   for (int b = 0; b < h->d.batch; b++)
     if (!(vmax[b] > 0.0)) { sco_set_error("sco_sqp_load_vel_limit: vmax must be positive"); return SCO_ERR_ARG; }
-  SCO_HIP(hipSetDevice(h->device));
+  SCO_ON_DEVICE(h->device);
   SCO_HIP(hipMemcpyAsync(h->d.vmax, vmax, (size_t)h->d.batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
   SCO_HIP(hipStreamSynchronize(h->stream));
   h->vel_loaded = true; h->solved = false;
@@ -919,7 +919,7 @@ extern "C" int sco_sqp_load_joint_limits(sco_sqp *h, const double *lo, const dou
   const size_t cnt = (size_t)h->d.batch * h->d.d;
   for (size_t k = 0; k < cnt; k++)
     if (!(lo[k] < hi[k])) { sco_set_error("sco_sqp_load_joint_limits: need lo < hi"); return SCO_ERR_ARG; }
-  SCO_HIP(hipSetDevice(h->device));
+  SCO_ON_DEVICE(h->device);
   SCO_HIP(hipMemcpyAsync(h->d.jlo, lo, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
   SCO_HIP(hipMemcpyAsync(h->d.jhi, hi, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
   SCO_HIP(hipStreamSynchronize(h->stream));
@@ -938,7 +938,7 @@ extern "C" int sco_sqp_set_groups(sco_sqp *h, int n_groups, const unsigned int *
     if (mk == 0u || (mk & ~all)) { sco_set_error("sco_sqp_set_groups: every block needs a group < n_groups"); return SCO_ERR_ARG; }
     for (int g = 0; g < n_groups; g++) if ((mk >> g) & 1u) overlap[g] |= mk & ~(1u << g);    // prob.py:139-142
   }
-  SCO_HIP(hipSetDevice(h->device));
+  SCO_ON_DEVICE(h->device);
   SCO_HIP(hipMemcpy((void *)s.gmask, block_mask, (size_t)s.NB * sizeof(unsigned int), hipMemcpyHostToDevice));
   SCO_HIP(hipMemcpy((void *)s.goverlap, overlap, sizeof overlap, hipMemcpyHostToDevice));
   s.G = n_groups;
@@ -949,7 +949,7 @@ extern "C" int sco_sqp_set_groups(sco_sqp *h, int n_groups, const unsigned int *
 extern "C" int sco_sqp_fetch_flags(sco_sqp *h, int *flags) {
   if (!h || !flags) return SCO_ERR_ARG;
   if (!h->solved) { sco_set_error("sco_sqp_fetch_flags: call sco_sqp_solve first"); return SCO_ERR_STATE; }
-  SCO_HIP(hipSetDevice(h->device));
+  SCO_ON_DEVICE(h->device);
   const size_t B = h->d.batch;
   std::vector<SqpScalars> sc(B);
   SCO_HIP(hipMemcpy(sc.data(), h->d.sc, B * sizeof(SqpScalars), hipMemcpyDeviceToHost));
@@ -960,7 +960,7 @@ extern "C" int sco_sqp_fetch_flags(sco_sqp *h, int *flags) {
 extern "C" int sco_sqp_fetch_groups(sco_sqp *h, unsigned int *nonconverged) {
   if (!h || !nonconverged) return SCO_ERR_ARG;
   if (!h->solved) { sco_set_error("sco_sqp_fetch_groups: call sco_sqp_solve first"); return SCO_ERR_STATE; }
-  SCO_HIP(hipSetDevice(h->device));
+  SCO_ON_DEVICE(h->device);
   SCO_HIP(hipMemcpy(nonconverged, h->d.nonconv, (size_t)h->d.batch * sizeof(unsigned int), hipMemcpyDeviceToHost));
   return SCO_OK;
 }
@@ -970,6 +970,14 @@ static hipEvent_t next_event(sco_sqp *h, size_t &cursor) {
     hipEvent_t e; (void)hipEventCreate(&e); h->events.push_back(e);
   }
   return h->events[cursor++];
+}
+
+// problems the host loop's launch cap left unfinished: failed + SCO_SQP_FLAG_CAPPED
+__global__ void sqp_cap_kernel(SqpDev s) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= s.batch) return;
+  SqpScalars &sc = s.sc[b];
+  if (sc.state != ST_DONE) { sc.state = ST_DONE; sc.success = 0; sc.flags |= SCO_SQP_FLAG_CAPPED; s.active[b] = 0; }
 }
 
 extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco_qp_settings *qs) {
@@ -984,7 +992,26 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   if ((h->desc.family & SCO_FAM_FLAG_JOINT_LIMITS) && !h->jl_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_joint_limits first"); return SCO_ERR_STATE;
   }
-  SCO_HIP(hipSetDevice(h->device));
+  h->solved = false;            // a failed call must not leave an older result readable through fetch / trace
+  // settings are checked before the first launch: nothing on the device is touched by a call that is going to fail
+  if (qs->max_iter <= 0 || !(qs->rho > 0) || !(qs->sigma > 0) || qs->scaling < 0 || !(qs->alpha > 0) || !(qs->alpha < 2)) {
+    sco_set_error("sco_sqp_solve: bad QP settings (max_iter, rho, sigma > 0; 0 < alpha < 2; scaling >= 0)"); return SCO_ERR_ARG;
+  }
+  if (!(params->initial_trust_region_size > 0) || !(params->initial_penalty_coeff > 0) ||
+      !(params->trust_shrink_ratio > 0) || !(params->trust_expand_ratio > 0) || !(params->merit_coeff_increase_ratio > 0) ||
+      params->max_merit_coeff_increases < 0) {
+    sco_set_error("sco_sqp_solve: bad SQP parameters"); return SCO_ERR_ARG;
+  }
+  if (qs->adaptive_rho) {
+    if (!(qs->adaptive_rho_tolerance > 1.0) || qs->check_termination <= 0) {
+      sco_set_error("sco_sqp_solve: adaptive_rho needs adaptive_rho_tolerance > 1 and check_termination > 0"); return SCO_ERR_ARG;
+    }
+    if (!sco_qp_can_adapt(h->qp1)) {
+      sco_set_error("sco_sqp_solve: adaptive_rho: the dense form of the global-memory tier cannot park a solve");
+      return SCO_ERR_CAPACITY;
+    }
+  }
+  SCO_ON_DEVICE(h->device);
   SqpDev &s = h->d;
   SqpParamsDev p{params->improve_ratio_threshold, params->min_trust_region_size, params->min_approx_improve,
                  params->trust_shrink_ratio, params->trust_expand_ratio, params->cnt_tolerance,
@@ -1053,6 +1080,13 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     SCO_HIP(hipStreamSynchronize(h->stream));
     h->rounds++;
   }
+  if (n_active > 0) {
+    // the launch cap ended the loop with problems still running (it is sized so that this cannot happen while every
+    // problem respects max_sqp_iters): they are reported as capped failures, never silently as finished
+    hipLaunchKernelGGL(sqp_cap_kernel, dim3((s.batch + SCO_BLOCK - 1) / SCO_BLOCK), block, 0, h->stream, s);
+    SCO_HIP(hipGetLastError());
+    SCO_HIP(hipStreamSynchronize(h->stream));
+  }
   // ---- timing: sum the event intervals by stage
   double ms[5] = {0, 0, 0, 0, 0};
   for (size_t i = 1; i < ec; i++) {
@@ -1069,7 +1103,7 @@ extern "C" int sco_sqp_fetch(sco_sqp *h, double *x, int *success, int *sqp_iters
                              long long *admm_iters, double *merit, double *max_violation) {
   if (!h) return SCO_ERR_ARG;
   if (!h->solved) { sco_set_error("sco_sqp_fetch: call sco_sqp_solve first"); return SCO_ERR_STATE; }
-  SCO_HIP(hipSetDevice(h->device));
+  SCO_ON_DEVICE(h->device);
   const SqpDev &s = h->d; const size_t B = s.batch;
   if (x) SCO_HIP(hipMemcpy(x, s.x, B * s.n_x * sizeof(double), hipMemcpyDeviceToHost));
   std::vector<SqpScalars> sc(B);
@@ -1097,7 +1131,7 @@ extern "C" int sco_sqp_fetch(sco_sqp *h, double *x, int *success, int *sqp_iters
 extern "C" int sco_sqp_trace(sco_sqp *h, int cap, double *trace, int *n_entries) {
   if (!h || !trace || !n_entries || cap <= 0) return SCO_ERR_ARG;
   if (!h->solved) { sco_set_error("sco_sqp_trace: call sco_sqp_solve first"); return SCO_ERR_STATE; }
-  SCO_HIP(hipSetDevice(h->device));
+  SCO_ON_DEVICE(h->device);
   const SqpDev &s = h->d; const size_t B = s.batch;
   std::vector<double> tr(B * s.trace_cap * TRACE_W);
   std::vector<SqpScalars> sc(B);

@@ -59,3 +59,14 @@ def gather_results(local, total, device=None):
         chunk = raw[r * cap * item: r * cap * item + (rhi - rlo) * item]
         out[rlo:rhi] = np.frombuffer(chunk.tobytes(), dtype=RESULT_DTYPE)
     return out
+
+
+def solve_sharded(shard, total, params=None, qp_settings=None):
+    """One step of the sharded job on this rank: solve the rank's own shard (`shard` is a
+    ``batch.TrajOptBatch`` holding problems [lo, hi) of the `total`), then all-gather the
+    24-byte result records.  Returns (this rank's full fetch result, the (total,) records).
+    No other inter-rank traffic exists on the path."""
+    shard.solve(params, qp_settings)
+    res = shard.fetch(with_merit=True)
+    rec = pack_results(res.merit, res.max_violation, res.success, res.sqp_iters)
+    return res, gather_results(rec, total)

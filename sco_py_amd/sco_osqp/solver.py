@@ -1,22 +1,85 @@
-"""Penalty-SQP driver of the SCO front-end.
+"""Penalty-SQP driver of the SCO front-end (host side).
 
-Mirror of ``sco_py.sco_osqp.solver`` (/root/reference/sco_py/sco_osqp/solver.py):
-same attributes, same ``solve`` signature and return value, same accept / shrink /
-expand / converge decisions in the same order.  Each QP is solved on the GPU via
-``Prob.optimize``; the fully device-resident batch loop lives in
-:mod:`sco_py_amd.batch` (``sco_sqp_*`` in include/sco_hip.h).
+Same public surface as ``sco_py.sco_osqp.solver.Solver`` (/root/reference/sco_py/sco_osqp/solver.py:8-59):
+the eleven tuning attributes with the reference's defaults (:17-28), ``solve(prob, method, tol, verbose,
+osqp_eps_abs, osqp_eps_rel, osqp_max_iter, rho, adaptive_rho, sigma) -> bool``, the exception for an unknown
+method (:59), ``False`` when the projection QP fails (:81-82), and ``prob.nonconverged_groups`` filled on a
+group stall (:209-235).
 
-``Solver.trace`` (not in the reference) records one tuple per trust-region trial so
-that runs can be compared stage by stage.
+The control flow is organised the way the device loop is (``sqp_post_kernel`` in csrc/sco_sqp.hip), not the
+way the reference writes it: every trust-region trial produces one ``Trial`` record of numbers, one pure
+function ``classify_trial`` turns the record into a decision code, and a flat state machine
+(CONVEXIFY -> TRIAL -> ... -> DONE) acts on the code.  The order in which the decisions are tested is part of
+the behaviour (it decides which exit a borderline step takes) and is the reference's:
+bad model (:181) -> y-converged (:196) -> stalled group (:205-235) -> shrink (:237) / accept (:242), and the
+x-convergence test only after a shrink (:248).
+
+``Solver.trace`` (not in the reference) keeps one row per trial, (code, merit, model_merit, new_merit, trust,
+penalty): the artefact the parity tests compare with the device loop and with the golden reference runs.
 """
 import time
+from collections import namedtuple
 
 import numpy as np
 
 from . import osqp_utils
 
-# decision codes stored in the trace (shared with the C ABI, include/sco_hip.h)
+# decision codes (shared with the C ABI, include/sco_hip.h, and with oracle/sco_ref.py)
 STEP_PROJECT, STEP_ACCEPT, STEP_SHRINK, STEP_YCONV, STEP_XCONV, STEP_BAD, STEP_GROUP = range(7)
+
+BAD_MODEL_THRESHOLD = -1e-5          # solver.py:261
+ZERO_IMPROVE_NUDGE = 1e-12           # solver.py:151-152: an exactly zero model improvement is nudged off zero
+
+Thresholds = namedtuple("Thresholds", "improve_ratio min_approx_improve cnt_tolerance")
+Trial = namedtuple("Trial", "merit model_merit new_merit merit_vec model_vec")
+Verdict = namedtuple("Verdict", "code approx_improve exact_improve ratio stalled reported")
+
+
+def classify_trial(trial, thr, group_index, group_overlap, group_order):
+    """Decision for one trust-region trial; a pure function of the trial's numbers.
+
+    ``group_index``: gid -> position in the merit vectors (``prob.gid2ind``); ``group_overlap``: gid -> gids
+    sharing a constraint (``prob._cnt_groups_overlap``); ``group_order``: the gids in vector order (sorted,
+    prob.py:559).  Returns a ``Verdict``: ``stalled`` = the violated groups whose model predicts no progress and
+    none of whose overlapping groups progresses (they end the run); ``reported`` = what the reference leaves in
+    ``prob.nonconverged_groups`` then (the stalled ones followed by every violated group under the y threshold,
+    solver.py:232-234).  STEP_SHRINK here never means x-converged: that depends on the trust size and is the
+    caller's test.
+    """
+    approx = trial.merit - trial.model_merit
+    if not approx:
+        approx += ZERO_IMPROVE_NUDGE
+    exact = trial.merit - trial.new_merit
+    ratio = exact / approx
+
+    def verdict(code, stalled=(), reported=()):
+        return Verdict(code, approx, exact, ratio, list(stalled), list(reported))
+
+    if approx < BAD_MODEL_THRESHOLD:
+        return verdict(STEP_BAD)
+    if approx < thr.min_approx_improve:
+        return verdict(STEP_YCONV)
+
+    per_group = np.asarray(trial.merit_vec, dtype=np.float64) - np.asarray(trial.model_vec, dtype=np.float64)
+    if per_group.shape == (0,):              # no groups: the scalar stands in, and it already passed the y test
+        per_group = np.array([approx])
+        violated = np.array([True])
+    else:
+        violated = np.asarray(trial.merit_vec) > thr.cnt_tolerance
+    stalled = []
+    for gid, k in group_index.items():
+        if not (violated[k] and per_group[k] < thr.min_approx_improve):
+            continue
+        if any(per_group[group_index[other]] > thr.min_approx_improve for other in group_overlap[gid]):
+            continue                         # a group sharing a constraint with it is still making progress
+        stalled.append(gid)
+    if stalled:
+        under = [g for k, g in enumerate(group_order) if violated[k] and per_group[k] < thr.min_approx_improve]
+        return verdict(STEP_GROUP, stalled, stalled + under)
+
+    if exact < 0 or ratio < thr.improve_ratio:
+        return verdict(STEP_SHRINK)
+    return verdict(STEP_ACCEPT)
 
 
 class Solver(object):
@@ -36,6 +99,7 @@ class Solver(object):
         self.initial_penalty_coeff = 1e3
         self.trace = []
 
+    # ------------------------------------------------------------------ public entry
     def solve(self,
               prob,
               method=None,
@@ -48,149 +112,93 @@ class Solver(object):
               adaptive_rho: bool = osqp_utils.DEFAULT_ADAPTIVE_RHO,
               sigma: float = osqp_utils.DEFAULT_SIGMA,
               ):
-        """Returns whether the solve succeeded (solver.py:30-59).  ``tol``
-        permanently overwrites three thresholds of this instance (Q8)."""
+        """Whether the solve succeeded (solver.py:30-59).  ``tol`` permanently overwrites three thresholds of
+        this instance (Q8), also when the method is then rejected."""
         if tol is not None:
-            self.min_trust_region_size = tol
-            self.min_approx_improve = tol
-            self.cnt_tolerance = tol
+            self.min_trust_region_size = self.min_approx_improve = self.cnt_tolerance = tol
         if method != "penalty_sqp":
             raise Exception("This method is not supported.")
-        qp_kw = dict(osqp_eps_abs=osqp_eps_abs, osqp_eps_rel=osqp_eps_rel,
-                     osqp_max_iter=osqp_max_iter, rho=rho, adaptive_rho=adaptive_rho, sigma=sigma)
-        return self._penalty_sqp(prob, verbose=verbose, **qp_kw)
+        return self._penalty_sqp(prob, verbose=verbose, osqp_eps_abs=osqp_eps_abs, osqp_eps_rel=osqp_eps_rel,
+                                 osqp_max_iter=osqp_max_iter, rho=rho, adaptive_rho=adaptive_rho, sigma=sigma)
 
-    # @profile
+    # ------------------------------------------------------------------ outer loop
     def _penalty_sqp(self, prob, verbose=False, **qp_kw):
-        """Outer loop: project onto the linear constraints, then minimise the
-        merit function, raising the penalty coefficient while the constraints stay
-        violated (solver.py:62-105)."""
-        t0 = time.time()
+        """Project onto the linear constraints, then minimise the merit function once per penalty level,
+        raising the penalty while the constraints stay violated (solver.py:62-105)."""
+        say = _Narrator(verbose)
+        clock = time.time()
         self.trace = []
-        trust = self.initial_trust_region_size
-        penalty = self.initial_penalty_coeff
-
-        # the projection QP runs with DEFAULT solver settings (Q7, solver.py:81)
-        if not prob.find_closest_feasible_point():
+        if not prob.find_closest_feasible_point():        # default QP settings on purpose (Q7, solver.py:81)
             return False
-        self.trace.append((STEP_PROJECT, 0.0, 0.0, 0.0, trust, penalty))
+        penalty = self.initial_penalty_coeff
+        self.trace.append((STEP_PROJECT, 0.0, 0.0, 0.0, self.initial_trust_region_size, penalty))
+        outcome = False
+        for _level in range(self.max_merit_coeff_increases):
+            minimised = self._min_merit_fn(prob, penalty, self.initial_trust_region_size, verbose=verbose, **qp_kw)
+            if prob.get_max_cnt_violation() <= self.cnt_tolerance:
+                outcome = minimised
+                break
+            penalty *= self.merit_coeff_increase_ratio    # still infeasible: next level starts from the full trust box
+        say("penalty sqp finished in %.3f s" % (time.time() - clock))
+        return outcome
 
-        for _ in range(self.max_merit_coeff_increases):
-            success = self._min_merit_fn(prob, penalty, trust, verbose=verbose, **qp_kw)
-            if verbose:
-                print("\n")
-            if prob.get_max_cnt_violation() > self.cnt_tolerance:
-                penalty = penalty * self.merit_coeff_increase_ratio
-                trust = self.initial_trust_region_size
-            else:
-                if verbose:
-                    print("sqp time: ", time.time() - t0)
-                return success
-        if verbose:
-            print("sqp time: ", time.time() - t0)
-        return False
-
-    # @profile
+    # ------------------------------------------------------------------ inner loop
     def _min_merit_fn(self, prob, penalty_coeff, trust_region_size, verbose=False, **qp_kw):
-        """Trust-region minimisation of the l1 merit function for a fixed penalty
-        coefficient (solver.py:108-253)."""
-        sqp_iter = 1
+        """Trust-region minimisation of the l1 merit function at a fixed penalty coefficient
+        (solver.py:108-253) as a two-state machine: CONVEXIFY builds the model at the current point and saves
+        it; TRIAL solves the boxed QP and lets ``classify_trial`` decide."""
+        say = _Narrator(verbose)
+        thr = Thresholds(self.improve_ratio_threshold, self.min_approx_improve, self.cnt_tolerance)
+        trust = trust_region_size
+        state, sqp_iter = "CONVEXIFY", 0
+        base_merit = base_vec = None
         while True:
-            if verbose:
-                print("  sqp_iter: {0}".format(sqp_iter))
-            prob.convexify()
-            prob.update_obj(penalty_coeff)
-            merit = prob.get_value(penalty_coeff)
-            merit_vec = prob.get_value(penalty_coeff, True)
-            prob.save()
+            if state == "CONVEXIFY":
+                sqp_iter += 1
+                prob.convexify()
+                prob.update_obj(penalty_coeff)
+                base_merit = prob.get_value(penalty_coeff)
+                base_vec = prob.get_value(penalty_coeff, True)
+                prob.save()
+                say("sqp iteration %d: merit %r" % (sqp_iter, base_merit))
+                state = "TRIAL"
+                continue
 
-            while True:
-                if verbose:
-                    print("    trust region size: {0}".format(trust_region_size))
-                prob.add_trust_region(trust_region_size)
-                _ = prob.optimize(verbose=verbose, **qp_kw)     # result ignored (Q6)
-                model_merit = prob.get_approx_value(penalty_coeff)
-                model_merit_vec = prob.get_approx_value(penalty_coeff, True)
-                new_merit = prob.get_value(penalty_coeff)
+            prob.add_trust_region(trust)
+            prob.optimize(verbose=verbose, **qp_kw)        # a failed QP leaves the point where it was (Q6)
+            trial = Trial(base_merit, prob.get_approx_value(penalty_coeff), prob.get_value(penalty_coeff),
+                          base_vec, prob.get_approx_value(penalty_coeff, True))
+            v = classify_trial(trial, thr, prob.gid2ind, prob._cnt_groups_overlap, sorted(prob._cnt_groups.keys()))
+            row = (trial.merit, trial.model_merit, trial.new_merit, trust, penalty_coeff)
+            say("  trust %g: model %r, new %r, improvement model %.3e / exact %.3e (ratio %.3g) -> %s"
+                % (trust, trial.model_merit, trial.new_merit, v.approx_improve, v.exact_improve, v.ratio,
+                   _CODE_NAMES[v.code]))
 
-                approx_improve = merit - model_merit
-                if not approx_improve:
-                    approx_improve += 1e-12
-                exact_improve = merit - new_merit
-                ratio = exact_improve / approx_improve
+            if v.code in (STEP_BAD, STEP_YCONV):
+                prob.restore()
+                self.trace.append((v.code,) + row)
+                return v.code == STEP_YCONV
+            # from here on the group report is fresh for this trial (solver.py:209)
+            prob.nonconverged_groups = list(v.reported)
+            if v.code == STEP_GROUP:
+                prob.restore()
+                self.trace.append((STEP_GROUP,) + row)
+                return True
+            if v.code == STEP_ACCEPT:
+                self.trace.append((STEP_ACCEPT,) + row)
+                trust *= self.trust_expand_ratio
+                state = "CONVEXIFY"
+                continue
+            prob.restore()                                  # STEP_SHRINK
+            trust *= self.trust_shrink_ratio
+            if self._x_converged(trust):
+                self.trace.append((STEP_XCONV,) + row)      # one trace row per QP solve
+                return True
+            self.trace.append((STEP_SHRINK,) + row)
 
-                # per-group bookkeeping; with no groups the scalar takes their place
-                approx_improve_vec = merit_vec - model_merit_vec
-                violated = merit_vec > self.cnt_tolerance
-                if approx_improve_vec.shape == (0,):
-                    approx_improve_vec = np.array([approx_improve])
-                    violated = approx_improve_vec > -np.inf
-
-                if verbose:
-                    print("      merit: {0}. model_merit: {1}. new_merit: {2}".format(
-                        merit, model_merit, new_merit))
-                    print("      approx_merit_improve: {0}. exact_merit_improve: {1}. "
-                          "merit_improve_ratio: {2}".format(approx_improve, exact_improve, ratio))
-
-                rec = (merit, model_merit, new_merit, trust_region_size, penalty_coeff)
-                if self._bad_model(approx_improve):
-                    if verbose:
-                        print("Approximate merit function got worse ({0})".format(approx_improve))
-                        print("Either convexification is wrong to zeroth order, or you're in "
-                              "numerical trouble.")
-                    prob.restore()
-                    self.trace.append((STEP_BAD,) + rec)
-                    return False
-
-                if self._y_converged(approx_improve):
-                    if verbose:
-                        print("Converged: y tolerance")
-                    prob.restore()
-                    self.trace.append((STEP_YCONV,) + rec)
-                    return True
-
-                # a violated group whose model predicts no progress, and none of
-                # whose overlapping groups is progressing, ends the run
-                prob.nonconverged_groups = []
-                for gid, idx in prob.gid2ind.items():
-                    if violated[idx] and approx_improve_vec[idx] < self.min_approx_improve:
-                        if any(approx_improve_vec[prob.gid2ind[g2]] > self.min_approx_improve
-                               for g2 in prob._cnt_groups_overlap[gid]):
-                            continue
-                        prob.nonconverged_groups.append(gid)
-                if len(prob.nonconverged_groups) > 0:
-                    if verbose:
-                        print("Converged: y tolerance")
-                    prob.restore()
-                    for i, g in enumerate(sorted(prob._cnt_groups.keys())):
-                        if violated[i] and self._y_converged(approx_improve_vec[i]):
-                            prob.nonconverged_groups.append(g)
-                    self.trace.append((STEP_GROUP,) + rec)
-                    return True
-
-                if self._shrink_trust_region(exact_improve, ratio):
-                    prob.restore()
-                    if verbose:
-                        print("Shrinking trust region")
-                    self.trace.append((STEP_SHRINK,) + rec)
-                    trust_region_size = trust_region_size * self.trust_shrink_ratio
-                else:
-                    if verbose:
-                        print("Growing trust region")
-                    self.trace.append((STEP_ACCEPT,) + rec)
-                    trust_region_size = trust_region_size * self.trust_expand_ratio
-                    break
-
-                if self._x_converged(trust_region_size):
-                    if verbose:
-                        print("Converged: x tolerance")
-                    self.trace[-1] = (STEP_XCONV,) + rec      # one trace row per QP solve
-                    return True
-
-            sqp_iter = sqp_iter + 1
-
+    # ------------------------------------------------------------------ the reference's predicate names
     def _bad_model(self, approx_merit_improve):
-        return approx_merit_improve < -1e-5                 # solver.py:261
+        return approx_merit_improve < BAD_MODEL_THRESHOLD
 
     def _shrink_trust_region(self, exact_merit_improve, merit_improve_ratio):
         return (exact_merit_improve < 0) or (merit_improve_ratio < self.improve_ratio_threshold)
@@ -200,3 +208,19 @@ class Solver(object):
 
     def _y_converged(self, approx_merit_improve):
         return approx_merit_improve < self.min_approx_improve
+
+
+_CODE_NAMES = {STEP_PROJECT: "project", STEP_ACCEPT: "accept, expand", STEP_SHRINK: "reject, shrink",
+               STEP_YCONV: "converged (model improvement)", STEP_XCONV: "converged (trust region)",
+               STEP_BAD: "model got worse: give up", STEP_GROUP: "converged (stalled constraint group)"}
+
+
+class _Narrator(object):
+    """verbose=True progress lines (wording is ours; the reference prints different text)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __call__(self, text):
+        if self.on:
+            print(text)

@@ -438,3 +438,36 @@ def test_adaptive_rho_is_passed_down_the_seam(backend):
     assert np.allclose(var.get_value(), 2.0, atol=1e-4)
     # the projection QP runs with the defaults, the penalty QPs with the caller's settings
     assert [s[5] for s in seen][0] == 0.0 and all(s[5] == 1.0 for s in seen[1:]) and len(seen) > 1
+
+
+def test_classify_trial_takes_the_exits_in_the_reference_order():
+    """solver.py:181-251: bad model -> y-converged -> stalled group -> shrink / accept, on crafted numbers."""
+    from sco_py_amd.sco_osqp import solver as sv
+    thr = sv.Thresholds(0.25, 1e-8, 1e-4)
+    none = ({}, {}, [])
+    e = np.zeros(0)
+
+    def code(merit, model, new, mv=e, av=e, groups=none):
+        return sv.classify_trial(sv.Trial(merit, model, new, mv, av), thr, *groups)
+
+    assert code(1.0, 1.1, 0.0).code == sv.STEP_BAD                       # model worse than -1e-5 wins over everything
+    assert code(1.0, 1.0 - 1e-9, 5.0).code == sv.STEP_YCONV              # under the y threshold, even though new is worse
+    v = code(1.0, 1.0, 1.0)                                              # exactly zero improvement is nudged to 1e-12
+    assert v.code == sv.STEP_YCONV and v.approx_improve == 1e-12
+    assert code(1.0, 0.5, 0.95).code == sv.STEP_SHRINK                   # ratio 0.1 < 0.25
+    assert code(1.0, 0.5, 1.2).code == sv.STEP_SHRINK                    # exact improvement negative
+    assert code(1.0, 0.5, 0.6).code == sv.STEP_ACCEPT
+    # groups "a", "b" overlap, "c" stands alone; vector order is the sorted ids
+    gi = {"a": 0, "b": 1, "c": 2}
+    ov = {"a": {"b"}, "b": {"a"}, "c": set()}
+    groups = (gi, ov, ["a", "b", "c"])
+    mv = np.array([1.0, 1.0, 1.0])
+    # "a" predicts nothing but its neighbour "b" progresses: no stall; the accept test decides
+    v = code(3.0, 2.0, 2.1, mv, np.array([1.0, 0.5, 0.5]), groups)
+    assert v.code == sv.STEP_ACCEPT and v.reported == []
+    # "c" violated, no progress, no overlap: stall; the report lists it, then every violated group under the threshold
+    v = code(3.0, 2.0, 2.1, mv, np.array([1.0, 0.5, 1.0]), groups)
+    assert v.code == sv.STEP_GROUP and v.stalled == ["c"] and v.reported == ["c", "a", "c"]
+    # a satisfied group (merit below cnt_tolerance) cannot stall
+    v = code(3.0, 2.0, 2.1, np.array([1.0, 1.0, 1e-5]), np.array([0.5, 0.5, 1e-5]), groups)
+    assert v.code == sv.STEP_ACCEPT

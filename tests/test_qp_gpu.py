@@ -470,3 +470,15 @@ def test_both_core_inversion_routes_agree(gpu, monkeypatch):
         monkeypatch.setenv("SCO_QP_FACTOR_CHOLESKY", "1")
         _, x_c, st_c, it_c = _check(probs, check=[])
         assert np.array_equal(st_s, st_c) and np.array_equal(it_s, it_c) and np.abs(x_s - x_c).max() < 1e-10
+
+
+def test_null_index_array_with_a_non_empty_pattern_is_rejected(gpu):
+    import ctypes as C
+    lib = _lib.load()
+    h = C.c_void_p()
+    Pp = np.array([0, 1], dtype=np.int32); Ap = np.array([0, 1], dtype=np.int32); Ai = np.array([0], dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    rc = lib.sco_qp_create(0, 1, 1, 1, ip(Pp), None, ip(Ap), ip(Ai), C.byref(h))
+    assert rc == -1 and not h.value
+    rc = lib.sco_qp_create(0, 1, 1, 1, ip(Pp), ip(Ai), ip(Ap), None, C.byref(h))
+    assert rc == -1 and not h.value

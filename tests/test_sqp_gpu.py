@@ -598,3 +598,37 @@ def test_non_finite_problem_data_fails_that_problem_only(gpu):
     res = sb.solve_batch(arrays, params=_lib.default_sqp_params(max_sqp_iters=30))
     assert not bool(res.success[2])
     _compare(res, probs, [0, 1, 3])
+
+
+def test_failed_solve_leaves_no_stale_result_and_bad_settings_fail_before_any_launch(gpu):
+    """A call that is going to fail touches nothing on the device and does not leave an older result readable."""
+    arrays, probs = af.make_batch(2, **SMALL)
+    with sb.TrajOptBatch(2, SMALL["d"], SMALL["T"], SMALL["K"], SMALL["O"]) as tb:
+        tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                arrays["point_frac"], arrays["obstacles"])
+        tb.solve()
+        good = tb.fetch()
+        for bad in (dict(max_iter=0), dict(rho=0.0), dict(sigma=-1.0), dict(alpha=2.5),
+                    dict(adaptive_rho=1, adaptive_rho_tolerance=0.5)):
+            with pytest.raises(_lib.ScoHipError):
+                tb.solve(None, _lib.default_qp_settings(**bad))
+            with pytest.raises(_lib.ScoHipError):      # the earlier result is gone, not mixed with a half-run one
+                tb.fetch()
+        with pytest.raises(_lib.ScoHipError):
+            tb.solve(_lib.default_sqp_params(initial_trust_region_size=0.0))
+        tb.solve()
+        again = tb.fetch()
+        assert np.array_equal(good.x, again.x) and np.array_equal(good.sqp_iters, again.sqp_iters)
+
+
+def test_entry_points_put_the_callers_device_back(gpu):
+    """Every ABI call runs on its handle's device and restores the caller's current device (one device here: the
+    check is that the current device is unchanged and HIP state stays usable around create/solve/destroy)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    cur = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(cur)) == 0
+    before = cur.value
+    arrays, _ = af.make_batch(1, **SMALL)
+    sb.solve_batch(arrays)
+    assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == before
