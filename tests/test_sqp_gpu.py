@@ -131,6 +131,16 @@ def test_full_size_batch_properties(gpu):
     assert np.all(np.isfinite(res.x))
 
 
+def test_full_size_batch_sampled_against_the_oracle(gpu):
+    """BASELINE configs[2] at full size: every 16th problem of the 1024-problem bench batch against the oracle
+    (same decisions, QP statuses, ADMM iteration counts per QP, merits, trajectory to 1e-6) -- the driver-run
+    slice of the whole-batch sweeps in scripts/gpu_parity_sweep.py (64 oracle solves, about a minute of CPU)."""
+    B = 1024
+    arrays, probs = af.make_batch(B)
+    res = sb.solve_batch(arrays)
+    _compare(res, probs, range(0, B, 16))
+
+
 def test_descriptor_validation(gpu):
     with pytest.raises(_lib.ScoHipError) as e:
         sb.TrajOptBatch(0, 3, 6, 2, 2)
