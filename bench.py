@@ -76,9 +76,9 @@ def cpu_baseline_all_cores(dims, per_core=8, timeout=240):
     the moment every worker has reported ready to the last result.  Plain child processes, started before anything
     touches the GPU; returns None if a worker fails or overruns."""
     import subprocess
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    nproc = cores
-    cores = max(1, min(cores, 64))
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = _cpu_share()                      # a container may own fewer CPUs than it can see
+    cores = max(1, min(nproc, share if share else nproc, 64))
     # children never touch the GPU: drop any profiler preload / tool hooks from their environment
     env = {k: v for k, v in os.environ.items()
            if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER"))}
@@ -111,10 +111,31 @@ def cpu_baseline_all_cores(dims, per_core=8, timeout=240):
             if pr.poll() is None:
                 pr.kill()
         return None
-    return {"value": iters / dt, "unit": "sco_iters/s", "cores": cores, "nproc": nproc, "kind": "port",
+    return {"value": iters / dt, "unit": "sco_iters/s", "cores": cores, "nproc": nproc, "cpu_share": share, "kind": "port",
             "threads_per_process": 1,
             "sample": "problems 0..%d of the same batch, %d per single-threaded oracle process, one process per core, "
                       "%.1f s after the ready handshake (start-up excluded)" % (cores * per_core - 1, per_core, dt)}
+
+
+def _cpu_share():
+    """CPUs this container may actually use (cgroup quota), or None if unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                     # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:        # cgroup v1
+            quota = int(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            period = int(fh.read())
+        if quota > 0:
+            return max(1, quota // period)
+    except Exception:
+        pass
+    return None
 
 
 def _free_port():

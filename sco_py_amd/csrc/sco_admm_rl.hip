@@ -16,8 +16,8 @@
 // One iteration = 3 phases / 3 barriers (the profile of the 6-phase kernel,
 // profiles/r01_v4_pmc_summary.txt, showed 54 % of wave time in s_waitcnt/s_barrier):
 //   (1)  core-variable owners:  r_c                     (CW-entry gather-dot)
-//   (3)  all 512 threads:       register-tile W mat-vec; the 16 partial sums of a row
-//                                 are added across a DPP row (row_shr), no LDS hop
+//   (3)  all 512 threads:       register-tile W mat-vec; the 16 partial sums of a row are
+//                                 folded with lane swaps (rl_reduce_rows), no LDS hop
 //   (Y)  row owners:            core part of A x~, x~_e, z / y / x updates, t'
 // Data placement as in sco_admm_reg.hip: W tile and packed byte offsets in
 // registers, sparse values in LDS sliced-ELL images built in thread order
@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #define LT 512
@@ -34,9 +35,10 @@
 #define LGI (LT / LGJ)
 #define LCAP_M 1024
 #define LCAP_NC 160
-#define LCW 12          // entries of a core variable's column (default; 16 for the widest instantiation)
+#define LCW 12          // value slots of a core variable's column = 2 x operand pairs (default; 16 for the widest instantiation)
 #define LCW_MAX 16
-#define LRW 8           // core entries of a row
+#define LRW 8           // value slots of a row's core entries (4 aligned pairs)
+#define RL_ROLES 18
 
 // Paired sliced-ELL: slices of 64 items (one wavefront); entries 2h and 2h+1 of lane l
 // sit next to each other at base[s] + (64 h + l) * 2, so one ds_read_b128 per lane
@@ -63,8 +65,83 @@ static void build_sell2(int nitems, const std::vector<int> &ptr, const std::vect
 // --------------------------------------------------------------------------
 // host: thread assignment and per-thread programs
 // --------------------------------------------------------------------------
+// Thread assignment in which every core column sits in the SAME wavefront as all of its rows ("closed"): the
+// connected components of the row / core-column graph (rows of one eliminated variable tied together) are packed
+// whole into wavefronts.  Then the column sums A_C' t' of phase (1) only read t' values written by their own
+// wavefront, phase (1) follows phase (Y) without a workgroup barrier, and all eight wavefronts share the column
+// work (in a trajectory QP a component is a timestep).  False if a component needs more than 64 threads or the
+// components do not pack: the caller keeps the barrier then.
+static bool rl_assign_closed(const QpPlan &pl, const std::vector<int> &row_elim, const std::vector<std::vector<int>> &erows,
+                             std::vector<int> &slot_row, std::vector<int> &thr_core, std::vector<int> &thr_elim) {
+  const int m = pl.m, nc = pl.n_c, ne = pl.n_e;
+  std::vector<int> uf(m + nc + ne);
+  for (size_t i = 0; i < uf.size(); i++) uf[i] = (int)i;
+  auto find = [&](int a) { while (uf[a] != a) { uf[a] = uf[uf[a]]; a = uf[a]; } return a; };
+  auto unite = [&](int a, int b) { a = find(a); b = find(b); if (a != b) uf[a] = b; };
+  for (int i = 0; i < m; i++)
+    for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
+      const int c = pl.core_of[pl.Rj[s]];
+      if (c >= 0) unite(i, m + c);
+    }
+  for (int e = 0; e < ne; e++) for (int i : erows[e]) unite(m + nc + e, i);
+  struct Comp { std::vector<int> cols, elims, free_rows; int need = 0; };
+  std::vector<Comp> comps;
+  std::vector<int> comp_of(uf.size(), -1);
+  auto comp = [&](int node) -> Comp & {
+    const int r = find(node);
+    if (comp_of[r] < 0) { comp_of[r] = (int)comps.size(); comps.emplace_back(); }
+    return comps[comp_of[r]];
+  };
+  for (int c = 0; c < nc; c++) comp(m + c).cols.push_back(c);
+  for (int e = 0; e < ne; e++) comp(m + nc + e).elims.push_back(e);
+  for (int i = 0; i < m; i++) if (row_elim[i] < 0) comp(i).free_rows.push_back(i);
+  for (Comp &k : comps) {
+    int spare = 0;
+    for (int e : k.elims) spare += 2 - (int)erows[e].size();
+    const int extra = std::max(0, (int)k.free_rows.size() - spare);
+    k.need = std::max((int)k.elims.size() + (extra + 1) / 2, (int)k.cols.size());
+    if (k.need > 64) return false;
+    if (k.need == 0) k.need = 1;
+  }
+  std::vector<int> order(comps.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return comps[a].need > comps[b].need; });
+  int load[LWV] = {0};
+  std::vector<std::vector<int>> bin(LWV);
+  for (int k : order) {
+    int best = -1;
+    for (int w = 0; w < LWV; w++)
+      if (load[w] + comps[k].need <= 64 && (best < 0 || load[w] < load[best])) best = w;
+    if (best < 0) return false;
+    load[best] += comps[k].need; bin[best].push_back(k);
+  }
+  slot_row.assign(2 * LT, -1); thr_core.assign(LT, -1); thr_elim.assign(LT, -1);
+  for (int w = 0; w < LWV; w++) {
+    int base = 64 * w;
+    for (int k : bin[w]) {
+      const Comp &K = comps[k];
+      int t = base;
+      for (int e : K.elims) {
+        thr_elim[t] = e;
+        for (size_t q = 0; q < erows[e].size(); q++) slot_row[q * LT + t] = erows[e][q];
+        t++;
+      }
+      for (size_t j = 0; j < K.cols.size(); j++) thr_core[base + (int)j] = K.cols[j];
+      // rows without an eliminated variable: the threads behind the eliminated ones first (slot 0, then 1), then
+      // the slots the eliminated variables left empty
+      std::vector<int> slots;
+      for (int q = 0; q < 2; q++) for (int u = t; u < base + K.need; u++) slots.push_back(q * LT + u);
+      for (int q = 0; q < 2; q++) for (int u = base; u < t; u++) if (slot_row[q * LT + u] < 0) slots.push_back(q * LT + u);
+      if (slots.size() < K.free_rows.size()) return false;
+      for (size_t j = 0; j < K.free_rows.size(); j++) slot_row[slots[j]] = K.free_rows[j];
+      base += K.need;
+    }
+  }
+  return true;
+}
+
 bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
-  if (pl.n_c >= LCAP_NC || pl.m >= LCAP_M || pl.n_e > LT || pl.n_c > LT || pl.nnzA >= 65536 || pl.n > 2 * LT) return false;
+  if (pl.n_c + 4 > LCAP_NC || pl.m >= LCAP_M || pl.n_e > LT || pl.n_c > LT || pl.nnzA >= 65536 || pl.n > 2 * LT) return false;
   const int m = pl.m;
   // rows of every eliminated variable; every row's eliminated variable
   std::vector<int> row_elim(m, -1), row_epos(m, -1);
@@ -78,11 +155,19 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
       }
     }
   for (int e = 0; e < pl.n_e; e++) if (erows[e].size() > 2) return false;
-  // ---- thread assignment: slot (q, t) -> row
-  std::vector<int> slot_row(2 * LT, -1);
-  for (int e = 0; e < pl.n_e; e++)                 // eliminated variable e -> thread e
-    for (size_t q = 0; q < erows[e].size(); q++) slot_row[q * LT + e] = erows[e][q];
-  {
+  // ---- thread assignment: slot (q, t) -> row, thread -> core / eliminated variable
+  std::vector<int> slot_row, thr_core, thr_elim;
+  // The closed assignment is measured slower on the trajectory QPs (every wavefront then runs the widest row AND
+  // column code, 957 against 871 ms per bench step), so it is opt-in: SCO_QP_RL_CLOSED=1.
+  const char *closed = getenv("SCO_QP_RL_CLOSED");
+  rh.merged = closed && closed[0] == '1' && rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim);
+  if (!rh.merged) {
+    slot_row.assign(2 * LT, -1); thr_core.assign(LT, -1); thr_elim.assign(LT, -1);
+    for (int e = 0; e < pl.n_e; e++) {               // eliminated variable e -> thread e
+      thr_elim[e] = e;
+      for (size_t q = 0; q < erows[e].size(); q++) slot_row[q * LT + e] = erows[e][q];
+    }
+    for (int c = 0; c < pl.n_c; c++) thr_core[LT - 1 - c] = c;   // far from the eliminated-variable threads
     int cur = 0;
     std::vector<int> order;                        // free slots: threads without an eliminated variable first
     for (int q = 0; q < 2; q++) for (int t = pl.n_e; t < LT; t++) order.push_back(q * LT + t);
@@ -94,81 +179,125 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
       slot_row[order[cur]] = i;
     }
   }
-  // core variable c -> thread LT - 1 - c (far from the eliminated-variable threads)
-  // ---- sliced-ELL images in thread order
+  // ---- LDS positions of the row vectors (t', and w y / dy of the termination test).  A gather-dot reads its
+  // operands two at a time (one ds_read_b128 per aligned PAIR of positions), so rows that one column reads together
+  // should sit next to each other: rows with several core entries keep their order (the rows of one constraint
+  // block are consecutive and share their columns), then the rows with a single core entry grouped by that column
+  // (trust-region row, pin, joint limit of the same variable), every group on an even position.  Rows without a
+  // core entry are never gathered and get no position.
+  std::vector<int> pos(m, -1);
+  int npos = 0;
   {
-    // columns of core variables, item = thread
-    std::vector<int> ptr(LT + 1, 0), idx, src;
-    for (int t = 0; t < LT; t++) {
-      const int c = LT - 1 - t;
-      if (c < pl.n_c) {
-        const int j = pl.core_var[c];
-        if (pl.Ap[j + 1] - pl.Ap[j] > LCW_MAX) return false;
-        if (pl.Ap[j + 1] - pl.Ap[j] > LCW) rh.CW = LCW_MAX;
-        for (int p = pl.Ap[j]; p < pl.Ap[j + 1]; p++) { idx.push_back(pl.Ai[p]); src.push_back(p); }
+    std::vector<int> ncore(m, 0), onecol(m, -1);
+    for (int i = 0; i < m; i++)
+      for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
+        const int c = pl.core_of[pl.Rj[s]];
+        if (c >= 0) { ncore[i]++; onecol[i] = c; }
       }
-      ptr[t + 1] = (int)idx.size();
+    for (int i = 0; i < m; i++) if (ncore[i] >= 2) pos[i] = npos++;
+    std::vector<std::vector<int>> singles(pl.n_c);
+    for (int i = 0; i < m; i++) if (ncore[i] == 1) singles[onecol[i]].push_back(i);
+    for (int c = 0; c < pl.n_c; c++) {
+      if (singles[c].empty()) continue;
+      npos = (npos + 1) & ~1;
+      for (int i : singles[c]) pos[i] = npos++;
     }
-    build_sell2(LT, ptr, src, rh.Ac);
+    npos = (npos + 1) & ~1;                            // the always-zero pair sits at npos, npos + 1
+    rh.zpos = npos;
+    npos += 2;
+    for (int i = 0; i < m; i++) if (ncore[i] == 0) pos[i] = npos++;    // written, never gathered (no predicate in the loop)
+    if (npos > LCAP_M) return false;
   }
-  for (int q = 0; q < 2; q++) {
-    std::vector<int> ptr(LT + 1, 0), idx, src;
-    for (int t = 0; t < LT; t++) {
-      const int i = slot_row[q * LT + t];
-      if (i >= 0) {
-        int cnt = 0;
-        for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
-          const int c = pl.core_of[pl.Rj[s]];
-          if (c >= 0) { idx.push_back(c); src.push_back(pl.Rpos[s]); cnt++; }
-        }
-        if (cnt > LRW) return false;
-      }
-      ptr[t + 1] = (int)idx.size();
+  const int zcore = (pl.n_c + 1) & ~1;                 // always-zero pair of the core vectors
+  if (zcore + 2 > LCAP_NC) return false;
+  // pair lists: item -> [(pair index, source of the even element, source of the odd element)], -1 = structural zero
+  struct Pair { int p, s0, s1; };
+  auto make_pairs = [](std::vector<std::pair<int, int>> ent) {       // (position, source) -> pairs by position / 2
+    std::sort(ent.begin(), ent.end());
+    std::vector<Pair> out;
+    for (auto &e : ent) {
+      if (out.empty() || out.back().p != e.first / 2) out.push_back({e.first / 2, -1, -1});
+      ((e.first & 1) ? out.back().s1 : out.back().s0) = e.second;
     }
-    build_sell2(LT, ptr, src, q == 0 ? rh.Ar0 : rh.Ar1);
-  }
-  rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rh.Ar0.total + rh.Ar1.total + 64 * 16 + 5 * LT) + 12 * 4 * LCAP_NC;   // + check constants
-  // ---- per-thread tables: packed gather offsets and roles
-  const int CWv = rh.CW;
-  const int slots = CWv + 2 * LRW;
-  rh.off.assign((size_t)slots * LT, 0);
-  rh.role.assign((size_t)16 * LT, -1);
+    return out;
+  };
+  std::vector<std::vector<Pair>> colp(LT), rowp[2];
+  rowp[0].resize(LT); rowp[1].resize(LT);
+  size_t maxc = 0;
   for (int t = 0; t < LT; t++) {
-    for (int k = 0; k < CWv; k++) rh.off[(size_t)k * LT + t] = (unsigned short)(8 * m);             // zero of t'
-    for (int k = 0; k < 2 * LRW; k++) rh.off[(size_t)(CWv + k) * LT + t] = (unsigned short)(8 * pl.n_c);   // zero of x_C
+    const int c = thr_core[t];
+    if (c >= 0) {
+      const int j = pl.core_var[c];
+      std::vector<std::pair<int, int>> ent;
+      for (int p = pl.Ap[j]; p < pl.Ap[j + 1]; p++) ent.push_back({pos[pl.Ai[p]], p});
+      colp[t] = make_pairs(ent);
+      maxc = std::max(maxc, colp[t].size());
+    }
+    for (int q = 0; q < 2; q++) {
+      const int i = slot_row[q * LT + t];
+      if (i < 0) continue;
+      std::vector<std::pair<int, int>> ent;
+      for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
+        const int c2 = pl.core_of[pl.Rj[s]];
+        if (c2 >= 0) ent.push_back({c2, pl.Rpos[s]});
+      }
+      rowp[q][t] = make_pairs(ent);
+      if (rowp[q][t].size() > LRW / 2) return false;
+    }
+  }
+  if (maxc > LCW_MAX / 2) return false;
+  if (maxc > LCW / 2) rh.CW = LCW_MAX;
+  // ---- sliced-ELL images in thread order: two value slots per pair
+  auto image = [&](const std::vector<std::vector<Pair>> &items, SellHost &out) {
+    std::vector<int> ptr(LT + 1, 0), src;
+    for (int t = 0; t < LT; t++) {
+      for (const Pair &pr : items[t]) { src.push_back(pr.s0); src.push_back(pr.s1); }
+      ptr[t + 1] = (int)src.size();
+    }
+    build_sell2(LT, ptr, src, out);
+  };
+  image(colp, rh.Ac); image(rowp[0], rh.Ar0); image(rowp[1], rh.Ar1);
+  rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rh.Ar0.total + rh.Ar1.total + 64 * 16 + 5 * LT) + 12 * 4 * LCAP_NC;   // + check constants
+  // ---- per-thread tables: packed pair offsets (bytes) and roles
+  const int CPv = rh.CW / 2;
+  const int slots = CPv + 2 * (LRW / 2);
+  rh.off.assign((size_t)slots * LT, 0);
+  rh.role.assign((size_t)RL_ROLES * LT, -1);
+  for (int t = 0; t < LT; t++) {
+    for (int k = 0; k < CPv; k++) rh.off[(size_t)k * LT + t] = (unsigned short)(8 * rh.zpos);               // zero pair of t'
+    for (int k = 0; k < LRW; k++) rh.off[(size_t)(CPv + k) * LT + t] = (unsigned short)(8 * zcore);       // zero pair of x_C
     // role table: 0 core idx, 1 core var, 2 elim idx, 3 elim var, 4/5 row of slot 0/1,
     //             6/7 CSC position of the row's eliminated coefficient, 8 col base, 9/10 row bases,
-    //             11/12 position of P_jj for the core / eliminated variable
+    //             11/12 position of P_jj for the core / eliminated variable, 13-15 trip counts,
+    //             16/17 LDS position of the row of slot 0/1
     rh.role[(size_t)8 * LT + t] = rh.Ac.base[t / 64] + 2 * (t % 64);
     rh.role[(size_t)9 * LT + t] = rh.Ac.total + rh.Ar0.base[t / 64] + 2 * (t % 64);
     rh.role[(size_t)10 * LT + t] = rh.Ac.total + rh.Ar0.total + rh.Ar1.base[t / 64] + 2 * (t % 64);
-    rh.role[(size_t)13 * LT + t] = rh.Ac.width[t / 64];      // wave-uniform trip counts
+    rh.role[(size_t)13 * LT + t] = rh.Ac.width[t / 64];      // wave-uniform trip counts (value slots = 2 x pairs)
     rh.role[(size_t)14 * LT + t] = rh.Ar0.width[t / 64];
     rh.role[(size_t)15 * LT + t] = rh.Ar1.width[t / 64];
-    const int c = LT - 1 - t;
-    if (c < pl.n_c) {
+    const int c = thr_core[t];
+    if (c >= 0) {
       const int j = pl.core_var[c];
       rh.role[t] = c; rh.role[(size_t)LT + t] = j; rh.role[(size_t)11 * LT + t] = pl.Pdiag[j];
-      int k = 0;
-      for (int p = pl.Ap[j]; p < pl.Ap[j + 1]; p++, k++) rh.off[(size_t)k * LT + t] = (unsigned short)(8 * pl.Ai[p]);
+      for (size_t k = 0; k < colp[t].size(); k++) rh.off[k * LT + t] = (unsigned short)(16 * colp[t][k].p);
     }
-    if (t < pl.n_e) {
-      rh.role[(size_t)2 * LT + t] = t; rh.role[(size_t)3 * LT + t] = pl.elim_var[t];
-      rh.role[(size_t)12 * LT + t] = pl.Pdiag[pl.elim_var[t]];
+    const int e = thr_elim[t];
+    if (e >= 0) {
+      rh.role[(size_t)2 * LT + t] = e; rh.role[(size_t)3 * LT + t] = pl.elim_var[e];
+      rh.role[(size_t)12 * LT + t] = pl.Pdiag[pl.elim_var[e]];
     }
     for (int q = 0; q < 2; q++) {
       const int i = slot_row[q * LT + t];
       rh.role[(size_t)(4 + q) * LT + t] = i;
       if (i < 0) continue;
+      rh.role[(size_t)(16 + q) * LT + t] = pos[i];
       if (row_elim[i] >= 0) {
-        if (row_elim[i] != t) return false;
+        if (row_elim[i] != e) return false;
         rh.role[(size_t)(6 + q) * LT + t] = row_epos[i];
       }
-      int k = 0;
-      for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) {
-        const int c2 = pl.core_of[pl.Rj[s]];
-        if (c2 >= 0) { rh.off[(size_t)(CWv + q * LRW + k) * LT + t] = (unsigned short)(8 * c2); k++; }
-      }
+      for (size_t k = 0; k < rowp[q][t].size(); k++)
+        rh.off[(size_t)(CPv + q * (LRW / 2) + k) * LT + t] = (unsigned short)(16 * rowp[q][t][k].p);
     }
   }
   // P restricted to the core (for the dual residual): core c -> (position in triu values, core index)
@@ -205,6 +334,7 @@ struct RlArgs {
   double *x, *y, *resid;
   int *status, *iters;
   int warm;          // start from the previous (unscaled) solution held in x / y instead of zero
+  int merged;        // closed thread assignment (rl_assign_closed): no barrier between phases (Y) and (1)
   // time slicing (slice > 0): at most `slice` iterations per launch; an unfinished solve leaves status 0,
   // its iteration count in prog[b] and its scaled state in the s* arrays, and the next launch resumes it
   // bit-exactly (nothing is recomputed)
@@ -274,24 +404,26 @@ __device__ __forceinline__ double lgat(const double *base, unsigned int byte_off
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
-// N-entry gather-dot on the paired image: values V[128 h .. 128 h + 1] (one 16-byte
-// LDS read per pair), gathered operand at byte offset o[h] lo/hi half.  Offsets stay
-// packed two per VGPR (the empty asm stops the compiler from hoisting the unpack out
-// of the ADMM loop, which costs 2x the registers and spills).
+// Gather-dot over N value slots = N / 2 operand PAIRS: pair h multiplies the two values V[128 h], V[128 h + 1] of
+// the paired image (one 16-byte LDS read, contiguous per wavefront) with the two operands at byte offset o[h] of
+// `vec` (one 16-byte gather; o[h] is a multiple of 16).  A padded pair has zero values and gathers the always-zero
+// pair.  Offsets stay packed two per VGPR (the empty asm stops the compiler from hoisting the unpack out of the ADMM
+// loop, which costs 2x the registers and spills).  Even and odd elements run in two accumulation chains.
 template <int N>
 __device__ __forceinline__ double rl_dot(const double *V, unsigned int *o, const double *vec) {
-  dbl2 val[N / 2]; double g[N];
+  constexpr int NP = N / 2;
+  dbl2 val[NP], g[NP];
 #pragma unroll
-  for (int h = 0; h < N / 2; h++) {
-    asm volatile("" : "+v"(o[h]));
+  for (int h = 0; h < NP; h++) {
+    if ((h & 1) == 0) asm volatile("" : "+v"(o[h / 2]));
     val[h] = *(const dbl2 *)(V + 128 * h);
-    g[2 * h] = lgat(vec, o[h] & 0xffffu);
-    g[2 * h + 1] = lgat(vec, o[h] >> 16);
+    const unsigned int off = (h & 1) ? (o[h / 2] >> 16) : (o[h / 2] & 0xffffu);
+    g[h] = *(const dbl2 *)((const char *)vec + off);
   }
-  double acc = 0.0;
+  double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-  for (int h = 0; h < N / 2; h++) { acc += val[h].x * g[2 * h]; acc += val[h].y * g[2 * h + 1]; }
-  return acc;
+  for (int h = 0; h < NP; h++) { a0 += val[h].x * g[h].x; a1 += val[h].y * g[h].y; }
+  return a0 + a1;
 }
 
 // dispatch on the wave-uniform trip count so padded slots cost nothing
@@ -310,25 +442,48 @@ __device__ __forceinline__ double rl_dot_row(int w, const double *V, unsigned in
   return rl_dot<LRW>(V, o, vec);
 }
 
-// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15); the total lands in
-// lane 15 of the row.  Inclusive scan by doubling with row_shr 1, 2, 4, 8.
-__device__ __forceinline__ double row16_sum(double v) {
-#pragma unroll
-  for (int sh = 1; sh < 16; sh <<= 1) {
-    const int ctrl = 0x110 + sh;                      // row_shr:sh
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    int lo2, hi2;
-    switch (sh) {
-      case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
-      case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
-      case 4: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
-      default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
-    }
-    (void)ctrl;
-    v += __hiloint2double(hi2, lo2);
-  }
+// ---- phase (3) reduction --------------------------------------------------------------
+// The 16 partial sums of a row of the W mat-vec sit in the lanes with the same (lane >> 2) & 3:
+// 4 DPP rows (lane >> 4) x 4 lanes of a quad (lane & 3).  Two rows' partial sums are folded per
+// lane-swap instruction pair (v_permlane32_swap across the wavefront halves, v_permlane16_swap across
+// the DPP rows: after swapping register a of the upper lanes with register b of the lower lanes one
+// add leaves the pair sum of a in the lower and of b in the upper lanes), the last two levels run
+// inside the quad with quad_perm moves: 27 VALU instructions for 5 rows instead of the 60 of five
+// row_shr scans.  Fixed association order.
+typedef unsigned int rl_uint2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double rl_fold32(double a, double b) {
+  const rl_uint2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const rl_uint2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double rl_fold16(double a, double b) {
+  const rl_uint2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const rl_uint2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+// all four lanes of a quad end up with the quad's sum
+__device__ __forceinline__ double rl_quad_sum(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xb1, 0xf, 0xf, true),     // quad_perm [1,0,3,2]
+                        __builtin_amdgcn_update_dpp(0, lo, 0xb1, 0xf, 0xf, true));
+  lo = __double2loint(v); hi = __double2hiint(v);
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4e, 0xf, 0xf, true),     // quad_perm [2,3,0,1]
+                        __builtin_amdgcn_update_dpp(0, lo, 0x4e, 0xf, 0xf, true));
   return v;
 }
+// acc[rr] = this lane's partial sum of tile row rr.  Returns t[n]: in the lanes of DPP row h the total of
+// tile row 4 n + 2 (h & 1) + (h >> 1) (rl_tile_row below); garbage where that index is >= TR.
+#define RL_NT(TR) (((TR) + 3) / 4)
+template <int TR>
+__device__ __forceinline__ void rl_reduce_rows(const double (&acc)[TR], double (&t)[RL_NT(TR)]) {
+  constexpr int NU = (TR + 1) / 2;
+  double u[NU];
+#pragma unroll
+  for (int m = 0; m < NU; m++) u[m] = rl_fold32(acc[2 * m], 2 * m + 1 < TR ? acc[2 * m + 1] : 0.0);
+#pragma unroll
+  for (int n = 0; n < RL_NT(TR); n++) t[n] = rl_quad_sum(rl_fold16(u[2 * n], 2 * n + 1 < NU ? u[2 * n + 1] : 0.0));
+}
+__device__ __forceinline__ int rl_tile_row(int n, int h) { return 4 * n + 2 * (h & 1) + (h >> 1); }
 
 template <int TR, int TC, int CW, bool ADAPT>
 __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
@@ -336,10 +491,12 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   if (a.active && !a.active[b]) return;
   const int n = a.n, m = a.m, n_e = a.n_e, n_c = a.n_c;
 
-  __shared__ double s_tv[LCAP_M];                 // t' (by row), element m stays 0
-  __shared__ double s_rv[LCAP_NC];                // core right-hand side, zero padded
-  __shared__ double s_xc[LCAP_NC];                // x~_C, element n_c stays 0
-  __shared__ double s_chk[2 * LCAP_M + 2 * LCAP_NC];   // check scratch: w*y, dy (by row), x_C, dx_C
+  // row vectors are indexed by the planner's LDS position of a row (rl_plan_build), core vectors by core index;
+  // both keep an always-zero aligned pair for padded gathers (never written after the prologue)
+  __shared__ __attribute__((aligned(16))) double s_tv[LCAP_M];                 // t'
+  __shared__ __attribute__((aligned(16))) double s_rv[LCAP_NC];                // core right-hand side, zero padded
+  __shared__ __attribute__((aligned(16))) double s_xc[LCAP_NC];                // x~_C
+  __shared__ __attribute__((aligned(16))) double s_chk[2 * LCAP_M + 2 * LCAP_NC];   // check scratch: w*y, dy (rows), x_C, dx_C
   __shared__ double s_red[LWV * 8];
   double *swy = s_chk, *sdy = swy + LCAP_M, *sxc = sdy + LCAP_M, *sdxc = sxc + LCAP_NC;
   extern __shared__ double s_val[];
@@ -359,20 +516,23 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   auto pack = [&](int slot) -> unsigned int {
     return (unsigned int)a.off[(size_t)slot * LT + tid] | ((unsigned int)a.off[(size_t)(slot + 1) * LT + tid] << 16);
   };
-  unsigned int co[CW / 2], ro[2][LRW / 2];
+  unsigned int co[CW / 4], ro[2][LRW / 4];        // pair offsets, two per register
 #pragma unroll
-  for (int k = 0; k < CW / 2; k++) co[k] = pack(2 * k);
+  for (int k = 0; k < CW / 4; k++) co[k] = pack(2 * k);
 #pragma unroll
   for (int q = 0; q < 2; q++)
 #pragma unroll
-    for (int k = 0; k < LRW / 2; k++) ro[q][k] = pack(CW + q * LRW + 2 * k);
+    for (int k = 0; k < LRW / 4; k++) ro[q][k] = pack(CW / 2 + q * (LRW / 2) + 2 * k);
   const double *vcol = s_val + a.role[(size_t)8 * LT + tid];
   const double *vr0 = s_val + a.role[(size_t)9 * LT + tid];
   const double *vr1 = s_val + a.role[(size_t)10 * LT + tid];
   const int wcol = __builtin_amdgcn_readfirstlane(a.role[(size_t)13 * LT + tid]);
   const int wr0 = __builtin_amdgcn_readfirstlane(a.role[(size_t)14 * LT + tid]);
   const int wr1 = __builtin_amdgcn_readfirstlane(a.role[(size_t)15 * LT + tid]);
-  const int gi = tid / LGJ, gj = tid % LGJ;
+  // W tile of this thread: row group gi (4 per wavefront: bits 2-3 of the lane), column group gj (bits 0-1 and
+  // 4-5 of the lane: the 16 lanes whose partial sums rl_reduce_rows adds)
+  const int gi = (tid >> 6) * 4 + ((tid >> 2) & 3), gj = (tid & 3) + 4 * ((tid >> 4) & 3);
+  const int wrow_h = (tid >> 4) & 3;                 // DPP row of the lane: which tile rows' totals it receives
   double wreg[TR][TC];
   {
     const double *W = a.W + (size_t)b * n_c * n_c;
@@ -395,10 +555,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   double xe = 0.0, qe = 0.0, kinv = 0.0, ge = 0.0;
   if (eown >= 0) { qe = a.qs[(size_t)b * n + evar]; kinv = a.kee_inv[(size_t)b * n_e + eown]; ge = -qe * kinv; }
   // row state
-  int r_i[2]; double r_ls[2], r_us[2], r_rho[2], r_rinv[2], r_z[2], r_y[2], r_w[2], r_ae[2];
+  int r_i[2], r_p[2]; double r_ls[2], r_us[2], r_rho[2], r_rinv[2], r_z[2], r_y[2], r_w[2], r_ae[2];
 #pragma unroll
   for (int q = 0; q < 2; q++) {
     r_i[q] = a.role[(size_t)(4 + q) * LT + tid];
+    r_p[q] = a.role[(size_t)(16 + q) * LT + tid];       // LDS position of the row in t' / w y / dy
     r_ls[q] = r_us[q] = r_z[q] = r_y[q] = r_ae[q] = 0.0; r_rho[q] = r_rinv[q] = r_w[q] = 1.0;
     if (r_i[q] >= 0) {
       const int i = r_i[q];
@@ -437,9 +598,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   }
   for (int i = tid; i < LCAP_M; i += LT) s_tv[i] = 0.0;
   for (int i = tid; i < LCAP_NC; i += LT) { s_rv[i] = 0.0; s_xc[i] = 0.0; }
+  for (int i = tid; i < 2 * LCAP_M + 2 * LCAP_NC; i += LT) s_chk[i] = 0.0;
   __syncthreads();
   const double cscale = a.cscale[b];
   const double alpha = a.alpha, sigma = a.sigma;
+  const bool merged = a.merged != 0;
   const int it0 = a.slice > 0 ? a.prog[b] : 0;
   if (it0 > 0) {
     // resume an unfinished solve: every loop-carried value comes back from memory
@@ -449,7 +612,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     for (int q = 0; q < 2; q++)
       if (r_i[q] >= 0) {
         r_z[q] = a.sz[(size_t)b * m + r_i[q]]; r_y[q] = a.sy[(size_t)b * m + r_i[q]];
-        s_tv[r_i[q]] = a.st[(size_t)b * m + r_i[q]];
+        s_tv[r_p[q]] = a.st[(size_t)b * m + r_i[q]];
       }
     if (ADAPT && a.rflag[b]) {
       double tq[2] = {0.0, 0.0};
@@ -459,7 +622,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       if (eown >= 0) ge = ((sigma * xe - qe) + r_ae[0] * tq[0] + r_ae[1] * tq[1]) * kinv;
 #pragma unroll
       for (int q = 0; q < 2; q++)
-        if (r_i[q] >= 0) s_tv[r_i[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
+        if (r_i[q] >= 0) s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
     }
   } else if (a.warm) {
     // OSQP-style warm start from the previous solution of this handle (x, y unscaled in a.x / a.y):
@@ -467,7 +630,6 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
     if (cown >= 0) { xcv = a.x[(size_t)b * n + cvar] / Dg[cvar]; sxc[cown] = xcv; }
     if (eown >= 0) xe = a.x[(size_t)b * n + evar] / Dg[evar];
-    if (tid == 0) sxc[n_c] = 0.0;
     __syncthreads();
     double axc[2];
     axc[0] = rl_dot_row(wr0, vr0, ro[0], sxc); axc[1] = rl_dot_row(wr1, vr1, ro[1], sxc);
@@ -482,12 +644,12 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     if (eown >= 0) ge = ((sigma * xe - qe) + r_ae[0] * tq[0] + r_ae[1] * tq[1]) * kinv;
 #pragma unroll
     for (int q = 0; q < 2; q++)
-      if (r_i[q] >= 0) s_tv[r_i[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
+      if (r_i[q] >= 0) s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
   } else {
     // t' of the start point x = z = y = 0:  t = 0, g_e = -q_e / K_ee, t'_i = -rw_i a_ie g_e
 #pragma unroll
     for (int q = 0; q < 2; q++)
-      if (r_i[q] >= 0) s_tv[r_i[q]] = -(r_w[q] * r_rho[q]) * r_ae[q] * ge;
+      if (r_i[q] >= 0) s_tv[r_p[q]] = -(r_w[q] * r_rho[q]) * r_ae[q] * ge;
   }
   __syncthreads();
   if (ADAPT && tid == 0) { a.rflag[b] = 0; a.smask[b] = 0; }
@@ -525,16 +687,22 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     // (3) register-tile mat-vec; the 16 partial sums of a row sit in the 16 lanes of a
     //     DPP row and are added with row shifts (no LDS round trip, no extra barrier)
     {
-      double rr_[TC];
+      double rr_[TC], acc[TR], tot[RL_NT(TR)];
 #pragma unroll
       for (int cc = 0; cc < TC; cc++) rr_[cc] = s_rv[gj * TC + cc];
 #pragma unroll
       for (int rr = 0; rr < TR; rr++) {
-        double acc = 0.0;
+        acc[rr] = 0.0;
 #pragma unroll
-        for (int cc = 0; cc < TC; cc++) acc += wreg[rr][cc] * rr_[cc];
-        acc = row16_sum(acc);
-        if (gj == LGJ - 1 && gi * TR + rr < n_c) s_xc[gi * TR + rr] = acc;
+        for (int cc = 0; cc < TC; cc++) acc[rr] += wreg[rr][cc] * rr_[cc];
+      }
+      rl_reduce_rows<TR>(acc, tot);
+      if ((tid & 3) == 0) {
+#pragma unroll
+        for (int nn = 0; nn < RL_NT(TR); nn++) {
+          const int rr = rl_tile_row(nn, wrow_h);
+          if (rr < TR && gi * TR + rr < n_c) s_xc[gi * TR + rr] = tot[nn];
+        }
       }
     }
     STAMP(2)
@@ -567,17 +735,19 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
 #pragma unroll
       for (int q = 0; q < 2; q++)
         if (r_i[q] >= 0) {
-          s_tv[r_i[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
-          if (chk) { swy[r_i[q]] = r_w[q] * r_y[q]; sdy[r_i[q]] = dyq[q]; }
+          s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
+          if (chk) { swy[r_p[q]] = r_w[q] * r_y[q]; sdy[r_p[q]] = dyq[q]; }
         }
       if (cown >= 0) {
         const double xn = alpha * s_xc[cown] + (1.0 - alpha) * xcv;
         dxc = xn - xcv; xcv = xn;
         if (chk) { sxc[cown] = xn; sdxc[cown] = dxc; }
       }
-      if (chk && tid == 0) { swy[m] = 0.0; sxc[n_c] = 0.0; sdxc[n_c] = 0.0; }
       STAMP(4)
-      __syncthreads();
+      // closed assignment: the next phase (1) reads only t' written by its own wavefront (LDS operations of one
+      // wavefront complete in order), every other hazard is covered by the two remaining barriers; the
+      // termination test after a checked step reads what all wavefronts have just written
+      if (chk || !merged) __syncthreads();
       STAMP(5)
     }
   };
@@ -665,11 +835,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
 #pragma unroll
           for (int q = 0; q < 2; q++)
             if (r_i[q] >= 0) {
-              double dy = sdy[r_i[q]];
+              double dy = sdy[r_p[q]];
               if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
                 if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
               } else if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
-              sdy[r_i[q]] = dy; dyp[q] = dy;
+              sdy[r_p[q]] = dy; dyp[q] = dy;
               r1[0] = fmax(r1[0], fabs(s_cst[q * LT + tid] * dy));
             }
           lblock_reduce<1, true>(r1, s_red);
@@ -683,7 +853,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
             if (lhs[0] < -epi * ndy) {
               __syncthreads();
 #pragma unroll
-              for (int q = 0; q < 2; q++) if (r_i[q] >= 0) swy[r_i[q]] = r_w[q] * dyp[q];
+              for (int q = 0; q < 2; q++) if (r_i[q] >= 0) swy[r_p[q]] = r_w[q] * dyp[q];
               __syncthreads();
               double nat[1] = {0.0};
               {
@@ -693,7 +863,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               if (eown >= 0) nat[0] = fmax(nat[0], fabs((r_ae[0] * (r_w[0] * dyp[0]) + r_ae[1] * (r_w[1] * dyp[1])) / Dg[evar]));
               lblock_reduce<1, true>(nat, s_red);
 #pragma unroll
-              for (int q = 0; q < 2; q++) if (r_i[q] >= 0) swy[r_i[q]] = r_w[q] * r_y[q];
+              for (int q = 0; q < 2; q++) if (r_i[q] >= 0) swy[r_p[q]] = r_w[q] * r_y[q];
               __syncthreads();
               if (nat[0] < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
             }
@@ -764,7 +934,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     for (int q = 0; q < 2; q++)
       if (r_i[q] >= 0) {
         a.sz[(size_t)b * m + r_i[q]] = r_z[q]; a.sy[(size_t)b * m + r_i[q]] = r_y[q];
-        a.st[(size_t)b * m + r_i[q]] = s_tv[r_i[q]];
+        a.st[(size_t)b * m + r_i[q]] = s_tv[r_p[q]];
       }
     if (tid == 0) { a.prog[b] = iter; a.status[b] = 0; a.iters[b] = iter; }
     return;
@@ -863,7 +1033,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.As = d.As; ra.W = d.W; ra.qs = d.qs; ra.kee_inv = d.kee_inv; ra.ls = d.ls; ra.us = d.us; ra.rho = d.rho;
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
-  ra.warm = a.warm;
+  ra.warm = a.warm; ra.merged = rh.merged ? 1 : 0;
   ra.slice = a.slice; ra.prog = d.prog;
   ra.ad_interval = a.adaptive ? a.ad_interval : 0; ra.ad_tol = a.ad_tol;
   ra.rho_b = d.rho_b; ra.rflag = d.rflag; ra.smask = d.smask; ra.nupd = d.nupd; ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.st = d.st; ra.sg = d.sg;

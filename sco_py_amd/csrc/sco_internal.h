@@ -121,6 +121,8 @@ int reg_launch(const AdmmArgs &a, const RegHost &rh, const RegDev &rd, hipStream
 struct RlHost {
   int TR = 1, TC = 2, CW = 12;     // CW: slots for a core variable's column entries (12 or 16)
   int pcw = 0;                     // most P entries in a core variable's column (<= 4: cached in LDS for the termination test)
+  int zpos = 0;                    // LDS position of the always-zero pair of the row vectors
+  bool merged = false;             // closed thread assignment: phases (Y) and (1) share a wavefront, one barrier less per iteration
   SellHost Ac, Ar0, Ar1;
   size_t lds_bytes = 0;
   std::vector<unsigned short> off;

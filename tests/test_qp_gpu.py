@@ -482,3 +482,36 @@ def test_null_index_array_with_a_non_empty_pattern_is_rejected(gpu):
     assert rc == -1 and not h.value
     rc = lib.sco_qp_create(0, 1, 1, 1, ip(Pp), ip(Ai), ip(Ap), None, C.byref(h))
     assert rc == -1 and not h.value
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_device_admm_against_the_admm_free_solutions_of_the_golden_qps(gpu, k):
+    """The device ADMM on the golden 7-DOF x 20 penalty QPs against tests/golden/qp_exact_7x20.npz (interior point +
+    active-set polish, oracle/qp_exact.py): the converging QP lands on the optimum, the compounded-penalty QP (Q1) is
+    still far from it when max_iter = 100 000 ends the solve -- in both cases with the iteration count of the golden
+    reference run (the duplicated rows of the second QP are passed as physical rows here, as the reference does)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_qp_exact import golden_qp
+    from oracle import qp_exact as qe
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "trajopt_7x20.npz")); ex = np.load(os.path.join(gold, "qp_exact_7x20.npz"))
+    pre = "p0_qp%d" % k
+    P, q, A, l, u = golden_qp(g, pre)
+    st = _lib.default_qp_settings(rho=0.1, sigma=5e-10, eps_abs=1e-6, eps_rel=1e-9, max_iter=100000)
+    n, m, Pp, Pi, Ap, Ai, Pval, qq, Aval, ll, uu = _stack([(P, q, A, l, u)])
+    qp = _lib.BatchedQP(1, n, m, Pp, Pi, Ap, Ai)
+    try:
+        qp.load(Pval, qq, Aval, ll, uu)
+        x, y, status, iters, res = qp.solve(st)
+    finally:
+        qp.close()
+    assert iters[0] == int(g[pre + "_iters"]) and status[0] == int(g[pre + "_status"])
+    xs, obj = ex[pre + "_x"], float(ex[pre + "_obj"])
+    mine = 0.5 * x[0] @ P @ x[0] + q @ x[0]
+    if k == 1:
+        assert status[0] == 1 and np.abs(x[0] - xs).max() < 2e-4 and abs(mine - obj) < 1e-6 * (1 + abs(obj))
+    else:
+        r = qe.osqp_residuals(P, q, A, l, u, x[0], y[0])
+        assert status[0] == -2 and np.abs(x[0] - xs).max() > 0.1 and mine > obj + 1.0
+        assert r["dual"] > 1e-4 or r["primal_lower_bound"] > 1e-4
