@@ -25,11 +25,62 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12            # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+N_CU = 256
+CLOCK_HZ = 2.4e9             # spec maximum; the chip holds less under load, so the on-chip fractions below read low
+F64_PEAK = N_CU * 64 * 2 * CLOCK_HZ      # 78.6 TFLOP/s: 64 f64 FMA / clk / CU; MI355X's dense f64 MFMA rate is the same
+LDS_PEAK = N_CU * 256 * CLOCK_HZ         # 157 TB/s: 256 B / clk / CU for 8- and 16-byte LDS reads (MI355X_MICROARCH.md, LDS)
 
 
 def algorithmic_bytes_per_iter(n, m):
     # reads x~,x,q (3n) + nu,z,y,l,u,rho (6m); writes x,rhs_top (2n) + z,y,rhs_bottom (3m)
     return (5 * n + 9 * m) * 8
+
+
+def onchip_model(d, T, K, O, projection=False):
+    """Work of ONE ADMM iteration of one QP of the planar-arm family as the row-local kernel does it:
+    flops: the dense core solve W r (n_c^2 FMA), A x~ and A' t' (one FMA per non-zero of A each), 12 per constraint
+    row (relaxation, projection, dual step, next right-hand side) and 4 per variable; LDS bytes: the right-hand-side
+    broadcast of the W tile (512 threads x 9 doubles), 32 B per operand pair of the row and column gather-dots
+    (16 B of A values + 16 B of operands), the three vector writes and the x~_C read-back."""
+    n_x, R = d * T, K * O
+    if projection:
+        n, m, nnzA, n_c = n_x, 2 * d + n_x, 2 * d + n_x, n_x
+        col_pairs, row_pairs = n_x * 1, (2 * d + n_x) * 1
+    else:
+        n = n_x + T * R
+        m = 2 * d + T * R + n
+        nnzA = 2 * d + T * R * (d + 1) + n
+        n_c = n_x
+        col_pairs = n_x * (-(-R // 2) + 1)                 # the block's R rows in aligned pairs + (trust row, pin)
+        row_pairs = T * R * (d // 2 + 1) + (n_x + 2 * d)   # d consecutive core entries -> d/2 + 1 pairs; single-entry rows
+    flops = 2 * (n_c * n_c + 2 * nnzA) + 12 * m + 4 * n
+    lds = 512 * 9 * 8 + 32 * (col_pairs + row_pairs) + 8 * (2 * n_c + m) + 8 * n_c
+    return flops, lds
+
+
+def kernel_src_sha():
+    """Hash of every kernel source: a PMC measurement is only quoted for the kernels it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "sco_py_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(src, f), "rb") as fh:
+                h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(name):
+    """HBM bytes of the dominant kernel from the committed PMC passes (scripts/gpu_pmc.sh -> profiles/<name>), or
+    None when the kernels have changed since they were taken."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, "no PMC record"
+    with open(path) as fh:
+        tj = json.load(fh)
+    if tj.get("kernel_src_sha") != kernel_src_sha():
+        return None, "stale PMC record (taken on kernel sources %s)" % tj.get("kernel_src_sha")
+    return tj, path
 
 
 def cpu_baseline(n_problems, first, dims):
@@ -167,6 +218,8 @@ def main():
     ap.add_argument("--workload", choices=["7x20", "12x50"], default="7x20",
                     help="7x20 = BASELINE configs[2] (headline); 12x50 = configs[4] shape (structured global-memory tier)")
     ap.add_argument("--cpu-problems", type=int, default=16, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--aux-12x50", type=int, default=256,
+                    help="batch of the 12-DOF x 50 line reported under aux in a default 7x20 run (0 = skip)")
     ap.add_argument("--intended", action="store_true",
                     help="disable reference quirks Q1/Q2 (NOT the headline number)")
     ap.add_argument("--beyond", action="store_true",
@@ -207,122 +260,149 @@ def main():
     from sco_py_amd import _lib, batch as sb
     from sco_py_amd import dist as sd
 
-    big = args.workload == "12x50"
-    dims = dict(d=12, T=50, K=10, O=10) if big else dict(d=7, T=20, K=5, O=2)
-    B = args.batch if args.batch is not None else (256 if big else 1024)
-    if big and args.cpu_problems == 16:
-        args.cpu_problems = 0          # one 12x50 oracle solve takes minutes (tests/golden/make_big_oracle.py)
-    total = B * world
-    lo, hi = sd.shard_range(total, rank, world)
-    arrays, _ = af.make_batch(hi - lo, first=lo, **dims)
-    n_x = dims["d"] * dims["T"]; R = dims["K"] * dims["O"]
-    n = n_x + dims["T"] * R
-    m = 2 * dims["d"] + dims["T"] * R + n
-    n0, m0 = n_x, 2 * dims["d"] + n_x
-
-    params = _lib.default_sqp_params()
-    if args.beyond:
-        args.intended = True
-    if args.intended:
-        params.compound_penalty = 0; params.duplicate_rows = 0
-    qs = _lib.default_qp_settings()
-    if args.beyond:
-        params.max_sqp_iters = 20; params.warm_start_qps = 1; qs.adaptive_rho = 1
-    tb = sb.TrajOptBatch(hi - lo, dims["d"], dims["T"], dims["K"], dims["O"], device=local_rank)
-    tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
-            arrays["point_frac"], arrays["obstacles"])          # inputs resident in HBM from here on
-
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step():
-        return sd.solve_sharded(tb, total, params, qs)     # solve the shard + RCCL all-gather of 24 B/problem (no-op at N = 1)
+    def run(workload, B, steps, warmup, intended=False, beyond=False):
+        """Load `B` problems per rank (resident in HBM before the clock starts), time `steps` complete sharded solves."""
+        big = workload == "12x50"
+        dims = dict(d=12, T=50, K=10, O=10) if big else dict(d=7, T=20, K=5, O=2)
+        total = B * world
+        lo, hi = sd.shard_range(total, rank, world)
+        arrays, _ = af.make_batch(hi - lo, first=lo, **dims)
+        params = _lib.default_sqp_params()
+        if intended or beyond:
+            params.compound_penalty = 0; params.duplicate_rows = 0
+        qs = _lib.default_qp_settings()
+        if beyond:
+            params.max_sqp_iters = 20; params.warm_start_qps = 1; qs.adaptive_rho = 1
+        tb = sb.TrajOptBatch(hi - lo, dims["d"], dims["T"], dims["K"], dims["O"], device=local_rank)
+        tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                arrays["point_frac"], arrays["obstacles"])          # inputs resident in HBM from here on
+        for _ in range(warmup):
+            sd.solve_sharded(tb, total, params, qs)
+        sync()
+        t0 = time.perf_counter()
+        sco_iters = 0; admm_ms = 0.0; qp_launches = 0
+        stage_ms = np.zeros(5)
+        for _ in range(steps):
+            res, allrec = sd.solve_sharded(tb, total, params, qs)   # solve the shard + RCCL all-gather of 24 B/problem (no-op at N = 1)
+            sco_iters += int(allrec["sqp_iters"].sum())
+            tm = tb.last_timing()                                  # HIP-event sums of the step just finished, taken on the library's stream
+            stage_ms += [tm["convexify_ms"], tm["qp_setup_ms"], tm["admm_ms"], tm["decide_ms"], tm["total_ms"]]
+            admm_ms += tm["admm_ms"]
+            qp_launches += tm["rounds"] - 1                       # penalty-QP launches (the projection launch is tiny)
+        sync()
+        elapsed = time.perf_counter() - t0
+        # bookkeeping outside the timed region: every step solves the same loaded problems and the solve is
+        # deterministic (tests/test_sqp_gpu.py), so the per-QP iteration counts of the last step are those of every step
+        traces = tb.trace()
+        it_proj = steps * sum(int(t[0, 7]) for t in traces)
+        it_pen = steps * sum(int(t[1:, 7].sum()) for t in traces)
+        qp_solves = steps * int(res.qp_solves.sum())
+        tb.close()
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return dict(dims=dims, B=B, total=total, steps=steps, elapsed=elapsed, sco_iters=sco_iters, admm_ms=admm_ms,
+                    qp_launches=qp_launches, stage_ms=stage_ms / steps, it_proj=it_proj, it_pen=it_pen, qp_solves=qp_solves,
+                    success=float(np.mean(allrec["success"] != 0)))
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    sco_iters = 0
-    admm_ms = 0.0; admm_bytes = 0.0; admm_launches = 0; admm_iters_total = 0; qp_solves_total = 0; qp_launches = 0
-    stage_ms = np.zeros(5)
-    for _ in range(args.steps):
-        res, allrec = step()
-        sco_iters += int(allrec["sqp_iters"].sum())
-        tm = tb.last_timing()                                  # HIP-event sums of the step just finished (five floats)
-        stage_ms += [tm["convexify_ms"], tm["qp_setup_ms"], tm["admm_ms"], tm["decide_ms"], tm["total_ms"]]
-        admm_ms += tm["admm_ms"]
-        admm_launches += tm["rounds"]
-        qp_launches += tm["rounds"] - 1                       # penalty-QP launches (the projection launch is tiny)
-    sync()
-    elapsed = time.perf_counter() - t0
-    # bookkeeping for the roofline figure, outside the timed region: every step solves the same loaded problems and
-    # the solve is deterministic (tests/test_sqp_gpu.py), so the per-QP iteration counts of the last step are those
-    # of every step.  Algorithmic bytes of the ADMM kernel: iterations x (5n + 9m) x 8 over every QP of every problem.
-    traces = tb.trace()
-    it_proj = sum(int(t[0, 7]) for t in traces)
-    it_pen = sum(int(t[1:, 7].sum()) for t in traces)
-    admm_bytes = args.steps * (it_proj * algorithmic_bytes_per_iter(n0, m0) + it_pen * algorithmic_bytes_per_iter(n, m))
-    admm_iters_total = args.steps * (it_proj + it_pen)
-    qp_solves_total = args.steps * int(res.qp_solves.sum())
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def roofline(r, big):
+        """Roofline block of the dominant kernel: algorithmic work of this rank's launches / their HIP-event time."""
+        d = r["dims"]; n_x = d["d"] * d["T"]; R = d["K"] * d["O"]
+        n = n_x + d["T"] * R; m = 2 * d["d"] + d["T"] * R + n
+        n0, m0 = n_x, 2 * d["d"] + n_x
+        secs = r["admm_ms"] * 1e-3
+        launches = max(r["qp_launches"], 1)
+        alg_bytes = r["it_proj"] * algorithmic_bytes_per_iter(n0, m0) + r["it_pen"] * algorithmic_bytes_per_iter(n, m)
+        hbm_eq = {"label": "HBM-equivalent: the bytes an ADMM that streams its iterates through HBM would move, SURVEY 8(d) "
+                           "(5n + 9m) * 8 per problem-iteration; NOT traffic of this kernel",
+                  "achieved_GBps": alg_bytes / secs / 1e9 if secs > 0 else 0.0,
+                  "ratio_to_8TBps": alg_bytes / secs / HBM_PEAK if secs > 0 else 0.0,
+                  "algorithmic_bytes_per_launch": alg_bytes / launches}
+        if big:
+            tj, src = measured_traffic("r02_traffic_12x50.json")
+            traffic = tj["hbm_bytes_per_problem_iteration"] * (r["it_proj"] + r["it_pen"]) / launches if tj else None
+            return {"bound": "hbm", "kernel": "qp_admm_bt_kernel", "achieved": hbm_eq["achieved_GBps"], "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": hbm_eq["ratio_to_8TBps"], "traffic": traffic, "traffic_source": src,
+                    "algorithmic_bytes_per_launch": hbm_eq["algorithmic_bytes_per_launch"],
+                    "note": "one workgroup per problem streams A (565 KB) and the row state from L2 / MALL / HBM every "
+                            "iteration: achieved = algorithmic (5n+9m)*8 B per problem-iteration x iterations / kernel time "
+                            "(HIP events on the library stream)"}
+        f_pen, l_pen = onchip_model(d["d"], d["T"], d["K"], d["O"])
+        f_pro, l_pro = onchip_model(d["d"], d["T"], d["K"], d["O"], projection=True)
+        flops = r["it_pen"] * f_pen + r["it_proj"] * f_pro
+        lds = r["it_pen"] * l_pen + r["it_proj"] * l_pro
+        tj, src = measured_traffic("r02_traffic.json")
+        traffic = tj["hbm_bytes_per_step"] * r["steps"] / launches if tj and r["B"] == tj.get("batch") else None
+        return {"bound": "mfma", "kernel": "qp_admm_rl_kernel", "achieved": flops / secs / 1e12 if secs > 0 else 0.0,
+                "peak": F64_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / secs / F64_PEAK if secs > 0 else 0.0,
+                "traffic": traffic, "traffic_source": src,
+                "onchip": {"valu_frac": flops / secs / F64_PEAK if secs > 0 else 0.0,
+                           "lds_frac": lds / secs / LDS_PEAK if secs > 0 else 0.0,
+                           "flops_per_problem_iteration": f_pen, "lds_bytes_per_problem_iteration": l_pen,
+                           "clock_ghz_assumed": CLOCK_HZ / 1e9, "cus": N_CU},
+                "hbm_measured": {"bytes_per_launch": traffic,
+                                 "frac_of_8TBps": traffic * launches / secs / HBM_PEAK if traffic and secs > 0 else None},
+                "hbm_equivalent": hbm_eq,
+                "note": "f64 peak of MI355X: 64 FMA/clk/CU on the vector ALU = its dense f64 MFMA rate (78.6 TFLOP/s at 2.4 GHz); "
+                        "the kernel has no GEMM-shaped work (one dense 140 x 140 mat-vec per problem-iteration with a different "
+                        "matrix per problem), so its flops issue on the vector ALU and are priced against that peak.  Iterates live "
+                        "in LDS / registers for a whole solve: HBM sees the problem once per launch (hbm_measured, PMC)"}
+
+    big = args.workload == "12x50"
+    B = args.batch if args.batch is not None else (256 if big else 1024)
+    if big and args.cpu_problems == 16:
+        args.cpu_problems = 0          # one 12x50 oracle solve takes minutes (tests/golden/make_big_oracle.py)
+    r = run(args.workload, B, args.steps, args.warmup, args.intended, args.beyond)
+    aux12 = None
+    if world == 1 and not big and not (args.intended or args.beyond) and args.aux_12x50 > 0:
+        # BASELINE configs[4] shape on the structured global-memory tier: a small batch, one step, reported under aux
+        r12 = run("12x50", args.aux_12x50, 1, 0)
+        rf12 = roofline(r12, True)
+        aux12 = {"workload": "batch=%d x 12-DOF x 50-timestep (n=5600, m=10624, 5000 nonlinear rows) per GPU, parity mode, 1 step"
+                             % args.aux_12x50,
+                 "sco_iters_per_s": r12["sco_iters"] / r12["elapsed"], "ms_per_step": 1e3 * r12["elapsed"],
+                 "admm_problem_iterations_per_s": (r12["it_proj"] + r12["it_pen"]) / (r12["admm_ms"] * 1e-3),
+                 "roofline": {k: rf12[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}}
 
     if rank == 0:
-        achieved = admm_bytes / (admm_ms * 1e-3) / 1e9 if admm_ms > 0 else 0.0
-        # HBM traffic of the same kernel from the PMC counters: needs its own rocprofv3 --pmc passes
-        # (scripts/gpu_pmc.sh), so the committed measurement is quoted, not re-measured live
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and B == 1024 and not args.intended and not big:
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            # PMC figure of one whole step (all penalty-QP launches), spread over this run's launches
-            per_step = tj.get("hbm_bytes_per_step")
-            traffic = per_step * args.steps / max(qp_launches, 1) if per_step else None
-        tpath_big = os.path.join(ROOT, "profiles", "r01_traffic_12x50.json")
-        if big and os.path.exists(tpath_big) and not args.intended:
-            with open(tpath_big) as fh:      # measured per problem-iteration at B = 64; scaled to this run's launches
-                traffic = json.load(fh)["hbm_bytes_per_problem_iteration"] * admm_iters_total / max(qp_launches, 1)
+        dims = r["dims"]
         out = {
             "metric": "SCO iters/sec (batch of N trajopt QPs)",
-            "value": sco_iters / elapsed,
+            "value": r["sco_iters"] / r["elapsed"],
             "unit": "sco_iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * r["elapsed"] / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("batch=%d independent 12-DOF x 50-timestep planar-arm trajopt problems per GPU "
                                     "(n=5600, m=10624 + duplicated penalty rows, 5000 nonlinear rows), penalty SQP with "
-                                    "reference defaults" % B) if big else
+                                    "reference defaults; structured global-memory ADMM tier, f64 vector ALU (the MFMA "
+                                    "path north_star sketches is waived: the Jacobian is block diagonal, DESIGN.md 5)" % B) if big else
                                    ("batch=%d independent 7-DOF x 20-timestep planar-arm trajopt problems per GPU "
                                     "(n=340, m=554 + duplicated penalty rows, 200 nonlinear rows), penalty SQP with "
                                     "reference defaults" % B),
-                       "global_batch": total,
+                       "global_batch": r["total"],
                        "mode": "beyond-parity (quirks off, adaptive rho, warm QPs, <= 20 QPs)" if args.beyond else
                                ("intended" if args.intended else "parity"),
                        "parallelism": "batch-shard x%d, no data-path collective" % world},
-            "aux": {"qp_solves_per_s": qp_solves_total * world / elapsed,
-                    "admm_iters_per_s": admm_iters_total * world / elapsed,
+            "aux": {"qp_solves_per_s": r["qp_solves"] * world / r["elapsed"],
+                    "admm_iters_per_s": (r["it_proj"] + r["it_pen"]) * world / r["elapsed"],
                     "stage_ms_per_step": dict(zip(["convexify", "qp_setup", "admm", "decide", "total"],
-                                                  (stage_ms / args.steps).round(3).tolist())),
-                    "success_fraction": float(np.mean(allrec["success"] != 0)),
-                    "admm_launches_per_step": qp_launches / args.steps},
-            "roofline": {"bound": "hbm", "kernel": "qp_admm_bt_kernel" if big else "qp_admm_rl_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": admm_bytes / max(qp_launches, 1),
-                         "note": ("achieved = algorithmic (5n+9m)*8 B per problem-iteration x iterations / kernel time from "
-                                  "HIP events; one workgroup per problem streams A from L2/HBM every iteration and is "
-                                  "bound by the per-CU memory pipe (~29 B/clk, scripts/microbench/cu_stream.hip)") if big else
-                                 "achieved = algorithmic (5n+9m)*8 B per problem-iteration x iterations / kernel "
-                                 "time from HIP events on the library stream; iterates live in LDS/registers, so the "
-                                 "measured HBM traffic per launch (profiles/r01_traffic.json, PMC) is ~4 orders of magnitude "
-                                 "below the algorithmic bytes and frac may exceed what an HBM-streaming kernel could reach"},
+                                                  r["stage_ms"].round(3).tolist())),
+                    "success_fraction": r["success"],
+                    "admm_launches_per_step": r["qp_launches"] / args.steps,
+                    "kernel_src_sha": kernel_src_sha()},
+            "roofline": roofline(r, big),
         }
+        if aux12 is not None:
+            out["aux"]["config4_12x50"] = aux12
         if world == 1 and args.cpu_problems > 0:
             v, dt, it = cpu_baseline(args.cpu_problems, 0, dims)
             out["cpu_baseline"] = {"value": v, "unit": "sco_iters/s", "cores": 1, "kind": "port",
@@ -331,7 +411,6 @@ def main():
         if cpu_all is not None:
             out["aux"]["cpu_baseline_all_cores"] = cpu_all
         print(json.dumps(out))
-    tb.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -4,12 +4,14 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  It restates, on plain arrays instead of the reference's object
 graph, what the following reference code does for a problem made of
   * one quadratic objective  1/2 x'Qx + a'x + b0          (QuadExpr)
+  * non-quadratic objective terms  phi_k(x_I)              (Expr(f): numeric gradient + Hessian, degree-2 model)
   * affine equality / inequality rows                      (EqExpr/LEqExpr(AffExpr))
   * non-linear  g(x_I) <= val  /  h(x_I) = val  blocks     (LEqExpr/EqExpr(Expr(f)))
 with every citation relative to /root/reference/sco_py:
 
   S1  Expr.eval / grad                          expr.py:34-41, 78-100 (memo on round(x, 6): Q3)
   S2  Expr.convexify(deg 1), Eq/LEqExpr.convexify   expr.py:139-142, 314-371
+      Expr.convexify(deg 2) with the eigenvalue shift  expr.py:102-128, 143-153; prob.py:88-104, 532-534
   S3  Prob.update_obj and helpers               sco_osqp/prob.py:251-315, 414-512 (Q1, Q2)
   S4  Variable.add_trust_region                 sco_osqp/variable.py:37-45
   S5  osqp_utils.optimize assembly              sco_osqp/osqp_utils.py:136-193
@@ -52,6 +54,90 @@ def fd_jacobian(f, x):
             tab = [tab[k] + (tab[k] - tab[k - 1]) * fac for k in range(1, len(tab))]
         cols.append(tab[0])
     return np.stack(cols, axis=1)
+
+
+def fd_hessian(f, x):
+    """Hessian of a scalar f at x (n,): second central differences on the same halving ladder, Richardson
+    extrapolated -- the formula of sco_py_amd/numdiff.py:hessian (the stand-in for numdifftools.Hessian,
+    expr.py:108) and of obj_hess in csrc/sco_sqp.hip."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    H = np.zeros((n, n))
+    f0 = float(f(x))
+    steps = [FD_BASE * max(1.0, abs(x[j])) for j in range(n)]
+    for i in range(n):
+        for j in range(i, n):
+            tab = []
+            for k in range(FD_LEVELS):
+                hi, hj = steps[i] / (2.0 ** k), steps[j] / (2.0 ** k)
+                if i == j:
+                    xp = x.copy(); xm = x.copy()
+                    xp[i] += hi; xm[i] -= hi
+                    tab.append((float(f(xp)) - 2.0 * f0 + float(f(xm))) / (hi * hi))
+                else:
+                    xpp = x.copy(); xpm = x.copy(); xmp = x.copy(); xmm = x.copy()
+                    xpp[i] += hi; xpp[j] += hj
+                    xpm[i] += hi; xpm[j] -= hj
+                    xmp[i] -= hi; xmp[j] += hj
+                    xmm[i] -= hi; xmm[j] -= hj
+                    tab.append((float(f(xpp)) - float(f(xpm)) - float(f(xmp)) + float(f(xmm))) / (4.0 * hi * hj))
+            for lv in range(1, FD_LEVELS):
+                fac = 1.0 / (4.0 ** lv - 1.0)
+                tab = [tab[k] + (tab[k] - tab[k - 1]) * fac for k in range(1, len(tab))]
+            H[i, j] = H[j, i] = tab[0]
+    return H
+
+
+def min_eig_jacobi(H, sweeps=12):
+    """Smallest eigenvalue of a small symmetric matrix by cyclic Jacobi rotations (what the device does; the
+    reference calls scipy.linalg.eigvalsh, expr.py:145 -- the two agree to rounding)."""
+    A = np.array(H, dtype=np.float64)
+    n = A.shape[0]
+    for _ in range(sweeps):
+        for p in range(n - 1):
+            for q in range(p + 1, n):
+                if A[p, q] == 0.0:
+                    continue
+                if abs(A[p, q]) < 1e-300:
+                    continue
+                theta = (A[q, q] - A[p, p]) / (2.0 * A[p, q])
+                t = (1.0 if theta >= 0 else -1.0) / (abs(theta) + np.sqrt(theta * theta + 1.0))
+                c = 1.0 / np.sqrt(t * t + 1.0); s_ = t * c
+                Rp, Rq = A[:, p].copy(), A[:, q].copy()
+                A[:, p] = c * Rp - s_ * Rq; A[:, q] = s_ * Rp + c * Rq
+                Rp, Rq = A[p, :].copy(), A[q, :].copy()
+                A[p, :] = c * Rp - s_ * Rq; A[q, :] = s_ * Rp + c * Rq
+    return float(np.min(np.diag(A)))
+
+
+class ObjBlock(object):
+    """One non-quadratic objective BoundExpr: scalar callable f on the block's own variables x[idx]
+    (prob.py:88-104).  eval is memoised on the rounded point like every Expr (Q3, expr.py:34-41); gradient and
+    Hessian are numeric and never cached (expr.py:61-69, 102-109)."""
+
+    def __init__(self, f, idx):
+        self.f = f
+        self.idx = np.asarray(idx, dtype=np.int64)
+        self._eval_cache = {}
+        self.emulate_memo = True
+
+    def eval(self, xb):
+        if not self.emulate_memo:
+            return float(self.f(xb))
+        k = tuple(np.round(xb, N_DIGS))
+        if k not in self._eval_cache:
+            self._eval_cache[k] = float(self.f(xb))
+        return self._eval_cache[k]
+
+    def convexify(self, xb, exact_eig=True):              # expr.py:143-153 (eigvalsh, as the reference)
+        H = fd_hessian(self.f, xb)
+        lam = float(np.min(np.linalg.eigvalsh(H))) if exact_eig else min_eig_jacobi(H)
+        if lam < 0:
+            H = H - np.eye(H.shape[0]) * lam
+        g = fd_jacobian(lambda v: np.array([float(self.f(v))]), xb)[0]
+        A = g - xb.dot(H)
+        b = 0.5 * xb.dot(H).dot(xb) - g.dot(xb) + self.eval(xb)
+        return H, A, b
 
 
 class Block(object):
@@ -105,7 +191,8 @@ class Block(object):
 
 
 class FlatProblem(object):
-    def __init__(self, x0, Q, a, b0=0.0, lin_A=None, lin_lo=None, lin_hi=None, blocks=(), prox_count=None):
+    def __init__(self, x0, Q, a, b0=0.0, lin_A=None, lin_lo=None, lin_hi=None, blocks=(), prox_count=None,
+                 obj_blocks=()):
         self.x0 = np.asarray(x0, dtype=np.float64).ravel()
         self.n_x = self.x0.shape[0]
         # how many Variables with a value contain each atom: find_closest_feasible_point
@@ -121,6 +208,7 @@ class FlatProblem(object):
         self.lin_lo = np.asarray(lin_lo, dtype=np.float64).ravel()
         self.lin_hi = np.asarray(lin_hi, dtype=np.float64).ravel()
         self.blocks = list(blocks)
+        self.obj_blocks = list(obj_blocks)
 
 
 class SolverParams(object):
@@ -164,7 +252,7 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
     P_ = params or SolverParams()
     qs = dict(qp_settings or {})
     solve_qp = qp_solver or (lambda P, q, A, l, u, w, kw: osqp_ref.solve(P, q, A, l, u, w=w, **kw))
-    for blk in p.blocks:
+    for blk in list(p.blocks) + list(p.obj_blocks):
         blk.emulate_memo = emulate_memo
     st = _State()
     st.x = p.x0.copy(); st.x_saved = None
@@ -174,7 +262,19 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
     m_lin = p.lin_A.shape[0]
 
     def quad_obj(x):
-        return 0.5 * x.dot(p.Q.dot(x)) + p.a.dot(x) + p.b0
+        # prob.py:571-573: quadratic objective expressions, then the non-quadratic ones at their true value
+        v = 0.5 * x.dot(p.Q.dot(x)) + p.a.dot(x) + p.b0
+        for ob in p.obj_blocks:
+            v += ob.eval(x[ob.idx])
+        return v
+
+    def model_obj(x, omodels):
+        # prob.py:625-626: quadratic objective expressions, then the degree-2 models of the non-quadratic ones
+        v = 0.5 * x.dot(p.Q.dot(x)) + p.a.dot(x) + p.b0
+        for ob, (H, A, b) in zip(p.obj_blocks, omodels):
+            xb = x[ob.idx]
+            v += 0.5 * xb.dot(H.dot(xb)) + A.dot(xb) + b
+        return v
 
     def record(kind, merit, model, new, trust, pen, res):
         st.trace.append((kind, merit, model, new, trust, pen, res.info.status_val, res.info.iter))
@@ -247,6 +347,7 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
                 return False
             st.sqp_iters += 1
             # convexify (prob.py:522-544)
+            omodels = [ob.convexify(st.x[ob.idx]) for ob in p.obj_blocks]        # degree 2 (prob.py:532-534)
             models = [b.convexify(st.x[b.idx]) for b in p.blocks]
             # update_obj (prob.py:414-426): spawn pattern on first use, refresh rows, scale costs
             if state["masks"] is None:
@@ -265,7 +366,16 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
                 rows.append(R.tocsr())
                 hi.append(-bb)
                 lo.append(-bb if b.kind == "eq" else np.full(b.r, -np.inf))
-            q = np.concatenate([p.a, np.full(n_slack, state["slack_cost"])])
+            qx = p.a.copy()
+            Pit = Pfull
+            if omodels:
+                # QuadExpr lowering (prob.py:348-367, osqp_utils.py:153-163): Q into P, A into q
+                Hs = sp.lil_matrix((n, n))
+                for ob, (H, A, b) in zip(p.obj_blocks, omodels):
+                    Hs[np.ix_(ob.idx, ob.idx)] = Hs[np.ix_(ob.idx, ob.idx)].toarray() + H
+                    qx[ob.idx] += A
+                Pit = Pfull + sp.triu(Hs.tocsc(), format="csc")
+            q = np.concatenate([qx, np.full(n_slack, state["slack_cost"])])
             lin_ext = sp.hstack([p.lin_A, sp.csr_matrix((m_lin, n_slack))]).tocsr() if n_slack else p.lin_A
             A_top = sp.vstack([lin_ext] + rows).tocsr() if rows else lin_ext
             w_top = np.concatenate([np.ones(m_lin, dtype=np.int64), np.full(m_nl, state["k"], dtype=np.int64)])
@@ -284,7 +394,7 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
                 A = sp.vstack([A_top, sp.identity(n, format="csr")]).tocsc()
                 l = np.concatenate([lo_top, lb]); u = np.concatenate([hi_top, ub])
                 w = np.concatenate([w_top, np.ones(n, dtype=np.int64)])
-                res = run_qp(Pfull, q, A, l, u, w, qs)
+                res = run_qp(Pit, q, A, l, u, w, qs)
                 if res.info.status_val in (1, 2):                 # prob.py:197-203
                     st.x = res.x[:n_x].copy()
                 # model merit (prob.py:605-630): full Jacobian, not the masked rows
@@ -293,7 +403,7 @@ def penalty_sqp(p, params=None, qp_settings=None, record_qps=False, emulate_memo
                     v = Am.dot(st.x[b.idx]) + bm
                     bmviol.append(float(np.sum(np.abs(v) if b.kind == "eq" else np.maximum(v, 0.0))))
                 mviol = sum(bmviol)
-                model_merit = quad_obj(st.x) + penalty * mviol
+                model_merit = model_obj(st.x, omodels) + penalty * mviol
                 model_vec = group_vec(bmviol)                 # get_approx_value(vectorize=True), prob.py:617-622
                 nviol = sum(float(np.sum(b.violation(st.x[b.idx]))) for b in p.blocks)
                 new_merit = quad_obj(st.x) + penalty * nviol
@@ -404,7 +514,12 @@ def trajopt_flat(prob, analytic_jac=False):
         jac = (lambda th, pr=prob: af.ee_jac(th, pr["link_len"])) if analytic_jac else None
         blocks.append(Block("eq", f, np.arange((T - 1) * d, T * d), prob["target"], jac=jac,
                             groups=prob["groups"][T] if prob.get("groups") is not None else None))
+    obj_blocks = []
+    if prob.get("cost_weight") is not None:
+        for t in range(T):
+            fc = (lambda th, pr=prob: af.ee_cost(th, pr["link_len"], pr["cost_target"], pr["cost_weight"]))
+            obj_blocks.append(ObjBlock(fc, np.arange(t * d, (t + 1) * d)))
     # the object-API construction (tests/trajopt_build.py) binds every atom to two
     # Variables: the whole trajectory and its timestep block
     return FlatProblem(prob["x0"], Q.tocsc(), np.zeros(n_x), 0.0, lin.tocsr(), lin_lo, lin_hi, blocks,
-                       prox_count=np.full(n_x, 2.0))
+                       prox_count=np.full(n_x, 2.0), obj_blocks=obj_blocks)

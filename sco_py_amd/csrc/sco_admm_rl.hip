@@ -29,6 +29,12 @@
 #include <cstdlib>
 #include <cstring>
 
+// Diagnostic builds only (scripts/build_ablate.py): -DRL_ABLATE=<mask> removes one piece of the iteration so that its
+// cost can be read off the per-iteration time (results are wrong; never compiled into the product).
+//   1 column sums (1)   2 row dots of (Y)   4 W mat-vec FMAs   8 lane-swap reduction   16 the barriers
+#ifndef RL_ABLATE
+#define RL_ABLATE 0
+#endif
 #define LT 512
 #define LWV (LT / 64)
 #define LGJ 16
@@ -678,11 +684,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     STAMP(6)
     // (1) core right-hand side
     {
-      const double dv = rl_dot_col<CW>(wcol, vcol, co, s_tv);
+      const double dv = (RL_ABLATE & 1) ? 0.0 : rl_dot_col<CW>(wcol, vcol, co, s_tv);
       if (cown >= 0) s_rv[cown] = (sigma * xcv - qc) + dv;
     }
     STAMP(0)
-    __syncthreads();
+    if (!(RL_ABLATE & 16)) __syncthreads();
     STAMP(1)
     // (3) register-tile mat-vec; the 16 partial sums of a row sit in the 16 lanes of a
     //     DPP row and are added with row shifts (no LDS round trip, no extra barrier)
@@ -694,8 +700,12 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       for (int rr = 0; rr < TR; rr++) {
         acc[rr] = 0.0;
 #pragma unroll
-        for (int cc = 0; cc < TC; cc++) acc[rr] += wreg[rr][cc] * rr_[cc];
+        for (int cc = 0; cc < ((RL_ABLATE & 4) ? 1 : TC); cc++) acc[rr] += wreg[rr][cc] * rr_[cc];
       }
+      if (RL_ABLATE & 8) {
+#pragma unroll
+        for (int nn = 0; nn < RL_NT(TR); nn++) tot[nn] = acc[nn];
+      } else
       rl_reduce_rows<TR>(acc, tot);
       if ((tid & 3) == 0) {
 #pragma unroll
@@ -706,13 +716,13 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       }
     }
     STAMP(2)
-    __syncthreads();
+    if (!(RL_ABLATE & 16)) __syncthreads();
     STAMP(3)
     // (Y) rows, eliminated variable, updates, next t'
     {
       double zc[2];
-      zc[0] = rl_dot_row(wr0, vr0, ro[0], s_xc);
-      zc[1] = rl_dot_row(wr1, vr1, ro[1], s_xc);
+      zc[0] = (RL_ABLATE & 2) ? s_xc[0] : rl_dot_row(wr0, vr0, ro[0], s_xc);
+      zc[1] = (RL_ABLATE & 2) ? s_xc[1] : rl_dot_row(wr1, vr1, ro[1], s_xc);
       // x~_e = g_e - (1/K_ee) sum_i rw_i a_ie (A_iC x~_C)
       const double xte = ge - kinv * ((r_w[0] * r_rho[0]) * r_ae[0] * zc[0] + (r_w[1] * r_rho[1]) * r_ae[1] * zc[1]);
       double tq[2], dyq[2];
@@ -747,7 +757,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       // closed assignment: the next phase (1) reads only t' written by its own wavefront (LDS operations of one
       // wavefront complete in order), every other hazard is covered by the two remaining barriers; the
       // termination test after a checked step reads what all wavefronts have just written
-      if (chk || !merged) __syncthreads();
+      if ((chk || !merged) && (chk || !(RL_ABLATE & 16))) __syncthreads();
       STAMP(5)
     }
   };
@@ -819,9 +829,22 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           }
         }
         CSTAMP(0)
-        // the tolerances only need max(|z|, |Ax|) and max(|q|, |A'y|, |Px|): four maxima to reduce instead of seven
-        double w4[4] = {v[0], fmax(v[1], v[2]), v[3], fmax(v[4], fmax(v[5], v[6]))};
-        lblock_reduce<4, true>(w4, s_red);
+        // the tolerances only need max(|z|, |Ax|) and max(|q|, |A'y|, |Px|): four maxima instead of seven.  The norms
+        // that open the two infeasibility tests, |E dy| (dy clipped to the cone of the bounds) and |D dx|, ride along:
+        // one six-value block reduction (two barriers) instead of three reductions on an unconverged iterate.
+        double w4[6] = {v[0], fmax(v[1], v[2]), v[3], fmax(v[4], fmax(v[5], v[6])), 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+          if (r_i[q] >= 0) {
+            double dy = sdy[r_p[q]];
+            if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
+              if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
+            } else if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
+            w4[4] = fmax(w4[4], fabs(s_cst[q * LT + tid] * dy));
+          }
+        if (cown >= 0) w4[5] = fabs(s_cst[2 * LT + tid] * dxc);
+        if (eown >= 0) w4[5] = fmax(w4[5], fabs(s_cst[3 * LT + tid] * dxe));
+        lblock_reduce<6, true>(w4, s_red);
         CSTAMP(1)
         pri = w4[0]; dua = cinv * w4[2];
         if (!(pri <= SCO_INFTY) || !(dua <= SCO_INFTY)) { status = SCO_QP_NON_CVX; break; }
@@ -830,21 +853,18 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         const bool prim_ok = (m == 0) || (pri < eps_p), dual_ok = dua < eps_d;
         if (prim_ok && dual_ok) { status = approximate ? SCO_QP_SOLVED_INACCURATE : SCO_QP_SOLVED; break; }
         if (!prim_ok) {            // primal infeasibility certificate from delta_y
-          double r1[1] = {0.0};
-          double dyp[2] = {0.0, 0.0};
-#pragma unroll
-          for (int q = 0; q < 2; q++)
-            if (r_i[q] >= 0) {
-              double dy = sdy[r_p[q]];
-              if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
-                if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
-              } else if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
-              sdy[r_p[q]] = dy; dyp[q] = dy;
-              r1[0] = fmax(r1[0], fabs(s_cst[q * LT + tid] * dy));
-            }
-          lblock_reduce<1, true>(r1, s_red);
-          const double ndy = r1[0];
+          const double ndy = w4[4];
           if (ndy > epi) {
+            double dyp[2] = {0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+              if (r_i[q] >= 0) {
+                double dy = sdy[r_p[q]];
+                if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
+                  if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
+                } else if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
+                dyp[q] = dy;
+              }
             double lhs[1] = {0.0};
 #pragma unroll
             for (int q = 0; q < 2; q++)
@@ -871,11 +891,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         }
         CSTAMP(2)
         if (!dual_ok) {            // dual infeasibility certificate from delta_x
-          double r1[1] = {0.0};
-          if (cown >= 0) r1[0] = fabs(s_cst[2 * LT + tid] * dxc);
-          if (eown >= 0) r1[0] = fmax(r1[0], fabs(s_cst[3 * LT + tid] * dxe));
-          lblock_reduce<1, true>(r1, s_red);
-          const double ndx = r1[0];
+          const double ndx = w4[5];
           if (ndx > edi) {
             double qdx[1] = {0.0};
             if (cown >= 0) qdx[0] = qc * dxc;

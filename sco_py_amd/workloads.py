@@ -131,7 +131,16 @@ def block_groups(T, reach, scheme):
     return g
 
 
-def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None):
+def ee_cost(theta, link_len, target, weight):
+    """Non-quadratic objective term of one timestep: weight * || ee(theta) - target ||^2 (task-space attraction).
+    Its Hessian in theta is indefinite away from the target, so the reference's degree-2 convexification
+    (expr.py:143-153) has to shift its eigenvalues."""
+    e = ee_pos(theta, link_len) - np.asarray(target, dtype=np.float64)
+    return float(weight) * float(e[0] * e[0] + e[1] * e[1])
+
+
+def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None,
+                 ee_cost_weight=None):
     """Seeded problem i of the batch.  reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
@@ -158,6 +167,11 @@ def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, v
         # joint-velocity limits |theta[t+1][j] - theta[t][j]| <= vmax: LINEAR inequalities, i.e.
         # LEqExpr(AffExpr) rows that go straight into every QP (prob.py:126-131, 317-346)
         out["vmax"] = float(vel_limit)
+    if ee_cost_weight is not None:
+        # a NON-QUADRATIC objective term per timestep, weight * ||ee(theta_t) - ee(goal)||^2: Prob.add_obj_expr routes
+        # it to _nonquad_obj_exprs and every SQP iteration convexifies it to degree 2 (prob.py:88-104, 532-534)
+        out["cost_weight"] = float(ee_cost_weight)
+        out["cost_target"] = ee_pos(goal, link_len)
     if joint_limit is not None:
         # joint limits lo_j <= theta[t][j] <= hi_j for every timestep: two more LEqExpr(AffExpr) blocks.  The box
         # hugs the straight line between start and goal (margin `joint_limit`), so that avoiding the obstacles
@@ -176,6 +190,9 @@ def make_batch(B, first=0, **kw):
         extra["groups"] = p0["groups"]
     if p0.get("vmax") is not None:
         extra["vmax"] = np.array([p["vmax"] for p in probs])
+    if p0.get("cost_weight") is not None:
+        extra["cost_weight"] = np.array([p["cost_weight"] for p in probs])
+        extra["cost_target"] = np.stack([p["cost_target"] for p in probs])
     if p0.get("jlo") is not None:
         extra["jlo"] = np.stack([p["jlo"] for p in probs]); extra["jhi"] = np.stack([p["jhi"] for p in probs])
     return dict(

@@ -1,0 +1,31 @@
+"""Diagnostic variants of the row-local ADMM kernel (-DRL_ABLATE=mask, see csrc/sco_admm_rl.hip): built here in
+parallel into gpurun-visible files sco_py_amd/csrc/variants/libsco_ablate_<mask>.so; scripts/gpu_ablate.sh times them."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sco_py_amd import _build
+
+masks = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 4, 8, 12, 16, 31]
+_build.build()                                   # product objects are current
+out = os.path.join(_build.CSRC, "variants")
+os.makedirs(out, exist_ok=True)
+
+
+def one(mask):
+    obj = os.path.join(out, "rl_%d.o" % mask)
+    subprocess.check_call([_build.hipcc_path()] + _build.FLAGS + ["-DRL_ABLATE=%d" % mask, "-c",
+                           os.path.join(_build.CSRC, "sco_admm_rl.hip"), "-o", obj])
+    objs = [os.path.join(_build.OBJ, os.path.splitext(s)[0] + ".o") for s in _build.SOURCES if s != "sco_admm_rl.hip"]
+    lib = os.path.join(out, "libsco_ablate_%d.so" % mask)
+    subprocess.check_call([_build.hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib, obj] + objs)
+    os.remove(obj)
+    return lib
+
+
+with ThreadPoolExecutor(min(len(masks), os.cpu_count() or 2)) as ex:
+    for lib in ex.map(one, masks):
+        print(lib)

@@ -19,13 +19,13 @@ from oracle import sco_ref as sr
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _compare_sequence(gold_qps, oracle_qps, tag):
+def _compare_sequence(gold_qps, oracle_qps, tag, xtol=1e-9):
     assert len(gold_qps) == len(oracle_qps), (tag, len(gold_qps), len(oracle_qps))
     for k, (a, b) in enumerate(zip(gold_qps, oracle_qps)):
         P, q, A, l, u = ct.expand_weighted_qp(b)
         ct.assert_qp_close(a, P, q, A, l, u, (tag, k))
         assert a["status"] == b["status"] and a["iters"] == b["iters"], (tag, k)
-        assert np.abs(a["x"] - b["x"]).max() < 1e-9, (tag, k)
+        assert np.abs(a["x"] - b["x"]).max() < xtol, (tag, k)
 
 
 def test_reference_suite_passed_under_the_harness():
@@ -61,6 +61,68 @@ def test_flat_oracle_reproduces_reference_qp_sequence_7x20():
     assert [q["A"].shape for q in gq] == [(154, 140), (554, 340), (754, 340)]
     _compare_sequence(gq, out.qps, "7x20")
     assert out.success == bool(g["p0_success"]) and np.abs(out.x - g["p0_x"]).max() < 1e-9
+
+
+def test_flat_oracle_reproduces_reference_run_12x50():
+    """BASELINE configs[4] run by the reference's own modules (tests/golden/make_golden_12x50.py): the flat oracle
+    assembles the same projection QP and first penalty QP (n = 5600, m = 10 624), takes the same number of
+    QPs with the same statuses and iteration counts, and ends on the same trajectory.  About half a minute: the first
+    penalty QP runs to max_iter = 100 000 on the CPU."""
+    g = np.load(os.path.join(GOLD, "trajopt_12x50.npz"))
+    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(0, d=12, T=50, K=10, O=10)), record_qps=True)
+    gq = ct.load_golden_qps(g, "p0_", sparse=True)
+    assert [q["A"].shape for q in gq] == [(624, 600), (10624, 5600)]
+    assert len(out.qps) == int(g["p0_n_qp_total"])
+    _compare_sequence(gq, out.qps[:len(gq)], "12x50")
+    assert [q["status"] for q in out.qps] == g["p0_qp_status"].tolist()
+    assert [q["iters"] for q in out.qps] == g["p0_qp_iters"].tolist()
+    assert out.success == bool(g["p0_success"]) and np.abs(out.x - g["p0_x"]).max() < 1e-9
+    stored = np.load(os.path.join(GOLD, "trajopt_12x50_oracle.npz"))           # what the GPU test compares with
+    assert np.abs(stored["x"] - g["p0_x"]).max() < 1e-9 and bool(stored["success"]) == bool(g["p0_success"])
+
+
+def _obj_cases():
+    import sys
+    sys.path.insert(0, GOLD)
+    from obj_cases import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_flat_oracle_reproduces_reference_runs_with_non_quadratic_objectives(case):
+    """Prob.add_obj_expr on a plain Expr (prob.py:88-104): every SQP iteration convexifies the term to degree 2 --
+    numeric Hessian, eigenvalue shift when it is indefinite, numeric gradient (expr.py:102-156) -- and the model goes
+    into P and q (prob.py:348-367).  The golden runs come from the reference's own modules
+    (tests/golden/make_golden_obj.py); the oracle must assemble the same QPs and take the same decisions."""
+    name, kw, attrs = _obj_cases()[case]
+    g = np.load(os.path.join(GOLD, "trajopt_obj.npz"))
+    pr = af.make_problem(**kw)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr), sr.SolverParams(**(attrs or {})), record_qps=True)
+    # a QP that stops on max_iter far from convergence amplifies last-bit differences of its data: 1e-7 on its iterate
+    _compare_sequence(ct.load_golden_qps(g, name + "_"), out.qps, name, xtol=1e-7)
+    assert out.success == bool(g[name + "_success"]) and np.abs(out.x - g[name + "_x"]).max() < 1e-7
+    assert abs(out.max_violation - float(g[name + "_max_violation"])) < 1e-7
+    # the degree-2 models were needed: some P has entries off the velocity objective's pattern, some Hessian was shifted
+    P1 = out.qps[1]["P"]
+    d = kw["d"]
+    assert np.abs(P1[0, 1:d]).max() > 0
+
+
+def test_eigenvalue_shift_of_the_degree_two_model():
+    """expr.py:143-153 on an indefinite Hessian: the shifted matrix is positive semi-definite, the cyclic Jacobi sweep
+    the device uses finds the same smallest eigenvalue as eigvalsh, and the model interpolates value and gradient."""
+    pr = af.make_problem(3, d=3, T=6, K=2, O=2, ee_cost_weight=5.0)
+    ob = sr.trajopt_flat(pr).obj_blocks[2]
+    xb = pr["x0"][6:9]
+    H0 = sr.fd_hessian(ob.f, xb)
+    lam = np.linalg.eigvalsh(H0)
+    assert lam[0] < -1e-3                                        # indefinite at this point: the shift is exercised
+    assert abs(sr.min_eig_jacobi(H0) - lam[0]) < 1e-12 * (1 + abs(lam[0]))
+    H, A, b = ob.convexify(xb)
+    assert np.linalg.eigvalsh(H)[0] > -1e-12
+    g = sr.fd_jacobian(lambda v: np.array([ob.f(v)]), xb)[0]
+    assert np.abs((H.dot(xb) + A) - g).max() < 1e-12              # gradient of the model at x
+    assert abs(0.5 * xb.dot(H).dot(xb) + A.dot(xb) + b - ob.f(xb)) < 1e-12
 
 
 def test_merit_log_of_the_reference_matches_oracle_trace():

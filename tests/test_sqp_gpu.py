@@ -171,6 +171,12 @@ def test_12dof_50step_problem_against_stored_oracle_run(gpu):
     assert np.array_equal(tr[:, 6:8], g["trace"][:, 6:8])             # same QP status / iterations
     assert np.abs(res.x[0] - g["x"]).max() < TOL
     assert bool(res.success[0]) == bool(g["success"])
+    # ... and the same problem run by the REFERENCE's own modules (tests/golden/make_golden_12x50.py)
+    r = np.load(os.path.join(GOLD, "trajopt_12x50.npz"))
+    assert bool(res.success[0]) == bool(r["p0_success"]) and np.abs(res.x[0] - r["p0_x"]).max() < TOL
+    assert tr.shape[0] == int(r["p0_n_qp_total"])
+    assert np.array_equal(tr[:, 6], r["p0_qp_status"]) and np.array_equal(tr[:, 7], r["p0_qp_iters"])
+    assert abs(res.max_violation[0] - float(r["p0_max_violation"])) < 1e-7
 
 
 @pytest.mark.parametrize("shape,B", [((1, 2, 1, 1), 1), ((2, 3, 1, 1), 3), ((1, 40, 1, 2), 2), ((5, 2, 3, 1), 5)])

@@ -71,6 +71,13 @@ def build_prob(mods, pr, analytic_jac=False):
         e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
         gids = pr["groups"][t] if pr.get("groups") is not None else None
         prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(e, np.zeros((R, 1))), sv), gids)
+    if pr.get("cost_weight") is not None:
+        # non-quadratic objective terms, one Expr per timestep Variable: numeric gradient and Hessian, degree-2
+        # convexification with the eigenvalue shift (expr.py:102-156; prob.py:88-104)
+        for t in range(T):
+            def fc(x, pr=pr):
+                return np.array([[af.ee_cost(x.ravel(), pr["link_len"], pr["cost_target"], pr["cost_weight"])]])
+            prob.add_obj_expr(mods.BoundExpr(mods.Expr(fc), step_vars[t]))
     if reach:
         # end-effector target as a non-linear equality on the last timestep (abs penalty, prob.py:280-315)
         def fe(x, pr=pr):
