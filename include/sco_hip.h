@@ -201,6 +201,13 @@ void sco_sqp_default_params(sco_sqp_params *p);
 #define SCO_FAM_FLAG_JOINT_LIMITS 32 /* OR-ed into `family`: joint limits lo_j <= theta[t][j] <= hi_j at every
                                   timestep as two more LINEAR inequality blocks (theta <= hi, then -theta <= -lo,
                                   after the velocity rows); lo, hi via sco_sqp_load_joint_limits */
+#define SCO_FAM_FLAG_EE_COST 64      /* OR-ed into `family`: a NON-QUADRATIC objective term per timestep,
+                                  weight * || ee(theta[t]) - target ||^2 (ee = end effector of the planar arm).
+                                  The reference routes such an Expr to Prob._nonquad_obj_exprs (prob.py:88-104) and
+                                  convexifies it to degree 2 on every SQP iteration: numeric Hessian, shifted by its
+                                  smallest eigenvalue when that is negative, numeric gradient (expr.py:102-156,
+                                  prob.py:532-534); the model goes into P and q (prob.py:348-367).  dof <= 16;
+                                  weight, target via sco_sqp_load_ee_cost */
 
 typedef struct sco_trajopt_desc {
   int batch;
@@ -237,6 +244,9 @@ int sco_sqp_load_target(sco_sqp *h, const double *target);
 int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax);
 /* SCO_FAM_FLAG_JOINT_LIMITS only, after sco_sqp_load: lo[batch][dof] < hi[batch][dof]. */
 int sco_sqp_load_joint_limits(sco_sqp *h, const double *lo, const double *hi);
+/* SCO_FAM_FLAG_EE_COST only, after sco_sqp_load: weight[batch] >= 0, target[batch][2]
+ * (what a caller of the reference passes as Expr(f) to Prob.add_obj_expr, prob.py:88-104). */
+int sco_sqp_load_ee_cost(sco_sqp *h, const double *weight, const double *target);
 
 /* Constraint groups (prob.add_cnt_expr(bound_expr, group_ids), prob.py:112-142): n_groups <= 32 group ids
  * in SORTED order (the reference sorts them, prob.py:538, 559); block_mask[n_blocks], n_blocks = horizon

@@ -81,6 +81,7 @@ ABI = {
     "sco_sqp_load_target": (C.c_int, [C.c_void_p, _DP]),
     "sco_sqp_load_vel_limit": (C.c_int, [C.c_void_p, _DP]),
     "sco_sqp_load_joint_limits": (C.c_int, [C.c_void_p, _DP, _DP]),
+    "sco_sqp_load_ee_cost": (C.c_int, [C.c_void_p, _DP, _DP]),
     "sco_sqp_set_groups": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]),
     "sco_sqp_fetch_groups": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint)]),
     "sco_sqp_fetch_flags": (C.c_int, [C.c_void_p, _IP]),

@@ -19,6 +19,7 @@ SCO_FAM_ARM_CIRCLES = 1
 SCO_FAM_ARM_REACH = 2
 SCO_FAM_FLAG_VEL_LIMITS = 16
 SCO_FAM_FLAG_JOINT_LIMITS = 32
+SCO_FAM_FLAG_EE_COST = 64
 TRACE_W = 8
 
 
@@ -32,7 +33,9 @@ class TrajOptBatch(object):
     (``reach=True``: the goal pin is replaced by the non-linear equality
     ee(theta[T-1]) = target, SCO_FAM_ARM_REACH; ``vel_limits=True``: linear rows
     |theta[t+1] - theta[t]| <= vmax in every QP, SCO_FAM_FLAG_VEL_LIMITS; ``joint_limits=True``:
-    linear rows lo <= theta[t] <= hi, SCO_FAM_FLAG_JOINT_LIMITS)
+    linear rows lo <= theta[t] <= hi, SCO_FAM_FLAG_JOINT_LIMITS; ``ee_cost=True``: a non-quadratic objective term
+    weight * ||ee(theta[t]) - target||^2 per timestep, convexified to degree 2 like ``Prob.add_obj_expr`` on a plain
+    ``Expr`` (numeric Hessian + eigenvalue shift), SCO_FAM_FLAG_EE_COST)
     solved per problem exactly like ``Solver().solve(prob, method="penalty_sqp")``.
     ``prox_count`` says how many Variables hold each atom in the equivalent object-API
     construction (it scales the projection QP of find_closest_feasible_point,
@@ -41,7 +44,7 @@ class TrajOptBatch(object):
     """
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
-                 prox_count=2, reach=False, vel_limits=False, joint_limits=False):
+                 prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False):
         self.B, self.d, self.T, self.K, self.O = int(batch), int(dof), int(horizon), int(n_points), int(n_obstacles)
         self.n_x = self.d * self.T
         self.device = int(device)
@@ -49,10 +52,12 @@ class TrajOptBatch(object):
         self.reach = bool(reach)
         self.vel_limits = bool(vel_limits)
         self.joint_limits = bool(joint_limits)
+        self.ee_cost = bool(ee_cost)
         desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O,
                                 (SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES) |
                                 (SCO_FAM_FLAG_VEL_LIMITS if self.vel_limits else 0) |
-                                (SCO_FAM_FLAG_JOINT_LIMITS if self.joint_limits else 0),
+                                (SCO_FAM_FLAG_JOINT_LIMITS if self.joint_limits else 0) |
+                                (SCO_FAM_FLAG_EE_COST if self.ee_cost else 0),
                                 1 if analytic_jac else 0, int(prox_count))
         _lib.check(_lib.load().sco_sqp_create(self.device, C.byref(desc), C.byref(self._h)))
 
@@ -74,7 +79,7 @@ class TrajOptBatch(object):
         self.close()
 
     def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles, target=None, vmax=None,
-             jlo=None, jhi=None):
+             jlo=None, jhi=None, cost_weight=None, cost_target=None):
         """Upload per-problem data (host arrays, copied).  ``target`` (B, 2): end-effector
         position of the reach variant (``goal`` is then ignored by the device)."""
         B, d, K, O = self.B, self.d, self.K, self.O
@@ -101,6 +106,12 @@ class TrajOptBatch(object):
                 raise ValueError("velocity limits need vmax (B,)")
             vmax = arr(np.broadcast_to(np.asarray(vmax, dtype=np.float64), (B,)), (B,))
             _lib.check(_lib.load().sco_sqp_load_vel_limit(self._h, _lib.dptr(vmax)))
+        if self.ee_cost:
+            if cost_weight is None or cost_target is None:
+                raise ValueError("the objective term needs cost_weight (B,) and cost_target (B, 2)")
+            cw = arr(np.broadcast_to(np.asarray(cost_weight, dtype=np.float64), (B,)), (B,))
+            ct = arr(cost_target, (B, 2))
+            _lib.check(_lib.load().sco_sqp_load_ee_cost(self._h, _lib.dptr(cw), _lib.dptr(ct)))
         if self.joint_limits:
             if jlo is None or jhi is None:
                 raise ValueError("joint limits need jlo, jhi (B, dof)")
@@ -172,9 +183,10 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
     a = batch_arrays
     with TrajOptBatch(a["B"], a["d"], a["T"], a["K"], a["O"], device=device, analytic_jac=analytic_jac,
                       prox_count=prox_count, reach=bool(a.get("reach")), vel_limits=a.get("vmax") is not None,
-                      joint_limits=a.get("jlo") is not None) as tb:
+                      joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
-                target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"))
+                target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
+                cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"))
         if a.get("groups") is not None:
             tb.set_groups(a["groups"])
         tb.solve(params, qp_settings)

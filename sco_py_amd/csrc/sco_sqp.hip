@@ -55,6 +55,12 @@ struct SqpDev {
   // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows, then m_jl joint-limit
   // rows (theta <= hi for every trajectory variable, then -theta <= -lo)
   int m_pin, m_vel, m_jl;
+  // SCO_FAM_FLAG_EE_COST: non-quadratic objective term weight * ||ee(theta_t) - target||^2 per timestep, convexified to
+  // degree 2 every SQP iteration (expr.py:143-153): oH = Hessian after the eigenvalue shift, oA, ob = the model's
+  // linear and constant part; ppos = position in qp1's P values of entry (row (t, 0), column (t, j))
+  int cost;
+  double *cw, *ctgt, *oH, *oA, *ob;   // [B], [B][2], [B][T][d*d], [B][T][d], [B][T]
+  const int *ppos;                    // [n_x]
   const double *a0c, *a1c;      // constant parts of the A values of the projection / penalty QP (shared)
   double *vmax;                 // [B]
   double *jlo, *jhi;            // [B][d]
@@ -92,7 +98,7 @@ struct sco_sqp {
   hipStream_t stream = nullptr;
   std::vector<void *> allocs;
   std::vector<hipEvent_t> events;
-  bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false;
+  bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false, cost_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   int rounds = 0;
 };
@@ -194,6 +200,64 @@ __device__ __forceinline__ double arm_ee_grad(const double *th, const double *le
     if (i >= j) g += comp == 0 ? -(len[i] * sn) : len[i] * cs;
   }
   return g;
+}
+
+// SCO_FAM_FLAG_EE_COST: weight * ||ee(theta) - target||^2 with up to two perturbed coordinates (finite differences)
+__device__ __forceinline__ double arm_ee_cost(const double *th, const double *len, int d, double tx, double ty, double w,
+                                              int pi, double hi, int pj, double hj) {
+  double phi = 0.0, ex = 0.0, ey = 0.0;
+  for (int i = 0; i < d; i++) {
+    double a = th[i];
+    if (i == pi) a += hi;
+    if (i == pj) a += hj;
+    phi += a;
+    double sn, cs;
+    sincos(phi, &sn, &cs);
+    ex += len[i] * cs; ey += len[i] * sn;
+  }
+  ex -= tx; ey -= ty;
+  return w * (ex * ex + ey * ey);
+}
+
+// Richardson extrapolation of a central-difference ladder (halving steps): sco_py_amd/numdiff.py:_richardson
+__device__ __forceinline__ double richardson(double (&tab)[FD_LEVELS]) {
+  double p4 = 4.0;
+#pragma unroll
+  for (int i = 1; i < FD_LEVELS; i++) {
+    const double fac = 1.0 / (p4 - 1.0);
+#pragma unroll
+    for (int lv = FD_LEVELS - 1; lv >= i; lv--) tab[lv] = tab[lv] + (tab[lv] - tab[lv - 1]) * fac;
+    p4 *= 4.0;
+  }
+  return tab[FD_LEVELS - 1];
+}
+
+// smallest eigenvalue of the symmetric d x d matrix H (d <= 16) by cyclic Jacobi rotations on a private copy
+// (the reference calls scipy.linalg.eigvalsh, expr.py:145; oracle/sco_ref.py:min_eig_jacobi is this sweep)
+#define OBJ_DMAX 16
+__device__ double min_eig_jacobi(const double *H, int d) {
+  double A[OBJ_DMAX * OBJ_DMAX];
+  for (int i = 0; i < d * d; i++) A[i] = H[i];
+  for (int sweep = 0; sweep < 12; sweep++)
+    for (int p = 0; p < d - 1; p++)
+      for (int q = p + 1; q < d; q++) {
+        const double apq = A[p * d + q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (A[q * d + q] - A[p * d + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < d; k++) {            // columns p, q
+          const double rp = A[k * d + p], rq = A[k * d + q];
+          A[k * d + p] = c * rp - sn * rq; A[k * d + q] = sn * rp + c * rq;
+        }
+        for (int k = 0; k < d; k++) {            // rows p, q
+          const double rp = A[p * d + k], rq = A[q * d + k];
+          A[p * d + k] = c * rp - sn * rq; A[q * d + k] = sn * rp + c * rq;
+        }
+      }
+  double lam = A[0];
+  for (int i = 1; i < d; i++) lam = fmin(lam, A[i * d + i]);
+  return lam;
 }
 
 // Non-linear row e of a problem: hinge rows (timestep-major, R per timestep) first, then the NE
@@ -316,11 +380,14 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
   {
     double *Pv = q1.Pval + (size_t)b * q1.nnzP;
     // pattern built on the host: column (t, j) holds [super-diagonal (-2) if t > 0, diagonal]
+    // (with SCO_FAM_FLAG_EE_COST the column also holds rows (t, 0 .. j - 1) of its diagonal block: the Hessian of the
+    // objective term, written by every convexify)
     int pos = 0;
     for (int col = 0; col < n_x; col++) {   // cheap: n_x entries, one thread
       if (tid == 0) {
         const int t = col / d;
         if (t > 0) Pv[pos++] = -2.0;
+        if (s.cost) for (int i = 0; i < col % d; i++) Pv[pos++] = 0.0;
         Pv[pos++] = (t == 0 || t == s.T - 1) ? 2.0 : 4.0;
       }
     }
@@ -367,6 +434,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
   if (tid == 0) s.newqp[b] = (state != ST_DONE && !parked) ? 1 : 0;
   if (state == ST_DONE || parked) return;
   __shared__ double red[NWAVE * 4];
+  __shared__ double of0[260];           // f of the non-quadratic objective terms at the convexification point
   const int n_x = s.n_x, d = s.d, T = s.T, R = s.R, O = s.O, n = s.n, m = s.m;
   double *x = s.x + (size_t)b * n_x, *xs = s.x_saved + (size_t)b * n_x;
   const double *len = s.link_len + (size_t)b * d;
@@ -466,8 +534,95 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     }
     double *qv = q1.q + (size_t)b * n;
     for (int i = tid; i < s.n_slack; i += SCO_BLOCK) qv[n_x + i] = slack_cost;   // prob.py:424-426
+    if (s.cost) {
+      // ---- non-quadratic objective terms: Expr.convexify(degree 2) (expr.py:143-153) per timestep block
+      const double tx = s.ctgt[(size_t)b * 2], ty = s.ctgt[(size_t)b * 2 + 1], cw = s.cw[b];
+      double *oH = s.oH + (size_t)b * T * d * d, *oA = s.oA + (size_t)b * T * d, *ob = s.ob + (size_t)b * T;
+      // f(x), memoised on the rounded point like every Expr.eval (expr.py:34-41); the term shares the point history of
+      // its timestep's constraint block (same Variable, same evaluation points): its value is the block's last column
+      for (int t = tid; t < T; t += SCO_BLOCK) {
+        double f;
+        if (ev_hit[t] >= 0) f = hval[((size_t)t * H + ev_hit[t]) * RM + (RM - 1)];
+        else {
+          f = arm_ee_cost(x + t * d, len, d, tx, ty, cw, -1, 0.0, -1, 0.0);
+          if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * RM + (RM - 1)] = f;
+        }
+        of0[t] = f;
+      }
+      __syncthreads();
+      // numeric Hessian (expr.py:102-109; second central differences on the halving ladder, Richardson: numdiff.py)
+      const int npair = d * (d + 1) / 2;
+      for (int e = tid; e < T * npair; e += SCO_BLOCK) {
+        const int t = e / npair;
+        int k = e % npair, i = 0;
+        while (k >= d - i) { k -= d - i; i++; }
+        const int j = i + k;
+        const double *th = x + t * d;
+        const double si = FD_BASE * fmax(1.0, fabs(th[i])), sj = FD_BASE * fmax(1.0, fabs(th[j]));
+        double tab[FD_LEVELS];
+#pragma unroll
+        for (int lv = 0; lv < FD_LEVELS; lv++) {
+          const double hi = si / (double)(1 << lv), hj = sj / (double)(1 << lv);
+          if (i == j) {
+            const double fp = arm_ee_cost(th, len, d, tx, ty, cw, i, hi, -1, 0.0);
+            const double fm = arm_ee_cost(th, len, d, tx, ty, cw, i, -hi, -1, 0.0);
+            tab[lv] = (fp - 2.0 * of0[t] + fm) / (hi * hi);
+          } else {
+            const double fpp = arm_ee_cost(th, len, d, tx, ty, cw, i, hi, j, hj);
+            const double fpm = arm_ee_cost(th, len, d, tx, ty, cw, i, hi, j, -hj);
+            const double fmp = arm_ee_cost(th, len, d, tx, ty, cw, i, -hi, j, hj);
+            const double fmm = arm_ee_cost(th, len, d, tx, ty, cw, i, -hi, j, -hj);
+            tab[lv] = (fpp - fpm - fmp + fmm) / (4.0 * hi * hj);
+          }
+        }
+        const double hv = richardson(tab);
+        oH[(size_t)t * d * d + i * d + j] = hv; oH[(size_t)t * d * d + j * d + i] = hv;
+      }
+      // numeric gradient (expr.py:61-69), parked in oA until the block's thread turns it into the model's A
+      for (int e = tid; e < T * d; e += SCO_BLOCK) {
+        const int t = e / d, j = e % d;
+        const double *th = x + t * d;
+        const double h0 = FD_BASE * fmax(1.0, fabs(th[j]));
+        double tab[FD_LEVELS];
+#pragma unroll
+        for (int lv = 0; lv < FD_LEVELS; lv++) {
+          const double h = h0 / (double)(1 << lv);
+          tab[lv] = (arm_ee_cost(th, len, d, tx, ty, cw, j, h, -1, 0.0) - arm_ee_cost(th, len, d, tx, ty, cw, j, -h, -1, 0.0)) / (2.0 * h);
+        }
+        oA[e] = richardson(tab);
+      }
+      __syncthreads();
+      // eigenvalue shift, then Q = H, A = g - x'H, b = 1/2 x'Hx - g.x + f (expr.py:145-152)
+      for (int t = tid; t < T; t += SCO_BLOCK) {
+        double *Ht = oH + (size_t)t * d * d;
+        const double *th = x + t * d;
+        const double lam = min_eig_jacobi(Ht, d);
+        if (lam < 0.0) for (int i = 0; i < d; i++) Ht[i * d + i] -= lam;
+        double xHx = 0.0, gx = 0.0, g[OBJ_DMAX], xH[OBJ_DMAX];
+        for (int j = 0; j < d; j++) {
+          g[j] = oA[t * d + j];
+          double acc = 0.0;
+          for (int i = 0; i < d; i++) acc += th[i] * Ht[i * d + j];
+          xH[j] = acc;
+        }
+        for (int j = 0; j < d; j++) { xHx += xH[j] * th[j]; gx += g[j] * th[j]; oA[t * d + j] = g[j] - xH[j]; }
+        ob[t] = (0.5 * xHx - gx) + of0[t];
+      }
+      __syncthreads();
+      // QuadExpr lowering (prob.py:348-367; osqp_utils.py:153-163): Q into the upper triangle of P, A into q
+      double *Pv = q1.Pval + (size_t)b * q1.nnzP;
+      for (int e = tid; e < T * npair; e += SCO_BLOCK) {
+        const int t = e / npair;
+        int k = e % npair, i = 0;
+        while (k >= d - i) { k -= d - i; i++; }
+        const int j = i + k;
+        const double base = (i == j) ? ((t == 0 || t == T - 1) ? 2.0 : 4.0) : 0.0;
+        Pv[s.ppos[t * d + j] + i] = base + oH[(size_t)t * d * d + i * d + j];
+      }
+      for (int e = tid; e < n_x; e += SCO_BLOCK) qv[e] = oA[e];
+    }
     // S7: merit at the convexification point (prob.py:571-579), S4 prerequisite: save
-    double v[2] = {traj_obj_partial(x, d, T, tid), 0.0};
+    double v[2] = {traj_obj_partial(x, d, T, tid) + ((s.cost && tid < T) ? of0[tid] : 0.0), 0.0};
     for (int e = tid; e < m_nl; e += SCO_BLOCK) {
       const RowRef q = row_ref(e, T, R);
       v[1] += row_viol(q, gs[e] - row_rhs(rc, q));
@@ -532,7 +687,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
     if (tid == 0) atomicAdd(s.n_active, 1);
     return;
   }
-  __shared__ double red[NWAVE * 4];
+  __shared__ double red[NWAVE * 6];
   const int n_x = s.n_x, d = s.d, T = s.T, R = s.R, O = s.O, n = s.n;
   double *x = s.x + (size_t)b * n_x, *xs = s.x_saved + (size_t)b * n_x;
   const double *len = s.link_len + (size_t)b * d;
@@ -554,7 +709,29 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
     ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * d, hn[t], d, xq + (t < T ? t : T - 1) * d) : -1;
   __syncthreads();
   // model violation uses the FULL Jacobian (prob.py:627-628), new violation f at the new point (prob.py:575-577)
-  double v[4] = {traj_obj_partial(xq, d, T, tid), 0.0, 0.0, 0.0};
+  // v: quadratic objective, model violation, new violation, objective MODELS at the new point (prob.py:625-626),
+  //    objective terms at the new point (prob.py:571-573), max violation at the saved point
+  double v[6] = {traj_obj_partial(xq, d, T, tid), 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (s.cost) {
+    const double *oH = s.oH + (size_t)b * T * d * d, *oA = s.oA + (size_t)b * T * d, *ob = s.ob + (size_t)b * T;
+    for (int t = tid; t < T; t += SCO_BLOCK) {
+      const double *th = xq + t * d, *Ht = oH + (size_t)t * d * d;
+      double xHx = 0.0, ax = 0.0;
+      for (int i = 0; i < d; i++) {
+        double acc = 0.0;
+        for (int j = 0; j < d; j++) acc += Ht[i * d + j] * th[j];
+        xHx += th[i] * acc; ax += oA[t * d + i] * th[i];
+      }
+      v[3] += (0.5 * xHx + ax) + ob[t];                        // QuadExpr.eval (expr.py:205-206)
+      double f;
+      if (ev_hit[t] >= 0) f = hval[((size_t)t * H + ev_hit[t]) * RM + (RM - 1)];
+      else {
+        f = arm_ee_cost(th, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b], -1, 0.0, -1, 0.0);
+        if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * RM + (RM - 1)] = f;
+      }
+      v[4] += f;
+    }
+  }
   for (int e = tid; e < m_nl; e += SCO_BLOCK) {
     const RowRef q = row_ref(e, T, R);
     const double rhs = row_rhs(rc, q);
@@ -568,7 +745,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
       if (p.memo && hn[q.blk] < H) hval[((size_t)q.blk * H + hn[q.blk]) * RM + q.r] = g;
     }
     v[2] += row_viol(q, g - rhs);
-    v[3] = fmax(v[3], row_viol(q, gs[e] - rhs));                 // max violation at the SAVED point
+    v[5] = fmax(v[5], row_viol(q, gs[e] - rhs));                 // max violation at the SAVED point
   }
   __syncthreads();
   if (p.memo) {
@@ -582,7 +759,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
       }
     }
   }
-  block_reduce_sm<3, 1>(v, red);
+  block_reduce_sm<5, 1>(v, red);
   // constraint groups: which violated groups stopped improving, and do their overlapping groups too
   // (solver.py:155-161, 209-235)
   __shared__ unsigned int g_stalled, g_report;
@@ -621,7 +798,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
     }
     __syncthreads();
   }
-  const double model_merit = v[0] + pen * v[1], new_merit = v[0] + pen * v[2];
+  const double model_merit = (v[0] + v[3]) + pen * v[1], new_merit = (v[0] + v[4]) + pen * v[2];
   double approx = merit - model_merit;
   if (approx == 0.0) approx += 1e-12;                           // solver.py:152-153
   const double exact = merit - new_merit;
@@ -656,7 +833,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
       atomicAdd(s.n_active, 1);
     } else {
       // _min_merit_fn returned: outer loop of _penalty_sqp (solver.py:84-105)
-      const double max_viol = v[3];
+      const double max_viol = v[5];
       sc.escalations += 1;
       if (!capped && max_viol > p.cnt_tolerance && sc.escalations < p.max_merit_coeff_increases) {
         sc.penalty = pen * p.merit_coeff_increase_ratio;
@@ -681,6 +858,9 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *
   const double *obs = s.obstacles + (size_t)b * O * 3;
   const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O};
   double v[3] = {traj_obj_partial(x, d, T, tid), 0.0, 0.0};
+  if (s.cost)
+    for (int t = tid; t < T; t += SCO_BLOCK)
+      v[0] += arm_ee_cost(x + t * d, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b], -1, 0.0, -1, 0.0);
   for (int e = tid; e < s.m_nl; e += SCO_BLOCK) {
     const RowRef q = row_ref(e, T, R);
     const double g = row_viol(q, row_value(rc, q, x + q.t * d, -1, 0.0) - row_rhs(rc, q));
@@ -718,7 +898,8 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
 extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
   if (!desc || !out) { sco_set_error("sco_sqp_create: null pointer"); return SCO_ERR_ARG; }
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
-      desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS)) ||
+      desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS | SCO_FAM_FLAG_EE_COST)) ||
+      ((desc->family & SCO_FAM_FLAG_EE_COST) && desc->dof > OBJ_DMAX) ||
       ((desc->family & 15) != SCO_FAM_ARM_CIRCLES && (desc->family & 15) != SCO_FAM_ARM_REACH)) {
     sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
   }
@@ -742,7 +923,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   SCO_HIP(hipStreamCreate(&h->stream));
   const int B = desc->batch, d = desc->dof, T = desc->horizon, K = desc->n_points, O = desc->n_obstacles;
   const bool reach = (desc->family & 15) == SCO_FAM_ARM_REACH, vel = (desc->family & SCO_FAM_FLAG_VEL_LIMITS) != 0;
-  const bool jl = (desc->family & SCO_FAM_FLAG_JOINT_LIMITS) != 0;
+  const bool jl = (desc->family & SCO_FAM_FLAG_JOINT_LIMITS) != 0, cost = (desc->family & SCO_FAM_FLAG_EE_COST) != 0;
   const int NE = reach ? 2 : 0;                  // equality rows (end-effector x, y) on the last timestep
   const int m_pin = reach ? d : 2 * d, dT1 = d * (T - 1), m_vel = vel ? 2 * dT1 : 0;
   const int m_jl = jl ? 2 * d * T : 0;
@@ -781,13 +962,17 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
     if (rc) return rc;
   }
   // ---- penalty QP pattern (prob.py:251-278 rows, osqp_utils.py:185-189 bound rows)
-  std::vector<int> jpos(n_x), epos(d, 0);
+  std::vector<int> jpos(n_x), epos(d, 0), ppos(n_x, 0);
   {
     std::vector<int> Pp(n + 1), Pi, Ap(n + 1), Ai;
     for (int col = 0; col < n; col++) {
       Pp[col] = (int)Pi.size();
       if (col < n_x) {
         if (col / d > 0) Pi.push_back(col - d);
+        ppos[col] = (int)Pi.size();
+        // a non-quadratic objective term fills the upper triangle of its timestep's diagonal block
+        if (cost) for (int i = 0; i < col % d; i++) Pi.push_back(col - col % d + i);
+        else ppos[col] -= col % d;                 // entry (i, j) sits at ppos + i; only i == j exists
         Pi.push_back(col);
       }
     }
@@ -820,7 +1005,8 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   s.batch = B; s.d = d; s.T = T; s.K = K; s.O = O; s.R = R; s.n_x = n_x; s.n_slack = n_slack; s.n = n;
   s.m_lin = m_lin; s.m_nl = m_nl; s.m = m; s.prox_count = desc->prox_count > 0 ? desc->prox_count : 1;
   s.analytic_jac = desc->analytic_jac; s.trace_cap = 64;
-  s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE); s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl;
+  s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE) + (cost ? 1 : 0);     // + the objective term's value
+  s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl; s.cost = cost ? 1 : 0;
   int rc = 0;
 #define AL(f, cnt) if ((rc = sq_alloc(h, (cnt), &s.f))) return rc;
   AL(x0, (size_t)B * n_x) AL(start, (size_t)B * d) AL(goal, (size_t)B * d) AL(link_len, (size_t)B * d)
@@ -832,7 +1018,11 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   AL(hkey, (size_t)B * s.NB * s.H * d) AL(hval, (size_t)B * s.NB * s.H * s.RM) AL(ckey, (size_t)B * s.NB * s.HC * d)
   AL(cJ, (size_t)B * s.NB * s.HC * s.RM * d) AL(cb, (size_t)B * s.NB * s.HC * s.RM) AL(hn, (size_t)B * s.NB)
   AL(cn, (size_t)B * s.NB)
+  AL(cw, (size_t)B) AL(ctgt, (size_t)B * 2)
+  AL(oH, cost ? (size_t)B * T * d * d : 1) AL(oA, cost ? (size_t)B * T * d : 1) AL(ob, cost ? (size_t)B * T : 1)
 #undef AL
+  { int *p; if ((rc = sq_alloc(h, (size_t)n_x, &p))) return rc; s.ppos = p;
+    SCO_HIP(hipMemcpy(p, ppos.data(), n_x * sizeof(int), hipMemcpyHostToDevice)); }
   { int *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_link = p; }
   { double *p; if ((rc = sq_alloc(h, (size_t)K, &p))) return rc; s.point_frac = p; }
   { int *p; if ((rc = sq_alloc(h, (size_t)n_x, &p))) return rc; s.jpos = p;
@@ -885,6 +1075,20 @@ extern "C" int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, c
   SCO_HIP(hipMemcpyAsync((void *)s.point_frac, point_frac, s.K * sizeof(double), hipMemcpyHostToDevice, h->stream));
   SCO_HIP(hipStreamSynchronize(h->stream));
   h->loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_load_ee_cost(sco_sqp *h, const double *weight, const double *target) {
+  if (!h || !weight || !target) { sco_set_error("sco_sqp_load_ee_cost: null pointer"); return SCO_ERR_ARG; }
+  if (!(h->desc.family & SCO_FAM_FLAG_EE_COST)) { sco_set_error("sco_sqp_load_ee_cost: family has no objective term"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_load_ee_cost: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  for (int b = 0; b < h->d.batch; b++)
+    if (!(weight[b] >= 0.0)) { sco_set_error("sco_sqp_load_ee_cost: weight must be >= 0"); return SCO_ERR_ARG; }
+  SCO_ON_DEVICE(h->device);
+  SCO_HIP(hipMemcpyAsync(h->d.cw, weight, (size_t)h->d.batch * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync(h->d.ctgt, target, (size_t)h->d.batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipStreamSynchronize(h->stream));
+  h->cost_loaded = true; h->solved = false;
   return SCO_OK;
 }
 
@@ -988,6 +1192,9 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   }
   if ((h->desc.family & SCO_FAM_FLAG_VEL_LIMITS) && !h->vel_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_vel_limit first"); return SCO_ERR_STATE;
+  }
+  if ((h->desc.family & SCO_FAM_FLAG_EE_COST) && !h->cost_loaded) {
+    sco_set_error("sco_sqp_solve: call sco_sqp_load_ee_cost first"); return SCO_ERR_STATE;
   }
   if ((h->desc.family & SCO_FAM_FLAG_JOINT_LIMITS) && !h->jl_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_joint_limits first"); return SCO_ERR_STATE;

@@ -23,3 +23,36 @@ for k in sorted(tot, key=lambda k: -tot[k].get("SQ_WAVE_CYCLES", tot[k].get("FET
         print("   %-24s %18.0f  (%d dispatches)%s" % (c, v, n, extra))
         out[k][c] = {"sum": v, "dispatches": n}
 json.dump(out, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
+
+# ---- traffic record of the dominant ADMM kernel, keyed by the kernel sources it was measured on (bench.py quotes it
+# only while sco_py_amd/csrc is unchanged): FETCH_SIZE (KiB) x 2 (gfx950 counts 64 B per 128-B request on wide streaming
+# reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KiB), one bench step (--steps 1 --warmup 0)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+for key, fname in (("qp_admm_rl_kernel", "traffic.json"), ("qp_admm_bt_kernel", "traffic_12x50.json")):
+    ks = [k for k in out if key in k and "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]]
+    if not ks:
+        continue
+    fetch = sum(out[k]["FETCH_SIZE"]["sum"] for k in ks); write = sum(out[k]["WRITE_SIZE"]["sum"] for k in ks)
+    launches = sum(out[k]["FETCH_SIZE"]["dispatches"] for k in ks)
+    rec = {"kernel": ", ".join(ks), "kernel_src_sha": bench.kernel_src_sha(),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 (scripts/gpu_pmc.sh)",
+           "batch": int(os.environ.get("PMC_BATCH", "1024")),
+           "fetch_KiB_raw": fetch, "write_KiB_raw": write, "launches": launches,
+           "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE x1",
+           "hbm_bytes_per_step": (2 * fetch + write) * 1024.0, "hbm_bytes_per_launch": (2 * fetch + write) * 1024.0 / max(launches, 1)}
+    if "SQ_INSTS_VALU" in out[ks[0]]:
+        rec["sq"] = {c: sum(out[k][c]["sum"] for k in ks if c in out[k]) for c in
+                     ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU",
+                      "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                      "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE")}
+    try:        # the bench line of the FETCH_SIZE pass: ADMM problem-iterations of the profiled step
+        line = [l for l in open(os.path.join(root, "pmc_FETCH_SIZE.json")) if l.startswith("{")][-1]
+        bj = json.loads(line)
+        its = bj["aux"]["admm_iters_per_s"] * bj["ms_per_step"] * 1e-3 * bj["steps"]
+        rec["problem_iterations"] = its
+        rec["hbm_bytes_per_problem_iteration"] = rec["hbm_bytes_per_step"] / its
+    except Exception as e:
+        print("no bench line for the iteration count:", e)
+    json.dump(rec, open(os.path.join(root, fname), "w"), indent=1)
+    print("wrote", os.path.join(root, fname))

@@ -108,6 +108,30 @@ def test_flat_oracle_reproduces_reference_runs_with_non_quadratic_objectives(cas
     assert np.abs(P1[0, 1:d]).max() > 0
 
 
+@pytest.mark.parametrize("case", [2, 3])
+def test_mirror_api_reproduces_reference_runs_with_non_quadratic_objectives(case, oracle_qp_backend):
+    """The product's host path (sco_py_amd.expr / prob / solver: arbitrary callables, numeric Hessians,
+    eigenvalue shift) builds the QPs the reference built."""
+    name, kw, attrs = _obj_cases()[case]
+    g = np.load(os.path.join(GOLD, "trajopt_obj.npz"))
+    pr = af.make_problem(**kw)
+    mods = ct.mirror_mods()
+    prob, traj, _, _ = tb.build_prob(mods, pr)
+    solver = mods.Solver()
+    for k, v in (attrs or {}).items():
+        setattr(solver, k, v)
+    ok = solver.solve(prob, method="penalty_sqp")
+    gold = ct.load_golden_qps(g, name + "_")
+    assert len(gold) == len(oracle_qp_backend) and ok == bool(g[name + "_success"])
+    n_x = pr["d"] * pr["T"]
+    for k, (a, rec) in enumerate(zip(gold, oracle_qp_backend)):
+        _, _, Ae, le, ue = ct.expand_weighted_qp(rec)
+        P2, q2, A2, l2, u2, perm = tb.canonical_qp(rec["P"], rec["q"], Ae, le, ue, n_x)
+        ct.assert_qp_close(a, P2, q2, A2, l2, u2, ("mirror", name, k))
+        assert a["status"] == rec["status"] and a["iters"] == rec["iters"]
+    assert np.abs(traj.get_value().ravel() - g[name + "_x"]).max() < 1e-7
+
+
 def test_eigenvalue_shift_of_the_degree_two_model():
     """expr.py:143-153 on an indefinite Hessian: the shifted matrix is positive semi-definite, the cyclic Jacobi sweep
     the device uses finds the same smallest eigenvalue as eigvalsh, and the model interpolates value and gradient."""
