@@ -35,6 +35,11 @@
 #ifndef RL_ABLATE
 #define RL_ABLATE 0
 #endif
+// experiment switches of diagnostic builds (scripts/build_ablate.py --variant): 1 static priority for wavefronts 4-7,
+// 2 register pin on the packed offsets (the r01 form), 4 unpadded right-hand side, 8 eight iterations per loop trip
+#ifndef RL_VARIANT
+#define RL_VARIANT 0
+#endif
 #define LT 512
 #define LWV (LT / 64)
 #define LGJ 16
@@ -263,7 +268,7 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
     build_sell2(LT, ptr, src, out);
   };
   image(colp, rh.Ac); image(rowp[0], rh.Ar0); image(rowp[1], rh.Ar1);
-  rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rh.Ar0.total + rh.Ar1.total + 64 * 16 + 5 * LT) + 12 * 4 * LCAP_NC;   // + check constants
+  rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rh.Ar0.total + rh.Ar1.total + 64 * 16 + 9 * LT) + 12 * 4 * LCAP_NC;   // + check constants
   // ---- per-thread tables: packed pair offsets (bytes) and roles
   const int CPv = rh.CW / 2;
   const int slots = CPv + 2 * (LRW / 2);
@@ -384,6 +389,51 @@ __device__ __forceinline__ double lwmax63(double v) {
 #undef RL_DPP_MAX
   return v;
 }
+typedef unsigned int rl_uint2 __attribute__((ext_vector_type(2)));
+// Block maximum of six values with the lane-swap folds of the W reduction (fmax instead of add; fmax is idempotent, so
+// an odd value folds with itself): 17 swap / max instructions, then two row_shr scans instead of six.  After the folds
+// lane 15 of DPP row r holds  t0: v0, v2, v1, v3 (r = 0..3)  and  t1: v4 (r = 0, 1), v5 (r = 2, 3).
+__device__ __forceinline__ double rl_fmax32(double a, double b) {
+  const rl_uint2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const rl_uint2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return fmax(__hiloint2double((int)hi.x, (int)lo.x), __hiloint2double((int)hi.y, (int)lo.y));
+}
+__device__ __forceinline__ double rl_fmax16(double a, double b) {
+  const rl_uint2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const rl_uint2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return fmax(__hiloint2double((int)hi.x, (int)lo.x), __hiloint2double((int)hi.y, (int)lo.y));
+}
+__device__ __forceinline__ double rl_rowmax15(double v) {        // maximum of a DPP row, valid in its lane 15
+  int lo, hi, lo2, hi2;
+#define RL_ROW_MAX(ctrl)                                                                     \
+  lo = __double2loint(v); hi = __double2hiint(v);                                            \
+  lo2 = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);                          \
+  hi2 = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);                          \
+  v = fmax(v, __hiloint2double(hi2, lo2));
+  RL_ROW_MAX(0x111) RL_ROW_MAX(0x112) RL_ROW_MAX(0x114) RL_ROW_MAX(0x118)
+#undef RL_ROW_MAX
+  return v;
+}
+__device__ __forceinline__ void lblock_max6(double (&v)[6], double *red) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double u0 = rl_fmax32(v[0], v[1]), u1 = rl_fmax32(v[2], v[3]), u2 = rl_fmax32(v[4], v[5]);
+  const double t0 = rl_rowmax15(rl_fmax16(u0, u1)), t1 = rl_rowmax15(rl_fmax16(u2, u2));
+  __syncthreads();
+  if ((lane & 15) == 15) {
+    const int r = lane >> 4;
+    red[wv * 6 + (r == 0 ? 0 : r == 1 ? 2 : r == 2 ? 1 : 3)] = t0;
+    if ((r & 1) == 0) red[wv * 6 + 4 + (r >> 1)] = t1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double r = red[k];
+#pragma unroll
+    for (int w = 1; w < LWV; w++) r = fmax(r, red[w * 6 + k]);
+    v[k] = r;
+  }
+}
+
 template <int NR, bool IS_MAX>
 __device__ __forceinline__ void lblock_reduce(double (&v)[NR], double *red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -413,15 +463,16 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 // Gather-dot over N value slots = N / 2 operand PAIRS: pair h multiplies the two values V[128 h], V[128 h + 1] of
 // the paired image (one 16-byte LDS read, contiguous per wavefront) with the two operands at byte offset o[h] of
 // `vec` (one 16-byte gather; o[h] is a multiple of 16).  A padded pair has zero values and gathers the always-zero
-// pair.  Offsets stay packed two per VGPR (the empty asm stops the compiler from hoisting the unpack out of the ADMM
-// loop, which costs 2x the registers and spills).  Even and odd elements run in two accumulation chains.
+// pair.  Offsets stay packed two per VGPR.  (With per-entry offsets an empty asm had to pin them packed or the compiler
+// hoisted the unpack out of the ADMM loop and spilled; with half as many pair offsets the pin only costs a move per
+// register: 1.095 -> 1.074 us per iteration without it.)  Even and odd elements run in two accumulation chains.
 template <int N>
 __device__ __forceinline__ double rl_dot(const double *V, unsigned int *o, const double *vec) {
   constexpr int NP = N / 2;
   dbl2 val[NP], g[NP];
 #pragma unroll
   for (int h = 0; h < NP; h++) {
-    if ((h & 1) == 0) asm volatile("" : "+v"(o[h / 2]));
+    if ((h & 1) == 0 && (RL_VARIANT & 2)) asm volatile("" : "+v"(o[h / 2]));
     val[h] = *(const dbl2 *)(V + 128 * h);
     const unsigned int off = (h & 1) ? (o[h / 2] >> 16) : (o[h / 2] & 0xffffu);
     g[h] = *(const dbl2 *)((const char *)vec + off);
@@ -456,7 +507,6 @@ __device__ __forceinline__ double rl_dot_row(int w, const double *V, unsigned in
 // add leaves the pair sum of a in the lower and of b in the upper lanes), the last two levels run
 // inside the quad with quad_perm moves: 27 VALU instructions for 5 rows instead of the 60 of five
 // row_shr scans.  Fixed association order.
-typedef unsigned int rl_uint2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double rl_fold32(double a, double b) {
   const rl_uint2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
   const rl_uint2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
@@ -500,7 +550,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   // row vectors are indexed by the planner's LDS position of a row (rl_plan_build), core vectors by core index;
   // both keep an always-zero aligned pair for padded gathers (never written after the prologue)
   __shared__ __attribute__((aligned(16))) double s_tv[LCAP_M];                 // t'
-  __shared__ __attribute__((aligned(16))) double s_rv[LCAP_NC];                // core right-hand side, zero padded
+  // core right-hand side: the TC entries of column group gj start at gj * TCP (TCP = TC rounded up to even), so a
+  // thread reads its tile's entries with 16-byte LDS reads (half the LDS cycles of 8-byte pairs)
+  constexpr int TCP = (RL_VARIANT & 4) ? TC : ((TC + 1) & ~1);
+  static_assert(LGJ * TCP <= LCAP_NC + 16, "padded right-hand side");
+  __shared__ __attribute__((aligned(16))) double s_rv[LCAP_NC + 16];
   __shared__ __attribute__((aligned(16))) double s_xc[LCAP_NC];                // x~_C
   __shared__ __attribute__((aligned(16))) double s_chk[2 * LCAP_M + 2 * LCAP_NC];   // check scratch: w*y, dy (rows), x_C, dx_C
   __shared__ double s_red[LWV * 8];
@@ -553,6 +607,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   // core-variable state
   const int cown = a.role[tid];
   const int cvar = cown >= 0 ? a.role[(size_t)LT + tid] : 0;
+  const int rvpos = cown >= 0 ? (cown / TC) * TCP + cown % TC : 0;     // slot of r_c in the padded right-hand side
   double xcv = 0.0, qc = 0.0;
   if (cown >= 0) qc = a.qs[(size_t)b * n + cvar];
   // eliminated-variable state
@@ -588,9 +643,12 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     s_cst[3 * LT + tid] = eown >= 0 ? Dg0[evar] : 1.0;
     const int pd0 = eown >= 0 ? a.role[(size_t)12 * LT + tid] : -1;
     s_cst[4 * LT + tid] = pd0 >= 0 ? (a.Ps + (size_t)b * a.nnzP)[pd0] : 0.0;
+    // ... and their reciprocals (slots 5-8): the test divides by E and D in every row and column norm
+    s_cst[5 * LT + tid] = 1.0 / s_cst[tid]; s_cst[6 * LT + tid] = 1.0 / s_cst[LT + tid];
+    s_cst[7 * LT + tid] = 1.0 / s_cst[2 * LT + tid]; s_cst[8 * LT + tid] = 1.0 / s_cst[3 * LT + tid];
   }
   // ... and the P entries of a core variable's column (value, core index; padded with 0 * x_C[n_c] = 0)
-  double *s_pcv = s_cst + 5 * LT;
+  double *s_pcv = s_cst + 9 * LT;
   int *s_pci = (int *)(s_pcv + 4 * LCAP_NC);
   if (a.pcw <= 4 && cown >= 0) {
     const double *Ps0 = a.Ps + (size_t)b * a.nnzP;
@@ -603,7 +661,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     }
   }
   for (int i = tid; i < LCAP_M; i += LT) s_tv[i] = 0.0;
-  for (int i = tid; i < LCAP_NC; i += LT) { s_rv[i] = 0.0; s_xc[i] = 0.0; }
+  for (int i = tid; i < LCAP_NC; i += LT) s_xc[i] = 0.0;
+  for (int i = tid; i < LCAP_NC + 16; i += LT) s_rv[i] = 0.0;
   for (int i = tid; i < 2 * LCAP_M + 2 * LCAP_NC; i += LT) s_chk[i] = 0.0;
   __syncthreads();
   const double cscale = a.cscale[b];
@@ -660,6 +719,12 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   __syncthreads();
   if (ADAPT && tid == 0) { a.rflag[b] = 0; a.smask[b] = 0; }
 
+  // Indices that only the prologue, the rare branches of the termination test and the epilogue need are re-read from
+  // the role table there instead of occupying registers for the whole solve (the loop had a scratch reload in the
+  // column phase of every iteration).  A slot holds a row exactly when it has an LDS position.
+#define RL_ROW(q) (a.role[(size_t)(4 + (q)) * LT + tid])
+#define RL_CVAR (a.role[(size_t)LT + tid])
+#define RL_EVAR (a.role[(size_t)3 * LT + tid])
   int status = 0, iter = 0;
   double pri = 0.0, dua = 0.0;
   double rho_new = 0.0;       // ADAPT: > 0 = park now, this is the rho to continue with
@@ -685,7 +750,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     // (1) core right-hand side
     {
       const double dv = (RL_ABLATE & 1) ? 0.0 : rl_dot_col<CW>(wcol, vcol, co, s_tv);
-      if (cown >= 0) s_rv[cown] = (sigma * xcv - qc) + dv;
+      if (cown >= 0) s_rv[rvpos] = (sigma * xcv - qc) + dv;
     }
     STAMP(0)
     if (!(RL_ABLATE & 16)) __syncthreads();
@@ -695,7 +760,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     {
       double rr_[TC], acc[TR], tot[RL_NT(TR)];
 #pragma unroll
-      for (int cc = 0; cc < TC; cc++) rr_[cc] = s_rv[gj * TC + cc];
+      for (int cc = 0; cc < TC; cc++) rr_[cc] = s_rv[gj * TCP + cc];
 #pragma unroll
       for (int rr = 0; rr < TR; rr++) {
         acc[rr] = 0.0;
@@ -744,7 +809,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       }
 #pragma unroll
       for (int q = 0; q < 2; q++)
-        if (r_i[q] >= 0) {
+        if (r_p[q] >= 0) {
           s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
           if (chk) { swy[r_p[q]] = r_w[q] * r_y[q]; sdy[r_p[q]] = dyq[q]; }
         }
@@ -762,6 +827,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     }
   };
   iter = it0;
+  if ((RL_VARIANT & 1) && tid >= LT / 2) __builtin_amdgcn_s_setprio(1);
   const int stop = (a.slice > 0 && it0 + a.slice < a.max_iter) ? it0 + a.slice : a.max_iter;
   while (!status && iter < stop && !(ADAPT && rho_new > 0.0)) {
     int next = stop;
@@ -769,6 +835,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     // twelve iterations per trip (two trips between termination tests at the default cadence of 25): a loop trip
     // costs several hundred cycles of instruction refetch (profiles/r01_v6_stamps.txt); 24 copies overflow the
     // instruction cache and are slower (1.33 against 1.26 us per iteration)
+    if (!(RL_VARIANT & 8))
     while (iter + 12 < next) { iter += 12; step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); }
     while (iter + 8 < next) { iter += 8; step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); }
     while (iter + 4 < next) { iter += 4; step(false); step(false); step(false); step(false); }
@@ -792,9 +859,9 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           axc[0] = rl_dot_row(wr0, vr0, ro[0], sxc); axc[1] = rl_dot_row(wr1, vr1, ro[1], sxc);
 #pragma unroll
           for (int q = 0; q < 2; q++)
-            if (r_i[q] >= 0) {
+            if (r_p[q] >= 0) {
               const double ax = axc[q] + r_ae[q] * xe;
-              const double ei = 1.0 / s_cst[q * LT + tid];
+              const double ei = s_cst[(5 + q) * LT + tid];
               v[0] = fmax(v[0], fabs(ei * (ax - r_z[q])));
               v[1] = fmax(v[1], fabs(ei * r_z[q]));
               v[2] = fmax(v[2], fabs(ei * ax));
@@ -813,14 +880,14 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           } else {
             for (int t = a.pc_ptr[cown]; t < a.pc_ptr[cown + 1]; t++) px += Ps[a.pc_pos[t]] * sxc[a.pc_core[t]];
           }
-          const double dj = 1.0 / s_cst[2 * LT + tid];
+          const double dj = s_cst[7 * LT + tid];
           v[3] = fabs(dj * (qc + px + aty)); v[4] = fabs(dj * qc); v[5] = fabs(dj * aty); v[6] = fabs(dj * px);
           if (ADAPT && adapt_pt) { vs[3] = fabs(qc + px + aty); vs[4] = fabs(qc); vs[5] = fabs(aty); vs[6] = fabs(px); }
         }
         if (eown >= 0) {
           const double px = s_cst[4 * LT + tid] * xe;
           const double aty = r_ae[0] * (r_w[0] * r_y[0]) + r_ae[1] * (r_w[1] * r_y[1]);
-          const double dj = 1.0 / s_cst[3 * LT + tid];
+          const double dj = s_cst[8 * LT + tid];
           v[3] = fmax(v[3], fabs(dj * (qe + px + aty))); v[4] = fmax(v[4], fabs(dj * qe));
           v[5] = fmax(v[5], fabs(dj * aty)); v[6] = fmax(v[6], fabs(dj * px));
           if (ADAPT && adapt_pt) {
@@ -835,7 +902,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         double w4[6] = {v[0], fmax(v[1], v[2]), v[3], fmax(v[4], fmax(v[5], v[6])), 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < 2; q++)
-          if (r_i[q] >= 0) {
+          if (r_p[q] >= 0) {
             double dy = sdy[r_p[q]];
             if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
               if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
@@ -844,7 +911,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           }
         if (cown >= 0) w4[5] = fabs(s_cst[2 * LT + tid] * dxc);
         if (eown >= 0) w4[5] = fmax(w4[5], fabs(s_cst[3 * LT + tid] * dxe));
-        lblock_reduce<6, true>(w4, s_red);
+        lblock_max6(w4, s_red);
         CSTAMP(1)
         pri = w4[0]; dua = cinv * w4[2];
         if (!(pri <= SCO_INFTY) || !(dua <= SCO_INFTY)) { status = SCO_QP_NON_CVX; break; }
@@ -858,7 +925,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
             double dyp[2] = {0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 2; q++)
-              if (r_i[q] >= 0) {
+              if (r_p[q] >= 0) {
                 double dy = sdy[r_p[q]];
                 if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
                   if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
@@ -868,22 +935,22 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
             double lhs[1] = {0.0};
 #pragma unroll
             for (int q = 0; q < 2; q++)
-              if (r_i[q] >= 0) lhs[0] += r_w[q] * (r_us[q] * fmax(dyp[q], 0.0) + r_ls[q] * fmin(dyp[q], 0.0));
+              if (r_p[q] >= 0) lhs[0] += r_w[q] * (r_us[q] * fmax(dyp[q], 0.0) + r_ls[q] * fmin(dyp[q], 0.0));
             lblock_reduce<1, false>(lhs, s_red);
             if (lhs[0] < -epi * ndy) {
               __syncthreads();
 #pragma unroll
-              for (int q = 0; q < 2; q++) if (r_i[q] >= 0) swy[r_p[q]] = r_w[q] * dyp[q];
+              for (int q = 0; q < 2; q++) if (r_p[q] >= 0) swy[r_p[q]] = r_w[q] * dyp[q];
               __syncthreads();
               double nat[1] = {0.0};
               {
                 const double dv = rl_dot_col<CW>(wcol, vcol, co, swy);
-                if (cown >= 0) nat[0] = fabs(dv / Dg[cvar]);
+                if (cown >= 0) nat[0] = fabs(dv / Dg[RL_CVAR]);
               }
-              if (eown >= 0) nat[0] = fmax(nat[0], fabs((r_ae[0] * (r_w[0] * dyp[0]) + r_ae[1] * (r_w[1] * dyp[1])) / Dg[evar]));
+              if (eown >= 0) nat[0] = fmax(nat[0], fabs((r_ae[0] * (r_w[0] * dyp[0]) + r_ae[1] * (r_w[1] * dyp[1])) / Dg[RL_EVAR]));
               lblock_reduce<1, true>(nat, s_red);
 #pragma unroll
-              for (int q = 0; q < 2; q++) if (r_i[q] >= 0) swy[r_p[q]] = r_w[q] * r_y[q];
+              for (int q = 0; q < 2; q++) if (r_p[q] >= 0) swy[r_p[q]] = r_w[q] * r_y[q];
               __syncthreads();
               if (nat[0] < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
             }
@@ -902,11 +969,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               if (cown >= 0) {
                 double px = 0.0;
                 for (int t = a.pc_ptr[cown]; t < a.pc_ptr[cown + 1]; t++) px += Ps[a.pc_pos[t]] * sdxc[a.pc_core[t]];
-                npx[0] = fabs(px / Dg[cvar]);
+                npx[0] = fabs(px / Dg[RL_CVAR]);
               }
               if (eown >= 0) {
                 const int pd = a.role[(size_t)12 * LT + tid];
-                if (pd >= 0) npx[0] = fmax(npx[0], fabs(Ps[pd] * dxe / Dg[evar]));
+                if (pd >= 0) npx[0] = fmax(npx[0], fabs(Ps[pd] * dxe / Dg[RL_EVAR]));
               }
               lblock_reduce<1, true>(npx, s_red);
               if (npx[0] < cscale * edi * ndx) {
@@ -915,8 +982,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
                 adc[0] = rl_dot_row(wr0, vr0, ro[0], sdxc); adc[1] = rl_dot_row(wr1, vr1, ro[1], sdxc);
 #pragma unroll
                 for (int q = 0; q < 2; q++)
-                  if (r_i[q] >= 0) {
-                    const double adx = (adc[q] + r_ae[q] * dxe) / Eg[r_i[q]];
+                  if (r_p[q] >= 0) {
+                    const double adx = (adc[q] + r_ae[q] * dxe) / Eg[RL_ROW(q)];
                     if ((r_us[q] < SCO_INFTY * SCO_MIN_SCALING && adx > edi * ndx) ||
                         (r_ls[q] > -SCO_INFTY * SCO_MIN_SCALING && adx < -edi * ndx)) bad[0] = 1.0;
                   }
@@ -944,13 +1011,13 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   if (!status && iter < a.max_iter) {
     // the slice is used up (or rho changes): park the solve
     if (ADAPT && rho_new > 0.0 && tid == 0) { a.rho_b[b] = rho_new; a.rflag[b] = 1; a.smask[b] = 1; a.nupd[b] += 1; }
-    if (cown >= 0) a.sx[(size_t)b * n + cvar] = xcv;
-    if (eown >= 0) { a.sx[(size_t)b * n + evar] = xe; a.sg[(size_t)b * n_e + eown] = ge; }
+    if (cown >= 0) a.sx[(size_t)b * n + RL_CVAR] = xcv;
+    if (eown >= 0) { a.sx[(size_t)b * n + RL_EVAR] = xe; a.sg[(size_t)b * n_e + eown] = ge; }
 #pragma unroll
     for (int q = 0; q < 2; q++)
-      if (r_i[q] >= 0) {
-        a.sz[(size_t)b * m + r_i[q]] = r_z[q]; a.sy[(size_t)b * m + r_i[q]] = r_y[q];
-        a.st[(size_t)b * m + r_i[q]] = s_tv[r_p[q]];
+      if (r_p[q] >= 0) {
+        a.sz[(size_t)b * m + RL_ROW(q)] = r_z[q]; a.sy[(size_t)b * m + RL_ROW(q)] = r_y[q];
+        a.st[(size_t)b * m + RL_ROW(q)] = s_tv[r_p[q]];
       }
     if (tid == 0) { a.prog[b] = iter; a.status[b] = 0; a.iters[b] = iter; }
     return;
@@ -968,17 +1035,21 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   {
     const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
     const double cinv = 1.0 / cscale;
-    if (cown >= 0) a.x[(size_t)b * n + cvar] = Dg[cvar] * xcv;
-    if (eown >= 0) a.x[(size_t)b * n + evar] = Dg[evar] * xe;
+    if (cown >= 0) a.x[(size_t)b * n + RL_CVAR] = Dg[RL_CVAR] * xcv;
+    if (eown >= 0) a.x[(size_t)b * n + RL_EVAR] = Dg[RL_EVAR] * xe;
 #pragma unroll
     for (int q = 0; q < 2; q++)
-      if (r_i[q] >= 0) a.y[(size_t)b * m + r_i[q]] = cinv * Eg[r_i[q]] * r_y[q] * r_w[q];
+      if (r_p[q] >= 0) a.y[(size_t)b * m + RL_ROW(q)] = cinv * Eg[RL_ROW(q)] * r_y[q] * r_w[q];
     if (tid == 0) {
       a.status[b] = status; a.iters[b] = iter;
       a.resid[2 * (size_t)b] = pri; a.resid[2 * (size_t)b + 1] = dua;
     }
   }
 }
+
+#undef RL_ROW
+#undef RL_CVAR
+#undef RL_EVAR
 
 // --------------------------------------------------------------------------
 // host glue

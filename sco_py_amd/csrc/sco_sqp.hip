@@ -29,6 +29,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #define NWAVE (SCO_BLOCK / 64)
@@ -1286,6 +1287,8 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     SCO_HIP(hipMemcpyAsync(&n_active, s.n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     SCO_HIP(hipStreamSynchronize(h->stream));
     h->rounds++;
+    if (getenv("SCO_SQP_TRACE_ROUNDS") && (h->rounds < 40 || h->rounds % 100 == 0))
+      fprintf(stderr, "sco_sqp_solve: round %d, %d problems active\n", h->rounds, n_active);
   }
   if (n_active > 0) {
     // the launch cap ended the loop with problems still running (it is sized so that this cannot happen while every

@@ -9,18 +9,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sco_py_amd import _build
 
-masks = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 4, 8, 12, 16, 31]
+# arguments: ablation masks as integers; "vN" = -DRL_VARIANT=N; "name=path.hip" = an alternative kernel source
+masks = sys.argv[1:] or ["0", "1", "2", "4", "8", "12", "16", "31"]
 _build.build()                                   # product objects are current
 out = os.path.join(_build.CSRC, "variants")
 os.makedirs(out, exist_ok=True)
 
 
 def one(mask):
-    obj = os.path.join(out, "rl_%d.o" % mask)
-    subprocess.check_call([_build.hipcc_path()] + _build.FLAGS + ["-DRL_ABLATE=%d" % mask, "-c",
-                           os.path.join(_build.CSRC, "sco_admm_rl.hip"), "-o", obj])
+    src, defs, tag = os.path.join(_build.CSRC, "sco_admm_rl.hip"), [], mask
+    if "=" in mask:
+        tag, src = mask.split("=", 1)
+    elif mask.startswith("v"):
+        defs = ["-DRL_VARIANT=%d" % int(mask[1:])]
+    else:
+        defs = ["-DRL_ABLATE=%d" % int(mask)]
+    mask = tag
+    obj = os.path.join(out, "rl_%s.o" % mask)
+    subprocess.check_call([_build.hipcc_path()] + _build.FLAGS + defs + ["-I", _build.CSRC, "-x", "hip", "-c", src, "-o", obj])
     objs = [os.path.join(_build.OBJ, os.path.splitext(s)[0] + ".o") for s in _build.SOURCES if s != "sco_admm_rl.hip"]
-    lib = os.path.join(out, "libsco_ablate_%d.so" % mask)
+    lib = os.path.join(out, "libsco_ablate_%s.so" % mask)
     subprocess.check_call([_build.hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib, obj] + objs)
     os.remove(obj)
     return lib

@@ -4,8 +4,8 @@ workgroups dispatched in list order, per-problem QP iteration chains from gpurun
 import sys, heapq
 import numpy as np
 
-US_PER_IT = 1.30e-3      # ms per ADMM iteration of one workgroup (measured 1.13-1.36 us)
-ROUND_OVERHEAD = 1.0     # ms of pre/setup/post per round
+US_PER_IT = 1.09e-3      # ms per ADMM iteration of one workgroup (r02: 1.06-1.10 us incl. the termination tests)
+ROUND_OVERHEAD = 0.35    # ms of pre, setup, post + host round trip per round (r02 kernel trace: 0.1-0.7)
 CUS = 256
 
 

@@ -515,3 +515,15 @@ def test_device_admm_against_the_admm_free_solutions_of_the_golden_qps(gpu, k):
         r = qe.osqp_residuals(P, q, A, l, u, x[0], y[0])
         assert status[0] == -2 and np.abs(x[0] - xs).max() > 0.1 and mine > obj + 1.0
         assert r["dual"] > 1e-4 or r["primal_lower_bound"] > 1e-4
+
+
+def test_closed_thread_assignment_gives_the_same_answer(gpu, monkeypatch):
+    """SCO_QP_RL_CLOSED=1 (opt-in, slower on the trajectory QPs: DESIGN.md 3.2): every core column in the wavefront of all
+    its rows, phase (1) without a workgroup barrier -- same status, iteration count and solution as the default plan."""
+    rng = np.random.default_rng(17)
+    probs = [penalty_qp(rng, 20, 7, 10) for _ in range(3)]
+    base = _check(probs)
+    monkeypatch.setenv("SCO_QP_RL_CLOSED", "1")
+    closed = _check(probs)
+    assert np.array_equal(base[2], closed[2]) and np.array_equal(base[3], closed[3])
+    assert np.abs(base[1] - closed[1]).max() < 1e-10
