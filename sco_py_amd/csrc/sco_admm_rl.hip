@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 // Diagnostic builds only (scripts/build_ablate.py): -DRL_ABLATE=<mask> removes one piece of the iteration so that its
 // cost can be read off the per-iteration time (results are wrong; never compiled into the product).
@@ -44,12 +45,21 @@
 #define LWV (LT / 64)
 #define LGJ 16
 #define LGI (LT / LGJ)
-#define LCAP_M 1024
+#define LCAP_M 1280
 #define LCAP_NC 160
 #define LCW 12          // value slots of a core variable's column = 2 x operand pairs (default; 16 for the widest instantiation)
 #define LCW_MAX 16
-#define LRW 8           // value slots of a row's core entries (4 aligned pairs)
-#define RL_ROLES 18
+#define LCW_MAX3 20       // three-row-slot instantiation: 10 operand pairs per column
+#define LNS_MAX 3
+#define LRW 8           // value slots of a row's core entries (4 aligned pairs); the wide instantiation (CW = 16) takes 10
+#define LRW_MAX 10
+#define RL_ROLES 25
+// role-table rows of row slot q (slots 0, 1 keep their r01 places; slot 2 follows)
+#define ROLE_ROW(q) ((q) < 2 ? 4 + (q) : 20)
+#define ROLE_EPOS(q) ((q) < 2 ? 6 + (q) : 21)
+#define ROLE_RBASE(q) ((q) < 2 ? 9 + (q) : 22)
+#define ROLE_RWID(q) ((q) < 2 ? 14 + (q) : 23)
+#define ROLE_POS(q) ((q) < 2 ? 16 + (q) : 24)
 
 // Paired sliced-ELL: slices of 64 items (one wavefront); entries 2h and 2h+1 of lane l
 // sit next to each other at base[s] + (64 h + l) * 2, so one ds_read_b128 per lane
@@ -151,8 +161,8 @@ static bool rl_assign_closed(const QpPlan &pl, const std::vector<int> &row_elim,
   return true;
 }
 
-bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
-  if (pl.n_c + 4 > LCAP_NC || pl.m >= LCAP_M || pl.n_e > LT || pl.n_c > LT || pl.nnzA >= 65536 || pl.n > 2 * LT) return false;
+static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min) {
+  if (pl.n_c + 4 > LCAP_NC || pl.m >= LNS_MAX * LT || pl.n_e > LT || pl.n_c > LT || pl.nnzA >= 65536 || pl.n > 2 * LT) return false;
   const int m = pl.m;
   // rows of every eliminated variable; every row's eliminated variable
   std::vector<int> row_elim(m, -1), row_epos(m, -1);
@@ -171,29 +181,38 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
   // The closed assignment is measured slower on the trajectory QPs (every wavefront then runs the widest row AND
   // column code, 957 against 871 ms per bench step), so it is opt-in: SCO_QP_RL_CLOSED=1.
   const char *closed = getenv("SCO_QP_RL_CLOSED");
-  rh.merged = closed && closed[0] == '1' && rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim);
+  rh.NS = 2;
+  rh.merged = ns_min == 2 && closed && closed[0] == '1' && rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim);
   if (!rh.merged) {
-    slot_row.assign(2 * LT, -1); thr_core.assign(LT, -1); thr_elim.assign(LT, -1);
-    for (int e = 0; e < pl.n_e; e++) {               // eliminated variable e -> thread e
-      thr_elim[e] = e;
-      for (size_t q = 0; q < erows[e].size(); q++) slot_row[q * LT + e] = erows[e][q];
-    }
-    for (int c = 0; c < pl.n_c; c++) thr_core[LT - 1 - c] = c;   // far from the eliminated-variable threads
-    int cur = 0;
-    std::vector<int> order;                        // free slots: threads without an eliminated variable first
-    for (int q = 0; q < 2; q++) for (int t = pl.n_e; t < LT; t++) order.push_back(q * LT + t);
-    for (int q = 0; q < 2; q++) for (int t = 0; t < pl.n_e; t++) order.push_back(q * LT + t);
-    for (int i = 0; i < m; i++) {
-      if (row_elim[i] >= 0) continue;
-      while (cur < (int)order.size() && slot_row[order[cur]] >= 0) cur++;
-      if (cur >= (int)order.size()) return false;
-      slot_row[order[cur]] = i;
+    // two row slots per thread; a pattern with more rows than that (velocity + joint limits at 7-DOF x 20: 1100) takes
+    // the three-slot instantiation.  The rows of an eliminated variable (<= 2) always sit in slots 0 and 1 of its thread.
+    for (int ns = ns_min; ns <= LNS_MAX; ns++) {
+      rh.NS = ns;
+      slot_row.assign((size_t)ns * LT, -1); thr_core.assign(LT, -1); thr_elim.assign(LT, -1);
+      for (int e = 0; e < pl.n_e; e++) {               // eliminated variable e -> thread e
+        thr_elim[e] = e;
+        for (size_t q = 0; q < erows[e].size(); q++) slot_row[q * LT + e] = erows[e][q];
+      }
+      for (int c = 0; c < pl.n_c; c++) thr_core[LT - 1 - c] = c;   // far from the eliminated-variable threads
+      int cur = 0;
+      std::vector<int> order;                        // free slots: threads without an eliminated variable first
+      for (int q = 0; q < ns; q++) for (int t = pl.n_e; t < LT; t++) order.push_back(q * LT + t);
+      for (int q = 0; q < ns; q++) for (int t = 0; t < pl.n_e; t++) order.push_back(q * LT + t);
+      bool ok = true;
+      for (int i = 0; i < m && ok; i++) {
+        if (row_elim[i] >= 0) continue;
+        while (cur < (int)order.size() && slot_row[order[cur]] >= 0) cur++;
+        if (cur >= (int)order.size()) ok = false;
+        else slot_row[order[cur]] = i;
+      }
+      if (ok) break;
+      if (ns == LNS_MAX) return false;
     }
   }
   // ---- LDS positions of the row vectors (t', and w y / dy of the termination test).  A gather-dot reads its
   // operands two at a time (one ds_read_b128 per aligned PAIR of positions), so rows that one column reads together
-  // should sit next to each other: rows with several core entries keep their order (the rows of one constraint
-  // block are consecutive and share their columns), then the rows with a single core entry grouped by that column
+  // should sit next to each other: rows with several core entries grouped by their set of columns (the rows of one
+  // constraint block; a velocity limit and its negated copy), then the rows with a single core entry grouped by that column
   // (trust-region row, pin, joint limit of the same variable), every group on an even position.  Rows without a
   // core entry are never gathered and get no position.
   std::vector<int> pos(m, -1);
@@ -205,7 +224,26 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
         const int c = pl.core_of[pl.Rj[s]];
         if (c >= 0) { ncore[i]++; onecol[i] = c; }
       }
-    for (int i = 0; i < m; i++) if (ncore[i] >= 2) pos[i] = npos++;
+    {
+      // rows with several core entries: rows with the SAME set of core columns next to each other (the rows of a
+      // constraint block already are; a velocity limit and its negated copy are d (T - 1) rows apart), groups in order
+      // of first appearance, every group on an even position
+      std::map<std::vector<int>, int> group_of;
+      std::vector<std::vector<int>> groups;
+      for (int i = 0; i < m; i++) {
+        if (ncore[i] < 2) continue;
+        std::vector<int> sig;
+        for (int s = pl.Rp[i]; s < pl.Rp[i + 1]; s++) { const int c = pl.core_of[pl.Rj[s]]; if (c >= 0) sig.push_back(c); }
+        std::sort(sig.begin(), sig.end());
+        auto it = group_of.find(sig);
+        if (it == group_of.end()) { group_of[sig] = (int)groups.size(); groups.emplace_back(1, i); }
+        else groups[it->second].push_back(i);
+      }
+      for (const auto &g : groups) {
+        npos = (npos + 1) & ~1;
+        for (int i : g) pos[i] = npos++;
+      }
+    }
     std::vector<std::vector<int>> singles(pl.n_c);
     for (int i = 0; i < m; i++) if (ncore[i] == 1) singles[onecol[i]].push_back(i);
     for (int c = 0; c < pl.n_c; c++) {
@@ -232,9 +270,10 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
     }
     return out;
   };
-  std::vector<std::vector<Pair>> colp(LT), rowp[2];
-  rowp[0].resize(LT); rowp[1].resize(LT);
-  size_t maxc = 0;
+  const int NSv = rh.NS;
+  std::vector<std::vector<Pair>> colp(LT), rowp[LNS_MAX];
+  for (int q = 0; q < NSv; q++) rowp[q].resize(LT);
+  size_t maxc = 0, maxr = 0;
   for (int t = 0; t < LT; t++) {
     const int c = thr_core[t];
     if (c >= 0) {
@@ -244,7 +283,7 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
       colp[t] = make_pairs(ent);
       maxc = std::max(maxc, colp[t].size());
     }
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < NSv; q++) {
       const int i = slot_row[q * LT + t];
       if (i < 0) continue;
       std::vector<std::pair<int, int>> ent;
@@ -253,11 +292,13 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
         if (c2 >= 0) ent.push_back({c2, pl.Rpos[s]});
       }
       rowp[q][t] = make_pairs(ent);
-      if (rowp[q][t].size() > LRW / 2) return false;
+      if (rowp[q][t].size() > LRW_MAX / 2) return false;
+      maxr = std::max(maxr, rowp[q][t].size());
     }
   }
-  if (maxc > LCW_MAX / 2) return false;
-  if (maxc > LCW / 2) rh.CW = LCW_MAX;
+  if (maxc > (NSv > 2 ? LCW_MAX3 : LCW_MAX) / 2) return false;
+  if (maxc > LCW / 2 || maxr > LRW / 2) rh.CW = LCW_MAX;      // the wide instantiation: 8 pairs per column, 5 per row
+  if (NSv > 2) rh.CW = LCW_MAX3;                              // three row slots: 10 pairs per column, 5 per row
   // ---- sliced-ELL images in thread order: two value slots per pair
   auto image = [&](const std::vector<std::vector<Pair>> &items, SellHost &out) {
     std::vector<int> ptr(LT + 1, 0), src;
@@ -267,26 +308,29 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
     }
     build_sell2(LT, ptr, src, out);
   };
-  image(colp, rh.Ac); image(rowp[0], rh.Ar0); image(rowp[1], rh.Ar1);
-  rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rh.Ar0.total + rh.Ar1.total + 64 * 16 + 9 * LT) + 12 * 4 * LCAP_NC;   // + check constants
+  image(colp, rh.Ac);
+  size_t rtot = 0;
+  for (int q = 0; q < NSv; q++) { image(rowp[q], rh.Ar[q]); rtot += rh.Ar[q].total; }
+  rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rtot + 64 * 16 + (2 * NSv + 5) * LT) + 12 * 4 * LCAP_NC;   // + check constants
   // ---- per-thread tables: packed pair offsets (bytes) and roles
   const int CPv = rh.CW / 2;
-  const int slots = CPv + 2 * (LRW / 2);
+  const int RPv = (rh.CW > LCW ? LRW_MAX : LRW) / 2;          // pairs per row slot
+  const int slots = CPv + NSv * RPv + 1;                         // + 1: the last register of a slot is packed from two table rows
   rh.off.assign((size_t)slots * LT, 0);
   rh.role.assign((size_t)RL_ROLES * LT, -1);
   for (int t = 0; t < LT; t++) {
     for (int k = 0; k < CPv; k++) rh.off[(size_t)k * LT + t] = (unsigned short)(8 * rh.zpos);               // zero pair of t'
-    for (int k = 0; k < LRW; k++) rh.off[(size_t)(CPv + k) * LT + t] = (unsigned short)(8 * zcore);       // zero pair of x_C
+    for (int k = 0; k < NSv * RPv + 1; k++) rh.off[(size_t)(CPv + k) * LT + t] = (unsigned short)(8 * zcore);   // zero pair of x_C
     // role table: 0 core idx, 1 core var, 2 elim idx, 3 elim var, 4/5 row of slot 0/1,
     //             6/7 CSC position of the row's eliminated coefficient, 8 col base, 9/10 row bases,
     //             11/12 position of P_jj for the core / eliminated variable, 13-15 trip counts,
     //             16/17 LDS position of the row of slot 0/1
     rh.role[(size_t)8 * LT + t] = rh.Ac.base[t / 64] + 2 * (t % 64);
-    rh.role[(size_t)9 * LT + t] = rh.Ac.total + rh.Ar0.base[t / 64] + 2 * (t % 64);
-    rh.role[(size_t)10 * LT + t] = rh.Ac.total + rh.Ar0.total + rh.Ar1.base[t / 64] + 2 * (t % 64);
+    for (int q = 0, acc = rh.Ac.total; q < NSv; acc += rh.Ar[q].total, q++) {
+      rh.role[(size_t)ROLE_RBASE(q) * LT + t] = acc + rh.Ar[q].base[t / 64] + 2 * (t % 64);
+      rh.role[(size_t)ROLE_RWID(q) * LT + t] = rh.Ar[q].width[t / 64];
+    }
     rh.role[(size_t)13 * LT + t] = rh.Ac.width[t / 64];      // wave-uniform trip counts (value slots = 2 x pairs)
-    rh.role[(size_t)14 * LT + t] = rh.Ar0.width[t / 64];
-    rh.role[(size_t)15 * LT + t] = rh.Ar1.width[t / 64];
     const int c = thr_core[t];
     if (c >= 0) {
       const int j = pl.core_var[c];
@@ -298,17 +342,18 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
       rh.role[(size_t)2 * LT + t] = e; rh.role[(size_t)3 * LT + t] = pl.elim_var[e];
       rh.role[(size_t)12 * LT + t] = pl.Pdiag[pl.elim_var[e]];
     }
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < NSv; q++) {
       const int i = slot_row[q * LT + t];
-      rh.role[(size_t)(4 + q) * LT + t] = i;
+      rh.role[(size_t)ROLE_ROW(q) * LT + t] = i;
       if (i < 0) continue;
-      rh.role[(size_t)(16 + q) * LT + t] = pos[i];
+      rh.role[(size_t)ROLE_POS(q) * LT + t] = pos[i];
       if (row_elim[i] >= 0) {
         if (row_elim[i] != e) return false;
-        rh.role[(size_t)(6 + q) * LT + t] = row_epos[i];
+        if (q >= 2) return false;                    // an eliminated variable's rows live in slots 0 and 1
+        rh.role[(size_t)ROLE_EPOS(q) * LT + t] = row_epos[i];
       }
       for (size_t k = 0; k < rowp[q][t].size(); k++)
-        rh.off[(size_t)(CPv + q * (LRW / 2) + k) * LT + t] = (unsigned short)(16 * rowp[q][t][k].p);
+        rh.off[(size_t)(CPv + q * RPv + k) * LT + t] = (unsigned short)(16 * rowp[q][t][k].p);
     }
   }
   // P restricted to the core (for the dual residual): core c -> (position in triu values, core index)
@@ -326,8 +371,21 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
   rh.TR = std::max(1, (pl.n_c + LGI - 1) / LGI);
   rh.TC = 2 * rh.TR;
   if (rh.TR == 5 && pl.n_c <= LGJ * 9) rh.TC = 9;
-  if (rh.CW > LCW && rh.TR != 5) return false;        // the wide-column variant exists for the 5-row tiles only
-  return rh.lds_bytes + 32 * 1024 <= 160 * 1024;   // + 30.2 KB of static LDS
+  if (rh.CW > LCW && rh.TR != 5) return false;        // the wide variants exist for the 5-row tiles only
+  return rh.lds_bytes + 40 * 1024 <= 160 * 1024;   // + 37.5 KB of static LDS
+}
+
+// Two row slots per thread where the pattern allows it; otherwise (more than 1024 rows, or more than 8 operand pairs in
+// a column) the three-slot instantiation with ten pairs per column.
+bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
+  {
+    RlHost two;
+    if (rl_plan_build_ns(pl, two, 2)) { rh = two; return true; }
+  }
+  RlHost three;
+  if (!rl_plan_build_ns(pl, three, 3)) return false;
+  rh = three;
+  return true;
 }
 
 // --------------------------------------------------------------------------
@@ -337,9 +395,9 @@ struct RlArgs {
   int n, m, n_e, n_c, nnzA, nnzP, max_iter, check;
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   const unsigned short *off; const int *role;
-  const int *srcAc, *srcAr0, *srcAr1, *pc_ptr, *pc_pos, *pc_core;
+  const int *srcAc, *srcAr[LNS_MAX], *pc_ptr, *pc_pos, *pc_core;
   int pcw;           // most P entries in a core column; <= 4: the termination test reads them from LDS
-  int totAc, totAr0, totAr1;
+  int totAc, totAr[LNS_MAX];
   const double *As, *W, *qs, *kee_inv, *ls, *us, *rho, *cscale, *Ps, *D, *E;
   const int *w, *active;
   double *x, *y, *resid;
@@ -490,13 +548,16 @@ __device__ __forceinline__ double rl_dot_col(int w, const double *V, unsigned in
   if (w <= 4) return rl_dot<4>(V, o, vec);
   if (w <= 8) return rl_dot<8>(V, o, vec);
   if constexpr (CW > 12) { if (w <= 12) return rl_dot<12>(V, o, vec); }
+  if constexpr (CW > 16) { if (w <= 16) return rl_dot<16>(V, o, vec); }
   return rl_dot<CW>(V, o, vec);
 }
-__device__ __forceinline__ double rl_dot_row(int w, const double *V, unsigned int *o, const double *vec) {
+template <int RW>
+__device__ __forceinline__ double rl_dot_row_w(int w, const double *V, unsigned int *o, const double *vec) {
   if (w <= 0) return 0.0;
   if (w <= 2) return rl_dot<2>(V, o, vec);
   if (w <= 4) return rl_dot<4>(V, o, vec);
-  return rl_dot<LRW>(V, o, vec);
+  if constexpr (RW > LRW) { if (w <= LRW) return rl_dot<LRW>(V, o, vec); }
+  return rl_dot<RW>(V, o, vec);
 }
 
 // ---- phase (3) reduction --------------------------------------------------------------
@@ -541,7 +602,7 @@ __device__ __forceinline__ void rl_reduce_rows(const double (&acc)[TR], double (
 }
 __device__ __forceinline__ int rl_tile_row(int n, int h) { return 4 * n + 2 * (h & 1) + (h >> 1); }
 
-template <int TR, int TC, int CW, bool ADAPT>
+template <int TR, int TC, int CW, bool ADAPT, int NS = 2>
 __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (a.active && !a.active[b]) return;
@@ -567,28 +628,34 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     double *V = s_val;
     for (int p = tid; p < a.totAc; p += LT) { const int s = a.srcAc[p]; V[p] = s >= 0 ? gAs[s] : 0.0; }
     V += a.totAc;
-    for (int p = tid; p < a.totAr0; p += LT) { const int s = a.srcAr0[p]; V[p] = s >= 0 ? gAs[s] : 0.0; }
-    V += a.totAr0;
-    for (int p = tid; p < a.totAr1; p += LT) { const int s = a.srcAr1[p]; V[p] = s >= 0 ? gAs[s] : 0.0; }
-    V += a.totAr1;
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+      for (int p = tid; p < a.totAr[q]; p += LT) { const int s = a.srcAr[q][p]; V[p] = s >= 0 ? gAs[s] : 0.0; }
+      V += a.totAr[q];
+    }
     for (int p = tid; p < 64 * 16; p += LT) V[p] = 0.0;
   }
   auto pack = [&](int slot) -> unsigned int {
     return (unsigned int)a.off[(size_t)slot * LT + tid] | ((unsigned int)a.off[(size_t)(slot + 1) * LT + tid] << 16);
   };
-  unsigned int co[CW / 4], ro[2][LRW / 4];        // pair offsets, two per register
+  constexpr int RW = CW > LCW ? LRW_MAX : LRW;     // value slots per row: the wide instantiation takes 5 operand pairs
+  constexpr int RO = (RW / 2 + 1) / 2;
+  unsigned int co[CW / 4], ro[NS][RO];             // pair offsets, two per register
+  auto rl_dot_row = [&](int w, const double *V, unsigned int *o, const double *vec) __attribute__((always_inline)) { return rl_dot_row_w<RW>(w, V, o, vec); };
 #pragma unroll
   for (int k = 0; k < CW / 4; k++) co[k] = pack(2 * k);
 #pragma unroll
-  for (int q = 0; q < 2; q++)
+  for (int q = 0; q < NS; q++)
 #pragma unroll
-    for (int k = 0; k < LRW / 4; k++) ro[q][k] = pack(CW / 2 + q * (LRW / 2) + 2 * k);
+    for (int k = 0; k < RO; k++) ro[q][k] = pack(CW / 2 + q * (RW / 2) + 2 * k);
   const double *vcol = s_val + a.role[(size_t)8 * LT + tid];
-  const double *vr0 = s_val + a.role[(size_t)9 * LT + tid];
-  const double *vr1 = s_val + a.role[(size_t)10 * LT + tid];
+  const double *vr[NS]; int wr[NS];
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    vr[q] = s_val + a.role[(size_t)ROLE_RBASE(q) * LT + tid];
+    wr[q] = __builtin_amdgcn_readfirstlane(a.role[(size_t)ROLE_RWID(q) * LT + tid]);
+  }
   const int wcol = __builtin_amdgcn_readfirstlane(a.role[(size_t)13 * LT + tid]);
-  const int wr0 = __builtin_amdgcn_readfirstlane(a.role[(size_t)14 * LT + tid]);
-  const int wr1 = __builtin_amdgcn_readfirstlane(a.role[(size_t)15 * LT + tid]);
   // W tile of this thread: row group gi (4 per wavefront: bits 2-3 of the lane), column group gj (bits 0-1 and
   // 4-5 of the lane: the 16 lanes whose partial sums rl_reduce_rows adds)
   const int gi = (tid >> 6) * 4 + ((tid >> 2) & 3), gj = (tid & 3) + 4 * ((tid >> 4) & 3);
@@ -616,39 +683,46 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   double xe = 0.0, qe = 0.0, kinv = 0.0, ge = 0.0;
   if (eown >= 0) { qe = a.qs[(size_t)b * n + evar]; kinv = a.kee_inv[(size_t)b * n_e + eown]; ge = -qe * kinv; }
   // row state
-  int r_i[2], r_p[2]; double r_ls[2], r_us[2], r_rho[2], r_rinv[2], r_z[2], r_y[2], r_w[2], r_ae[2];
+  int r_i[NS], r_p[NS]; double r_ls[NS], r_us[NS], r_rho[NS], r_rinv[NS], r_z[NS], r_y[NS], r_w[NS], r_ae[NS];
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
-    r_i[q] = a.role[(size_t)(4 + q) * LT + tid];
-    r_p[q] = a.role[(size_t)(16 + q) * LT + tid];       // LDS position of the row in t' / w y / dy
+  for (int q = 0; q < NS; q++) {
+    r_i[q] = a.role[(size_t)ROLE_ROW(q) * LT + tid];
+    r_p[q] = a.role[(size_t)ROLE_POS(q) * LT + tid];       // LDS position of the row in t' / w y / dy
     r_ls[q] = r_us[q] = r_z[q] = r_y[q] = r_ae[q] = 0.0; r_rho[q] = r_rinv[q] = r_w[q] = 1.0;
     if (r_i[q] >= 0) {
       const int i = r_i[q];
       r_ls[q] = a.ls[(size_t)b * m + i]; r_us[q] = a.us[(size_t)b * m + i];
       r_rho[q] = a.rho[(size_t)b * m + i]; r_rinv[q] = 1.0 / r_rho[q];
       r_w[q] = (double)a.w[(size_t)b * m + i];
-      const int ep = a.role[(size_t)(6 + q) * LT + tid];
+      const int ep = a.role[(size_t)ROLE_EPOS(q) * LT + tid];
       if (ep >= 0) r_ae[q] = gAs[ep];
     }
   }
   // per-thread constants of the termination test, parked in LDS (slot k of thread t at [k * LT + t]): the scalings
   // E of its two rows, D of its core / eliminated variable, the eliminated variable's P_ee.  Read back by the
   // same thread only; from global memory they cost the test ~2 us of exposed L2 latency every 25 iterations.
-  double *s_cst = s_val + a.totAc + a.totAr0 + a.totAr1 + 64 * 16;
+  // slots: CS_E + q = E of row slot q, CS_DC / CS_DE = D of the core / eliminated variable, CS_PEE = P_ee, then the
+  // reciprocals CS_RE + q, CS_RDC, CS_RDE (the test divides by E and D in every row and column norm)
+  constexpr int CS_E = 0, CS_DC = NS, CS_DE = NS + 1, CS_PEE = NS + 2, CS_RE = NS + 3, CS_RDC = 2 * NS + 3, CS_RDE = 2 * NS + 4, CS_N = 2 * NS + 5;
+  int atot = a.totAc;
+#pragma unroll
+  for (int q = 0; q < NS; q++) atot += a.totAr[q];
+  double *s_cst = s_val + atot + 64 * 16;
   {
     const double *Dg0 = a.D + (size_t)b * n, *Eg0 = a.E + (size_t)b * m;
-    s_cst[tid] = r_i[0] >= 0 ? Eg0[r_i[0]] : 1.0;
-    s_cst[LT + tid] = r_i[1] >= 0 ? Eg0[r_i[1]] : 1.0;
-    s_cst[2 * LT + tid] = cown >= 0 ? Dg0[cvar] : 1.0;
-    s_cst[3 * LT + tid] = eown >= 0 ? Dg0[evar] : 1.0;
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+      s_cst[(CS_E + q) * LT + tid] = r_i[q] >= 0 ? Eg0[r_i[q]] : 1.0;
+      s_cst[(CS_RE + q) * LT + tid] = 1.0 / s_cst[(CS_E + q) * LT + tid];
+    }
+    s_cst[CS_DC * LT + tid] = cown >= 0 ? Dg0[cvar] : 1.0;
+    s_cst[CS_DE * LT + tid] = eown >= 0 ? Dg0[evar] : 1.0;
     const int pd0 = eown >= 0 ? a.role[(size_t)12 * LT + tid] : -1;
-    s_cst[4 * LT + tid] = pd0 >= 0 ? (a.Ps + (size_t)b * a.nnzP)[pd0] : 0.0;
-    // ... and their reciprocals (slots 5-8): the test divides by E and D in every row and column norm
-    s_cst[5 * LT + tid] = 1.0 / s_cst[tid]; s_cst[6 * LT + tid] = 1.0 / s_cst[LT + tid];
-    s_cst[7 * LT + tid] = 1.0 / s_cst[2 * LT + tid]; s_cst[8 * LT + tid] = 1.0 / s_cst[3 * LT + tid];
+    s_cst[CS_PEE * LT + tid] = pd0 >= 0 ? (a.Ps + (size_t)b * a.nnzP)[pd0] : 0.0;
+    s_cst[CS_RDC * LT + tid] = 1.0 / s_cst[CS_DC * LT + tid]; s_cst[CS_RDE * LT + tid] = 1.0 / s_cst[CS_DE * LT + tid];
   }
   // ... and the P entries of a core variable's column (value, core index; padded with 0 * x_C[n_c] = 0)
-  double *s_pcv = s_cst + 9 * LT;
+  double *s_pcv = s_cst + CS_N * LT;
   int *s_pci = (int *)(s_pcv + 4 * LCAP_NC);
   if (a.pcw <= 4 && cown >= 0) {
     const double *Ps0 = a.Ps + (size_t)b * a.nnzP;
@@ -674,19 +748,19 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     if (cown >= 0) xcv = a.sx[(size_t)b * n + cvar];
     if (eown >= 0) { xe = a.sx[(size_t)b * n + evar]; ge = a.sg[(size_t)b * n_e + eown]; }
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NS; q++)
       if (r_i[q] >= 0) {
         r_z[q] = a.sz[(size_t)b * m + r_i[q]]; r_y[q] = a.sy[(size_t)b * m + r_i[q]];
         s_tv[r_p[q]] = a.st[(size_t)b * m + r_i[q]];
       }
     if (ADAPT && a.rflag[b]) {
-      double tq[2] = {0.0, 0.0};
+      double tq[NS] = {};
 #pragma unroll
-      for (int q = 0; q < 2; q++)
+      for (int q = 0; q < NS; q++)
         if (r_i[q] >= 0) tq[q] = r_w[q] * (r_rho[q] * r_z[q] - r_y[q]);
       if (eown >= 0) ge = ((sigma * xe - qe) + r_ae[0] * tq[0] + r_ae[1] * tq[1]) * kinv;
 #pragma unroll
-      for (int q = 0; q < 2; q++)
+      for (int q = 0; q < NS; q++)
         if (r_i[q] >= 0) s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
     }
   } else if (a.warm) {
@@ -696,11 +770,12 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     if (cown >= 0) { xcv = a.x[(size_t)b * n + cvar] / Dg[cvar]; sxc[cown] = xcv; }
     if (eown >= 0) xe = a.x[(size_t)b * n + evar] / Dg[evar];
     __syncthreads();
-    double axc[2];
-    axc[0] = rl_dot_row(wr0, vr0, ro[0], sxc); axc[1] = rl_dot_row(wr1, vr1, ro[1], sxc);
-    double tq[2] = {0.0, 0.0};
+    double axc[NS];
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NS; q++) axc[q] = rl_dot_row(wr[q], vr[q], ro[q], sxc);
+    double tq[NS] = {};
+#pragma unroll
+    for (int q = 0; q < NS; q++)
       if (r_i[q] >= 0) {
         r_z[q] = axc[q] + r_ae[q] * xe;
         r_y[q] = a.y[(size_t)b * m + r_i[q]] * cscale / (Eg[r_i[q]] * r_w[q]);
@@ -708,12 +783,12 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       }
     if (eown >= 0) ge = ((sigma * xe - qe) + r_ae[0] * tq[0] + r_ae[1] * tq[1]) * kinv;
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NS; q++)
       if (r_i[q] >= 0) s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
   } else {
     // t' of the start point x = z = y = 0:  t = 0, g_e = -q_e / K_ee, t'_i = -rw_i a_ie g_e
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NS; q++)
       if (r_i[q] >= 0) s_tv[r_p[q]] = -(r_w[q] * r_rho[q]) * r_ae[q] * ge;
   }
   __syncthreads();
@@ -722,7 +797,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   // Indices that only the prologue, the rare branches of the termination test and the epilogue need are re-read from
   // the role table there instead of occupying registers for the whole solve (the loop had a scratch reload in the
   // column phase of every iteration).  A slot holds a row exactly when it has an LDS position.
-#define RL_ROW(q) (a.role[(size_t)(4 + (q)) * LT + tid])
+#define RL_ROW(q) (a.role[(size_t)ROLE_ROW(q) * LT + tid])
 #define RL_CVAR (a.role[(size_t)LT + tid])
 #define RL_EVAR (a.role[(size_t)3 * LT + tid])
   int status = 0, iter = 0;
@@ -785,14 +860,14 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     STAMP(3)
     // (Y) rows, eliminated variable, updates, next t'
     {
-      double zc[2];
-      zc[0] = (RL_ABLATE & 2) ? s_xc[0] : rl_dot_row(wr0, vr0, ro[0], s_xc);
-      zc[1] = (RL_ABLATE & 2) ? s_xc[1] : rl_dot_row(wr1, vr1, ro[1], s_xc);
+      double zc[NS];
+#pragma unroll
+      for (int q = 0; q < NS; q++) zc[q] = (RL_ABLATE & 2) ? s_xc[q] : rl_dot_row(wr[q], vr[q], ro[q], s_xc);
       // x~_e = g_e - (1/K_ee) sum_i rw_i a_ie (A_iC x~_C)
       const double xte = ge - kinv * ((r_w[0] * r_rho[0]) * r_ae[0] * zc[0] + (r_w[1] * r_rho[1]) * r_ae[1] * zc[1]);
-      double tq[2], dyq[2];
+      double tq[NS], dyq[NS];
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < NS; q++) {
         const double zt = zc[q] + r_ae[q] * xte;
         const double zr = alpha * zt + (1.0 - alpha) * r_z[q];
         double zn = zr + r_rinv[q] * r_y[q];
@@ -808,7 +883,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         ge = rhs_e * kinv;
       }
 #pragma unroll
-      for (int q = 0; q < 2; q++)
+      for (int q = 0; q < NS; q++)
         if (r_p[q] >= 0) {
           s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
           if (chk) { swy[r_p[q]] = r_w[q] * r_y[q]; sdy[r_p[q]] = dyq[q]; }
@@ -855,13 +930,14 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
         double v[7] = {0, 0, 0, 0, 0, 0, 0};
         {
-          double axc[2];
-          axc[0] = rl_dot_row(wr0, vr0, ro[0], sxc); axc[1] = rl_dot_row(wr1, vr1, ro[1], sxc);
+          double axc[NS];
 #pragma unroll
-          for (int q = 0; q < 2; q++)
+          for (int q = 0; q < NS; q++) axc[q] = rl_dot_row(wr[q], vr[q], ro[q], sxc);
+#pragma unroll
+          for (int q = 0; q < NS; q++)
             if (r_p[q] >= 0) {
               const double ax = axc[q] + r_ae[q] * xe;
-              const double ei = s_cst[(5 + q) * LT + tid];
+              const double ei = s_cst[(CS_RE + q) * LT + tid];
               v[0] = fmax(v[0], fabs(ei * (ax - r_z[q])));
               v[1] = fmax(v[1], fabs(ei * r_z[q]));
               v[2] = fmax(v[2], fabs(ei * ax));
@@ -880,14 +956,14 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           } else {
             for (int t = a.pc_ptr[cown]; t < a.pc_ptr[cown + 1]; t++) px += Ps[a.pc_pos[t]] * sxc[a.pc_core[t]];
           }
-          const double dj = s_cst[7 * LT + tid];
+          const double dj = s_cst[CS_RDC * LT + tid];
           v[3] = fabs(dj * (qc + px + aty)); v[4] = fabs(dj * qc); v[5] = fabs(dj * aty); v[6] = fabs(dj * px);
           if (ADAPT && adapt_pt) { vs[3] = fabs(qc + px + aty); vs[4] = fabs(qc); vs[5] = fabs(aty); vs[6] = fabs(px); }
         }
         if (eown >= 0) {
-          const double px = s_cst[4 * LT + tid] * xe;
+          const double px = s_cst[CS_PEE * LT + tid] * xe;
           const double aty = r_ae[0] * (r_w[0] * r_y[0]) + r_ae[1] * (r_w[1] * r_y[1]);
-          const double dj = s_cst[8 * LT + tid];
+          const double dj = s_cst[CS_RDE * LT + tid];
           v[3] = fmax(v[3], fabs(dj * (qe + px + aty))); v[4] = fmax(v[4], fabs(dj * qe));
           v[5] = fmax(v[5], fabs(dj * aty)); v[6] = fmax(v[6], fabs(dj * px));
           if (ADAPT && adapt_pt) {
@@ -901,16 +977,16 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         // one six-value block reduction (two barriers) instead of three reductions on an unconverged iterate.
         double w4[6] = {v[0], fmax(v[1], v[2]), v[3], fmax(v[4], fmax(v[5], v[6])), 0.0, 0.0};
 #pragma unroll
-        for (int q = 0; q < 2; q++)
+        for (int q = 0; q < NS; q++)
           if (r_p[q] >= 0) {
             double dy = sdy[r_p[q]];
             if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
               if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
             } else if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
-            w4[4] = fmax(w4[4], fabs(s_cst[q * LT + tid] * dy));
+            w4[4] = fmax(w4[4], fabs(s_cst[(CS_E + q) * LT + tid] * dy));
           }
-        if (cown >= 0) w4[5] = fabs(s_cst[2 * LT + tid] * dxc);
-        if (eown >= 0) w4[5] = fmax(w4[5], fabs(s_cst[3 * LT + tid] * dxe));
+        if (cown >= 0) w4[5] = fabs(s_cst[CS_DC * LT + tid] * dxc);
+        if (eown >= 0) w4[5] = fmax(w4[5], fabs(s_cst[CS_DE * LT + tid] * dxe));
         lblock_max6(w4, s_red);
         CSTAMP(1)
         pri = w4[0]; dua = cinv * w4[2];
@@ -922,9 +998,9 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         if (!prim_ok) {            // primal infeasibility certificate from delta_y
           const double ndy = w4[4];
           if (ndy > epi) {
-            double dyp[2] = {0.0, 0.0};
+            double dyp[NS] = {};
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+            for (int q = 0; q < NS; q++)
               if (r_p[q] >= 0) {
                 double dy = sdy[r_p[q]];
                 if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
@@ -934,13 +1010,13 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               }
             double lhs[1] = {0.0};
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+            for (int q = 0; q < NS; q++)
               if (r_p[q] >= 0) lhs[0] += r_w[q] * (r_us[q] * fmax(dyp[q], 0.0) + r_ls[q] * fmin(dyp[q], 0.0));
             lblock_reduce<1, false>(lhs, s_red);
             if (lhs[0] < -epi * ndy) {
               __syncthreads();
 #pragma unroll
-              for (int q = 0; q < 2; q++) if (r_p[q] >= 0) swy[r_p[q]] = r_w[q] * dyp[q];
+              for (int q = 0; q < NS; q++) if (r_p[q] >= 0) swy[r_p[q]] = r_w[q] * dyp[q];
               __syncthreads();
               double nat[1] = {0.0};
               {
@@ -950,7 +1026,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               if (eown >= 0) nat[0] = fmax(nat[0], fabs((r_ae[0] * (r_w[0] * dyp[0]) + r_ae[1] * (r_w[1] * dyp[1])) / Dg[RL_EVAR]));
               lblock_reduce<1, true>(nat, s_red);
 #pragma unroll
-              for (int q = 0; q < 2; q++) if (r_p[q] >= 0) swy[r_p[q]] = r_w[q] * r_y[q];
+              for (int q = 0; q < NS; q++) if (r_p[q] >= 0) swy[r_p[q]] = r_w[q] * r_y[q];
               __syncthreads();
               if (nat[0] < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
             }
@@ -978,10 +1054,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               lblock_reduce<1, true>(npx, s_red);
               if (npx[0] < cscale * edi * ndx) {
                 double bad[1] = {0.0};
-                double adc[2];
-                adc[0] = rl_dot_row(wr0, vr0, ro[0], sdxc); adc[1] = rl_dot_row(wr1, vr1, ro[1], sdxc);
+                double adc[NS];
 #pragma unroll
-                for (int q = 0; q < 2; q++)
+                for (int q = 0; q < NS; q++) adc[q] = rl_dot_row(wr[q], vr[q], ro[q], sdxc);
+#pragma unroll
+                for (int q = 0; q < NS; q++)
                   if (r_p[q] >= 0) {
                     const double adx = (adc[q] + r_ae[q] * dxe) / Eg[RL_ROW(q)];
                     if ((r_us[q] < SCO_INFTY * SCO_MIN_SCALING && adx > edi * ndx) ||
@@ -1014,7 +1091,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     if (cown >= 0) a.sx[(size_t)b * n + RL_CVAR] = xcv;
     if (eown >= 0) { a.sx[(size_t)b * n + RL_EVAR] = xe; a.sg[(size_t)b * n_e + eown] = ge; }
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NS; q++)
       if (r_p[q] >= 0) {
         a.sz[(size_t)b * m + RL_ROW(q)] = r_z[q]; a.sy[(size_t)b * m + RL_ROW(q)] = r_y[q];
         a.st[(size_t)b * m + RL_ROW(q)] = s_tv[r_p[q]];
@@ -1038,7 +1115,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     if (cown >= 0) a.x[(size_t)b * n + RL_CVAR] = Dg[RL_CVAR] * xcv;
     if (eown >= 0) a.x[(size_t)b * n + RL_EVAR] = Dg[RL_EVAR] * xe;
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NS; q++)
       if (r_p[q] >= 0) a.y[(size_t)b * m + RL_ROW(q)] = cinv * Eg[RL_ROW(q)] * r_y[q] * r_w[q];
     if (tid == 0) {
       a.status[b] = status; a.iters[b] = iter;
@@ -1077,15 +1154,15 @@ int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd) {
   if ((rc = upl(allocs, rh.off, &rd.off))) return rc;
   if ((rc = upl(allocs, rh.role, &rd.role))) return rc;
   if ((rc = upl(allocs, rh.Ac.src, &rd.srcAc))) return rc;
-  if ((rc = upl(allocs, rh.Ar0.src, &rd.srcAr0))) return rc;
-  if ((rc = upl(allocs, rh.Ar1.src, &rd.srcAr1))) return rc;
+  for (int q = 0; q < LNS_MAX; q++)
+    if ((rc = upl(allocs, rh.Ar[q].src, &rd.srcAr[q]))) return rc;
   if ((rc = upl(allocs, rh.pc_ptr, &rd.pc_ptr))) return rc;
   if ((rc = upl(allocs, rh.pc_pos, &rd.pc_pos))) return rc;
   if ((rc = upl(allocs, rh.pc_core, &rd.pc_core))) return rc;
   return SCO_OK;
 }
 
-template <int TR, int TC, int CW, bool ADAPT>
+template <int TR, int TC, int CW, bool ADAPT, int NS = 2>
 static int rl_launch_k(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
   // hipFuncSetAttribute applies to the current device only
   static bool attr_done[64] = {};
@@ -1093,18 +1170,18 @@ static int rl_launch_k(const RlArgs &ra, int batch, size_t lds, hipStream_t st) 
   (void)hipGetDevice(&dev_);
   dev_ &= 63;
   if (!attr_done[dev_]) {
-    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC, CW, ADAPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 108 * 1024));
     attr_done[dev_] = true;
   }
-  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC, CW, ADAPT>), dim3(batch), dim3(LT), lds, st, ra);
+  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS>), dim3(batch), dim3(LT), lds, st, ra);
   SCO_HIP(hipGetLastError());
   return SCO_OK;
 }
-template <int TR, int TC, int CW = LCW>
+template <int TR, int TC, int CW = LCW, int NS = 2>
 static int rl_launch_one(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
   // the adaptive-rho variant is a separate instantiation: the default kernel's code is untouched by it
-  return ra.ad_interval > 0 ? rl_launch_k<TR, TC, CW, true>(ra, batch, lds, st) : rl_launch_k<TR, TC, CW, false>(ra, batch, lds, st);
+  return ra.ad_interval > 0 ? rl_launch_k<TR, TC, CW, true, NS>(ra, batch, lds, st) : rl_launch_k<TR, TC, CW, false, NS>(ra, batch, lds, st);
 }
 
 int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t st) {
@@ -1114,9 +1191,10 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.max_iter = a.max_iter; ra.check = a.check;
   ra.sigma = a.sigma; ra.alpha = a.alpha; ra.eps_abs = a.eps_abs; ra.eps_rel = a.eps_rel;
   ra.eps_prim_inf = a.eps_prim_inf; ra.eps_dual_inf = a.eps_dual_inf;
-  ra.off = rd.off; ra.role = rd.role; ra.srcAc = rd.srcAc; ra.srcAr0 = rd.srcAr0; ra.srcAr1 = rd.srcAr1;
+  ra.off = rd.off; ra.role = rd.role; ra.srcAc = rd.srcAc;
+  for (int q = 0; q < LNS_MAX; q++) { ra.srcAr[q] = rd.srcAr[q]; ra.totAr[q] = q < rh.NS ? rh.Ar[q].total : 0; }
   ra.pc_ptr = rd.pc_ptr; ra.pc_pos = rd.pc_pos; ra.pc_core = rd.pc_core; ra.pcw = rh.pcw;
-  ra.totAc = rh.Ac.total; ra.totAr0 = rh.Ar0.total; ra.totAr1 = rh.Ar1.total;
+  ra.totAc = rh.Ac.total;
   ra.As = d.As; ra.W = d.W; ra.qs = d.qs; ra.kee_inv = d.kee_inv; ra.ls = d.ls; ra.us = d.us; ra.rho = d.rho;
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
@@ -1133,6 +1211,13 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
     extern double *sco_debug_stamp_ptr; sco_debug_stamp_ptr = g_stamp;
   }
 #endif
+  if (rh.NS == 3) {
+    // three row slots per thread and ten operand pairs per column (velocity + joint limits at 7-DOF x 20: 1100 rows)
+    if (rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW_MAX3, 3>(ra, d.batch, rh.lds_bytes, st);
+    if (rh.TR == 5 && rh.TC == 10) return rl_launch_one<5, 10, LCW_MAX3, 3>(ra, d.batch, rh.lds_bytes, st);
+    sco_set_error("rl_launch: unsupported tile");
+    return SCO_ERR_CAPACITY;
+  }
   if (rh.CW > LCW) {
     if (rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW_MAX>(ra, d.batch, rh.lds_bytes, st);
     if (rh.TR == 5 && rh.TC == 10) return rl_launch_one<5, 10, LCW_MAX>(ra, d.batch, rh.lds_bytes, st);

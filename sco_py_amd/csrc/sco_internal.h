@@ -123,12 +123,13 @@ struct RlHost {
   int pcw = 0;                     // most P entries in a core variable's column (<= 4: cached in LDS for the termination test)
   int zpos = 0;                    // LDS position of the always-zero pair of the row vectors
   bool merged = false;             // closed thread assignment: phases (Y) and (1) share a wavefront, one barrier less per iteration
-  SellHost Ac, Ar0, Ar1;
+  int NS = 2;                      // row slots per thread (3: patterns with more than 1024 rows)
+  SellHost Ac, Ar[3];
   size_t lds_bytes = 0;
   std::vector<unsigned short> off;
   std::vector<int> role, pc_ptr, pc_pos, pc_core;
 };
-struct RlDev { const unsigned short *off; const int *role, *srcAc, *srcAr0, *srcAr1, *pc_ptr, *pc_pos, *pc_core; };
+struct RlDev { const unsigned short *off; const int *role, *srcAc, *srcAr[3], *pc_ptr, *pc_pos, *pc_core; };
 bool rl_plan_build(const QpPlan &pl, RlHost &rh);
 int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd);
 int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t st);

@@ -106,3 +106,33 @@ def test_malformed_patterns_are_rejected():
     ok_rows = np.array([0, 1, 0], dtype=np.int32)
     assert lib.sco_debug_plan_build(2, 2, ip(Pp), ip(lower), ip(Ap), ip(ok_rows), 1, ip(sizes)) != 0
     assert lib.sco_debug_plan_build(2, 2, ip(Pp), ip(Pi), ip(Ap), ip(ok_rows), 1, ip(sizes)) == 0
+
+
+@pytest.mark.parametrize("name,kw,cw", [
+    ("circles", {}, 12), ("objective terms", dict(ee_cost_weight=1.0), 12),
+    ("reach", dict(reach=True), 16), ("velocity limits", dict(vel_limit=0.3), 16),
+    ("joint limits", dict(joint_limit=0.2), 16),
+    ("velocity + joint limits", dict(vel_limit=0.3, joint_limit=0.2), 20),
+    ("reach + velocity limits", dict(reach=True, vel_limit=0.3), 20)])
+def test_which_device_families_land_on_the_row_local_tier(name, kw, cw):
+    """Host-side plan of the fastest ADMM tier (csrc/sco_admm_rl.hip: rl_plan_build) for the penalty QP of every device
+    family at 7-DOF x 20: gather-dots take operands in aligned pairs; CW = 12: a column <= 6 pairs, a row <= 4, two row
+    slots per thread; 16 (wide): 8 / 5; 20: the three-slot instantiation (10 / 5, up to 1536 rows) that velocity + joint
+    limits (1100 rows) and reach + velocity limits (9 pairs in a column) need."""
+    fits = True
+    from oracle import arm_family as af
+    from oracle import sco_ref as sr
+    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(0, **kw)), sr.SolverParams(max_qp_solves=2), record_qps=True)
+    q = out.qps[1]
+    P = sp.triu(sp.csc_matrix(q["P"] != 0), format="csc"); A = sp.csc_matrix(q["A"] != 0)
+    P.sort_indices(); A.sort_indices()
+    lib = _lib.load()
+    ip = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int))
+    Pp, Pi, Ap, Ai = (np.ascontiguousarray(a, dtype=np.int32) for a in (P.indptr, P.indices, A.indptr, A.indices))
+    sizes = np.zeros(16, dtype=np.int32); info = np.zeros(8, dtype=np.int32)
+    lib.sco_debug_plan_build.argtypes = [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4 + [C.c_int, C.POINTER(C.c_int)]
+    lib.sco_debug_rl_plan.argtypes = [C.POINTER(C.c_int)]
+    assert lib.sco_debug_plan_build(len(q["q"]), len(q["l"]), ip(Pp), ip(Pi), ip(Ap), ip(Ai), 1, ip(sizes)) == 0
+    assert lib.sco_debug_rl_plan(ip(info)) == 0
+    assert bool(info[0]) == fits, (name, info)
+    assert info[1] == cw and info[2] == 5 and info[4] + 40 * 1024 <= 160 * 1024

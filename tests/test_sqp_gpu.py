@@ -546,7 +546,8 @@ def test_joint_limits_7x20_batch_and_validation(gpu):
     arrays, probs = af.make_batch(4, joint_limit=0.2)
     res = sb.solve_batch(arrays)
     _compare(res, probs, range(2))
-    arrays, probs = af.make_batch(2, joint_limit=0.2, vel_limit=0.3)        # 18 rows per column: beyond the row-local tier
+    # 1100 rows, 9 operand pairs per column: the three-row-slot instantiation of the row-local tier (r02)
+    arrays, probs = af.make_batch(2, joint_limit=0.2, vel_limit=0.3)
     _compare(sb.solve_batch(arrays), probs, range(1))
     with sb.TrajOptBatch(1, 3, 6, 2, 2, joint_limits=True) as tb:
         a = af.make_batch(1, d=3, T=6, K=2, O=2, joint_limit=0.5)[0]
