@@ -37,7 +37,8 @@
 #define RL_ABLATE 0
 #endif
 // experiment switches of diagnostic builds (scripts/build_ablate.py --variant): 1 static priority for wavefronts 4-7,
-// 2 register pin on the packed offsets (the r01 form), 4 unpadded right-hand side, 8 eight iterations per loop trip
+// 2 register pin on the packed offsets (the r01 form), 4 unpadded right-hand side, 8 eight iterations per loop trip,
+// 16 no termination test (the loop structure around it stays), 32 the checked iteration writes no test scratch
 #ifndef RL_VARIANT
 #define RL_VARIANT 0
 #endif
@@ -397,6 +398,7 @@ struct RlArgs {
   const unsigned short *off; const int *role;
   const int *srcAc, *srcAr[LNS_MAX], *pc_ptr, *pc_pos, *pc_core;
   int pcw;           // most P entries in a core column; <= 4: the termination test reads them from LDS
+  int zpos;          // LDS position of the always-zero pair of the row vectors
   int totAc, totAr[LNS_MAX];
   const double *As, *W, *qs, *kee_inv, *ls, *us, *rho, *cscale, *Ps, *D, *E;
   const int *w, *active;
@@ -472,24 +474,53 @@ __device__ __forceinline__ double rl_rowmax15(double v) {        // maximum of a
 #undef RL_ROW_MAX
   return v;
 }
-__device__ __forceinline__ void lblock_max6(double (&v)[6], double *red) {
+__device__ __forceinline__ double rl_sum32(double a, double b) {
+  const rl_uint2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const rl_uint2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double rl_sum16(double a, double b) {
+  const rl_uint2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const rl_uint2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+// one step of a scan inside the DPP rows: v op (v shifted right by the row_shr control), lanes without a source keep v
+#define RL_ROW_STEP_MAX(v, ctrl)                                                             \
+  { const int lo_ = __double2loint(v), hi_ = __double2hiint(v);                              \
+    v = fmax(v, __hiloint2double(__builtin_amdgcn_update_dpp(hi_, hi_, ctrl, 0xf, 0xf, false),   \
+                                 __builtin_amdgcn_update_dpp(lo_, lo_, ctrl, 0xf, 0xf, false))); }
+#define RL_ROW_STEP_ADD(v, ctrl)                                                             \
+  { const int lo_ = __double2loint(v), hi_ = __double2hiint(v);                              \
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi_, ctrl, 0xf, 0xf, true),         \
+                          __builtin_amdgcn_update_dpp(0, lo_, ctrl, 0xf, 0xf, true)); }
+__device__ __forceinline__ double rl_bcast_lane(double v, int lane) {      // lane: compile-time constant
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// Block reduction of the termination test: maxima of v[0..5] and sums of v[6], v[7] over the workgroup, result in
+// every thread.  Inside a wavefront the lane-swap folds of the W reduction (fmax is idempotent, so an odd value folds
+// with itself; a sum folds with zero): after them lane 15 of DPP row r holds  t0: v0, v2, v1, v3 (r = 0..3),
+// t1: v4 (r = 0, 1), v5 (r = 2, 3),  t2: v6 (r = 0), v7 (r = 2).  Across the wavefronts: the eight partial results of
+// value k sit in red[8 k .. 8 k + 7], ONE 8-byte read per lane fetches all 64, three row_shr steps combine the eight
+// of a value in lane 8 k + 7 and v_readlane hands it to every lane.  (r02: every thread used to read all 48 partial
+// results back: 24 KB of LDS reads per wavefront, 1.5 k cycles of a 6.4 k-cycle test.)  Fixed association order.
+__device__ __forceinline__ void lblock_max6_sum2(double (&v)[8], double *red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const double u0 = rl_fmax32(v[0], v[1]), u1 = rl_fmax32(v[2], v[3]), u2 = rl_fmax32(v[4], v[5]);
+  const double u0 = rl_fmax32(v[0], v[1]), u1 = rl_fmax32(v[2], v[3]), u2 = rl_fmax32(v[4], v[5]), u3 = rl_sum32(v[6], v[7]);
   const double t0 = rl_rowmax15(rl_fmax16(u0, u1)), t1 = rl_rowmax15(rl_fmax16(u2, u2));
+  double t2 = rl_sum16(u3, 0.0);
+  RL_ROW_STEP_ADD(t2, 0x111) RL_ROW_STEP_ADD(t2, 0x112) RL_ROW_STEP_ADD(t2, 0x114) RL_ROW_STEP_ADD(t2, 0x118)
   __syncthreads();
   if ((lane & 15) == 15) {
     const int r = lane >> 4;
-    red[wv * 6 + (r == 0 ? 0 : r == 1 ? 2 : r == 2 ? 1 : 3)] = t0;
-    if ((r & 1) == 0) red[wv * 6 + 4 + (r >> 1)] = t1;
+    red[8 * (r == 0 ? 0 : r == 1 ? 2 : r == 2 ? 1 : 3) + wv] = t0;
+    if ((r & 1) == 0) { red[8 * (4 + (r >> 1)) + wv] = t1; red[8 * (6 + (r >> 1)) + wv] = t2; }
   }
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    double r = red[k];
-#pragma unroll
-    for (int w = 1; w < LWV; w++) r = fmax(r, red[w * 6 + k]);
-    v[k] = r;
-  }
+  double mx = red[lane], sm = mx;
+  RL_ROW_STEP_MAX(mx, 0x111) RL_ROW_STEP_MAX(mx, 0x112) RL_ROW_STEP_MAX(mx, 0x114)
+  RL_ROW_STEP_ADD(sm, 0x111) RL_ROW_STEP_ADD(sm, 0x112) RL_ROW_STEP_ADD(sm, 0x114)
+  v[0] = rl_bcast_lane(mx, 7); v[1] = rl_bcast_lane(mx, 15); v[2] = rl_bcast_lane(mx, 23); v[3] = rl_bcast_lane(mx, 31);
+  v[4] = rl_bcast_lane(mx, 39); v[5] = rl_bcast_lane(mx, 47); v[6] = rl_bcast_lane(sm, 55); v[7] = rl_bcast_lane(sm, 63);
 }
 
 template <int NR, bool IS_MAX>
@@ -734,12 +765,16 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       s_pci[k * LCAP_NC + cown] = on ? a.pc_core[t0 + k] : n_c;
     }
   }
+  if (tid < 4) { s_pcv[tid * LCAP_NC + n_c] = 0.0; s_pci[tid * LCAP_NC + n_c] = n_c; }     // the zero column: threads without a core variable
   for (int i = tid; i < LCAP_M; i += LT) s_tv[i] = 0.0;
   for (int i = tid; i < LCAP_NC; i += LT) s_xc[i] = 0.0;
   for (int i = tid; i < LCAP_NC + 16; i += LT) s_rv[i] = 0.0;
   for (int i = tid; i < 2 * LCAP_M + 2 * LCAP_NC; i += LT) s_chk[i] = 0.0;
   __syncthreads();
   const double cscale = a.cscale[b];
+  // 1 / c for the termination test, formed once and kept in scalar registers (wave-uniform)
+  const double cinv_v = 1.0 / cscale;
+  const double cinv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(cinv_v)), __builtin_amdgcn_readfirstlane(__double2loint(cinv_v)));
   const double alpha = a.alpha, sigma = a.sigma;
   const bool merged = a.merged != 0;
   const int it0 = a.slice > 0 ? a.prog[b] : 0;
@@ -915,80 +950,84 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     while (iter + 8 < next) { iter += 8; step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); }
     while (iter + 4 < next) { iter += 4; step(false); step(false); step(false); step(false); }
     while (iter + 1 < next) { iter++; step(false); }
-    iter++; step(true);
+    iter++; if (RL_VARIANT & 32) step(false); else step(true);
     {
       // ---- termination test (formulas of admm_check in sco_qp.hip) ---------------------
       CSTAMP0
       const bool adapt_pt = ADAPT && iter % a.ad_interval == 0 && iter < a.max_iter;
       double vs[7] = {0, 0, 0, 0, 0, 0, 0};       // ADAPT: the same norms of the SCALED iterates
-      for (int approximate = 0; approximate < 2 && !status; approximate++) {
+      for (int approximate = 0; approximate < 2 && !status && !(RL_VARIANT & 16); approximate++) {
         if (approximate && iter < a.max_iter) break;
         const double *Ps = a.Ps + (size_t)b * a.nnzP;
         const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
-        const double cinv = 1.0 / cscale;
         double ea = a.eps_abs, er = a.eps_rel, epi = a.eps_prim_inf, edi = a.eps_dual_inf;
         if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
-        double v[7] = {0, 0, 0, 0, 0, 0, 0};
+        // Branch-free: a slot without a row has a_e = z = y = 0, zero gather offsets and scaling 1, a thread without a
+        // core / eliminated variable has x = q = 0, scaling 1 and the zero entries of the P table, so every term below is
+        // an exact zero there (r02: the predicated form spent 180 of its 730 instructions on 64-bit register moves).
+        // |c x| = c |x| and max(c a, c b) = c max(a, b) hold exactly for c > 0, so the pairs of norms that the tolerances
+        // only use through their maximum are formed with one multiplication.
+        double w4[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double dyp[NS];
         {
           double axc[NS];
 #pragma unroll
           for (int q = 0; q < NS; q++) axc[q] = rl_dot_row(wr[q], vr[q], ro[q], sxc);
+          CSTAMP(0)
 #pragma unroll
-          for (int q = 0; q < NS; q++)
-            if (r_p[q] >= 0) {
-              const double ax = axc[q] + r_ae[q] * xe;
-              const double ei = s_cst[(CS_RE + q) * LT + tid];
-              v[0] = fmax(v[0], fabs(ei * (ax - r_z[q])));
-              v[1] = fmax(v[1], fabs(ei * r_z[q]));
-              v[2] = fmax(v[2], fabs(ei * ax));
-              if (ADAPT && adapt_pt) {
-                vs[0] = fmax(vs[0], fabs(ax - r_z[q])); vs[1] = fmax(vs[1], fabs(r_z[q])); vs[2] = fmax(vs[2], fabs(ax));
-              }
+          for (int q = 0; q < NS; q++) {
+            const double ax = axc[q] + r_ae[q] * xe;
+            const double ei = s_cst[(CS_RE + q) * LT + tid];
+            w4[0] = fmax(w4[0], ei * fabs(ax - r_z[q]));
+            w4[1] = fmax(w4[1], ei * fmax(fabs(r_z[q]), fabs(ax)));
+            if (ADAPT && adapt_pt) {
+              vs[0] = fmax(vs[0], fabs(ax - r_z[q])); vs[1] = fmax(vs[1], fabs(r_z[q])); vs[2] = fmax(vs[2], fabs(ax));
             }
+            // dy clipped to the cone of the bounds (a slot without a row reads the always-zero position)
+            const double dy0 = sdy[r_p[q] >= 0 ? r_p[q] : a.zpos];
+            const double dy1 = r_us[q] > SCO_INFTY * SCO_MIN_SCALING ? fmin(dy0, 0.0) : dy0;
+            const double dy = r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING ? fmax(dy1, 0.0) : dy1;
+            dyp[q] = dy;
+            w4[4] = fmax(w4[4], s_cst[(CS_E + q) * LT + tid] * fabs(dy));
+            w4[6] += r_w[q] * (r_us[q] * fmax(dy, 0.0) + r_ls[q] * fmin(dy, 0.0));
+          }
         }
         const double aty_c = rl_dot_col<CW>(wcol, vcol, co, swy);     // whole wave: the trip count is wave-uniform
-        if (cown >= 0) {
-          const double aty = aty_c;
+        CSTAMP(1)
+        {
+          const int cix = cown >= 0 ? cown : n_c;        // the table's zero column
           double px = 0.0;
           if (a.pcw <= 4) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) px += s_pcv[k * LCAP_NC + cown] * sxc[s_pci[k * LCAP_NC + cown]];
-          } else {
+            for (int k = 0; k < 4; k++) px += s_pcv[k * LCAP_NC + cix] * sxc[s_pci[k * LCAP_NC + cix]];
+          } else if (cown >= 0) {
             for (int t = a.pc_ptr[cown]; t < a.pc_ptr[cown + 1]; t++) px += Ps[a.pc_pos[t]] * sxc[a.pc_core[t]];
           }
           const double dj = s_cst[CS_RDC * LT + tid];
-          v[3] = fabs(dj * (qc + px + aty)); v[4] = fabs(dj * qc); v[5] = fabs(dj * aty); v[6] = fabs(dj * px);
-          if (ADAPT && adapt_pt) { vs[3] = fabs(qc + px + aty); vs[4] = fabs(qc); vs[5] = fabs(aty); vs[6] = fabs(px); }
+          w4[2] = dj * fabs(qc + px + aty_c);
+          w4[3] = dj * fmax(fabs(qc), fmax(fabs(aty_c), fabs(px)));
+          if (ADAPT && adapt_pt) { vs[3] = fabs(qc + px + aty_c); vs[4] = fabs(qc); vs[5] = fabs(aty_c); vs[6] = fabs(px); }
         }
-        if (eown >= 0) {
+        {
           const double px = s_cst[CS_PEE * LT + tid] * xe;
           const double aty = r_ae[0] * (r_w[0] * r_y[0]) + r_ae[1] * (r_w[1] * r_y[1]);
           const double dj = s_cst[CS_RDE * LT + tid];
-          v[3] = fmax(v[3], fabs(dj * (qe + px + aty))); v[4] = fmax(v[4], fabs(dj * qe));
-          v[5] = fmax(v[5], fabs(dj * aty)); v[6] = fmax(v[6], fabs(dj * px));
+          w4[2] = fmax(w4[2], dj * fabs(qe + px + aty));
+          w4[3] = fmax(w4[3], dj * fmax(fabs(qe), fmax(fabs(aty), fabs(px))));
           if (ADAPT && adapt_pt) {
             vs[3] = fmax(vs[3], fabs(qe + px + aty)); vs[4] = fmax(vs[4], fabs(qe));
             vs[5] = fmax(vs[5], fabs(aty)); vs[6] = fmax(vs[6], fabs(px));
           }
         }
-        CSTAMP(0)
-        // the tolerances only need max(|z|, |Ax|) and max(|q|, |A'y|, |Px|): four maxima instead of seven.  The norms
-        // that open the two infeasibility tests, |E dy| (dy clipped to the cone of the bounds) and |D dx|, ride along:
-        // one six-value block reduction (two barriers) instead of three reductions on an unconverged iterate.
-        double w4[6] = {v[0], fmax(v[1], v[2]), v[3], fmax(v[4], fmax(v[5], v[6])), 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < NS; q++)
-          if (r_p[q] >= 0) {
-            double dy = sdy[r_p[q]];
-            if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
-              if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
-            } else if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
-            w4[4] = fmax(w4[4], fabs(s_cst[(CS_E + q) * LT + tid] * dy));
-          }
-        if (cown >= 0) w4[5] = fabs(s_cst[CS_DC * LT + tid] * dxc);
-        if (eown >= 0) w4[5] = fmax(w4[5], fabs(s_cst[CS_DE * LT + tid] * dxe));
-        lblock_max6(w4, s_red);
-        CSTAMP(1)
+        CSTAMP(2)
+        // Everything that opens the two infeasibility tests rides along in the same block reduction (two barriers in
+        // all): the norms |E dy| and |D dx| and the two sums u' dy+ + l' dy- and q' dx.  On an unconverged iterate the
+        // test used to make three reductions one after the other.
+        w4[5] = fmax(s_cst[CS_DC * LT + tid] * fabs(dxc), s_cst[CS_DE * LT + tid] * fabs(dxe));
+        w4[7] = qc * dxc + qe * dxe;
+        CSTAMP(3)
+        lblock_max6_sum2(w4, s_red);
+        CSTAMP(4)
         pri = w4[0]; dua = cinv * w4[2];
         if (!(pri <= SCO_INFTY) || !(dua <= SCO_INFTY)) { status = SCO_QP_NON_CVX; break; }
         const double eps_p = ea + er * w4[1];
@@ -997,23 +1036,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
         if (prim_ok && dual_ok) { status = approximate ? SCO_QP_SOLVED_INACCURATE : SCO_QP_SOLVED; break; }
         if (!prim_ok) {            // primal infeasibility certificate from delta_y
           const double ndy = w4[4];
-          if (ndy > epi) {
-            double dyp[NS] = {};
-#pragma unroll
-            for (int q = 0; q < NS; q++)
-              if (r_p[q] >= 0) {
-                double dy = sdy[r_p[q]];
-                if (r_us[q] > SCO_INFTY * SCO_MIN_SCALING) {
-                  if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = 0.0; else dy = fmin(dy, 0.0);
-                } else if (r_ls[q] < -SCO_INFTY * SCO_MIN_SCALING) dy = fmax(dy, 0.0);
-                dyp[q] = dy;
-              }
-            double lhs[1] = {0.0};
-#pragma unroll
-            for (int q = 0; q < NS; q++)
-              if (r_p[q] >= 0) lhs[0] += r_w[q] * (r_us[q] * fmax(dyp[q], 0.0) + r_ls[q] * fmin(dyp[q], 0.0));
-            lblock_reduce<1, false>(lhs, s_red);
-            if (lhs[0] < -epi * ndy) {
+          if (ndy > epi && w4[6] < -epi * ndy) {
+            {
               __syncthreads();
 #pragma unroll
               for (int q = 0; q < NS; q++) if (r_p[q] >= 0) swy[r_p[q]] = r_w[q] * dyp[q];
@@ -1032,15 +1056,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
             }
           }
         }
-        CSTAMP(2)
+        CSTAMP(5)
         if (!dual_ok) {            // dual infeasibility certificate from delta_x
           const double ndx = w4[5];
           if (ndx > edi) {
-            double qdx[1] = {0.0};
-            if (cown >= 0) qdx[0] = qc * dxc;
-            if (eown >= 0) qdx[0] += qe * dxe;
-            lblock_reduce<1, false>(qdx, s_red);
-            if (qdx[0] < -cscale * edi * ndx) {
+            if (w4[7] < -cscale * edi * ndx) {
               double npx[1] = {0.0};
               if (cown >= 0) {
                 double px = 0.0;
@@ -1071,9 +1091,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           }
         }
       }
-      CSTAMP(3)
       __syncthreads();
-      CSTAMP(4)
+      CSTAMP(6)
       if (ADAPT && adapt_pt && !status) {
         // OSQP's rho estimate (compute_rho_estimate / adapt_rho of osqp 0.6, as recalled; oracle/osqp_ref.c)
         lblock_reduce<7, true>(vs, s_red);
@@ -1193,7 +1212,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.eps_prim_inf = a.eps_prim_inf; ra.eps_dual_inf = a.eps_dual_inf;
   ra.off = rd.off; ra.role = rd.role; ra.srcAc = rd.srcAc;
   for (int q = 0; q < LNS_MAX; q++) { ra.srcAr[q] = rd.srcAr[q]; ra.totAr[q] = q < rh.NS ? rh.Ar[q].total : 0; }
-  ra.pc_ptr = rd.pc_ptr; ra.pc_pos = rd.pc_pos; ra.pc_core = rd.pc_core; ra.pcw = rh.pcw;
+  ra.pc_ptr = rd.pc_ptr; ra.pc_pos = rd.pc_pos; ra.pc_core = rd.pc_core; ra.pcw = rh.pcw; ra.zpos = rh.zpos;
   ra.totAc = rh.Ac.total;
   ra.As = d.As; ra.W = d.W; ra.qs = d.qs; ra.kee_inv = d.kee_inv; ra.ls = d.ls; ra.us = d.us; ra.rho = d.rho;
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;

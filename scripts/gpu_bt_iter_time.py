@@ -7,7 +7,7 @@ from oracle import arm_family as af
 from sco_py_amd import batch as sb, _lib
 one, _ = af.make_batch(1, d=12, T=50, K=10, O=10)
 IT = 4000
-for B in (1, 8, 16, 32, 64, 128, 256):
+for B in [int(v) for v in os.environ.get("BS", "1,8,16,32,64,128,256").split(",")]:
     arrays = dict(one); arrays["B"] = B
     for k in ("x0", "start", "goal", "link_len", "obstacles"):
         arrays[k] = np.repeat(one[k], B, axis=0)
