@@ -284,9 +284,13 @@ def main():
                 arrays["point_frac"], arrays["obstacles"])          # inputs resident in HBM from here on
         for _ in range(warmup):
             sd.solve_sharded(tb, total, params, qs)
+        # the interpreter's cyclic collector walks every object torch has imported (a full pass took 40-75 ms in the
+        # middle of a step, scripts/experiments/host_overhead.py): park what exists now in the permanent generation
+        import gc
+        gc.collect(); gc.freeze()
         sync()
         t0 = time.perf_counter()
-        sco_iters = 0; admm_ms = 0.0; qp_launches = 0
+        sco_iters = 0; admm_ms = 0.0; qp_launches = 0; groups = 1
         stage_ms = np.zeros(5)
         for _ in range(steps):
             res, allrec = sd.solve_sharded(tb, total, params, qs)   # solve the shard + RCCL all-gather of 24 B/problem (no-op at N = 1)
@@ -294,7 +298,8 @@ def main():
             tm = tb.last_timing()                                  # HIP-event sums of the step just finished, taken on the library's stream
             stage_ms += [tm["convexify_ms"], tm["qp_setup_ms"], tm["admm_ms"], tm["decide_ms"], tm["total_ms"]]
             admm_ms += tm["admm_ms"]
-            qp_launches += tm["rounds"] - 1                       # penalty-QP launches (the projection launch is tiny)
+            qp_launches += tm["launches"]                         # penalty-QP launches over all stream groups (the projection launch is tiny)
+            groups = tm["groups"]
         sync()
         elapsed = time.perf_counter() - t0
         # bookkeeping outside the timed region: every step solves the same loaded problems and the solve is
@@ -309,7 +314,7 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         return dict(dims=dims, B=B, total=total, steps=steps, elapsed=elapsed, sco_iters=sco_iters, admm_ms=admm_ms,
-                    qp_launches=qp_launches, stage_ms=stage_ms / steps, it_proj=it_proj, it_pen=it_pen, qp_solves=qp_solves,
+                    qp_launches=qp_launches, groups=groups, stage_ms=stage_ms / steps, it_proj=it_proj, it_pen=it_pen, qp_solves=qp_solves,
                     success=float(np.mean(allrec["success"] != 0)))
 
     def roofline(r, big):
@@ -398,6 +403,7 @@ def main():
                                                   r["stage_ms"].round(3).tolist())),
                     "success_fraction": r["success"],
                     "admm_launches_per_step": r["qp_launches"] / args.steps,
+                    "stream_groups": r["groups"],
                     "kernel_src_sha": kernel_src_sha()},
             "roofline": roofline(r, big),
         }

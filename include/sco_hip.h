@@ -278,8 +278,13 @@ int sco_sqp_fetch(sco_sqp *h, double *x, int *success, int *sqp_iters, int *qp_s
 #define SCO_SQP_FLAG_TRACE_FULL 4  /* more decisions than sco_sqp_trace keeps (64)                              */
 int sco_sqp_fetch_flags(sco_sqp *h, int *flags);
 /* Number of device rounds (pre -> QP setup -> ADMM launch -> post) of the last solve, the projection round
- * included; with time slicing one QP spans several rounds. */
+ * included; with time slicing one QP spans several rounds.  A large batch is cut into stream groups whose rounds
+ * run side by side (scheduling only, results unchanged; SCO_SQP_GROUPS=1 in the environment keeps one group):
+ * `rounds` counts the group that needed most. */
 int sco_sqp_last_rounds(const sco_sqp *h, int *rounds);
+/* Round launches of the last solve summed over its stream groups (projection round excluded), and the number of
+ * groups it used (either pointer may be null). */
+int sco_sqp_last_launches(const sco_sqp *h, int *launches, int *groups);
 
 /* Per-problem decision trace of the last solve, for stage-wise parity checks:
  * trace[batch][cap][8] = {kind, merit, model_merit, new_merit, trust, penalty,

@@ -172,8 +172,11 @@ class TrajOptBatch(object):
         _lib.check(_lib.load().sco_sqp_last_timing(self._h, _lib.dptr(ms)))
         rounds = C.c_int(0)
         _lib.check(_lib.load().sco_sqp_last_rounds(self._h, C.byref(rounds)))
+        launches, groups = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.load().sco_sqp_last_launches(self._h, C.byref(launches), C.byref(groups)))
         return dict(convexify_ms=float(ms[0]), qp_setup_ms=float(ms[1]), admm_ms=float(ms[2]),
-                    decide_ms=float(ms[3]), total_ms=float(ms[4]), rounds=int(rounds.value))
+                    decide_ms=float(ms[3]), total_ms=float(ms[4]), rounds=int(rounds.value),
+                    launches=int(launches.value), groups=int(groups.value))
 
 
 def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_jac=False, prox_count=2):

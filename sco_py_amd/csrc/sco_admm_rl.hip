@@ -394,6 +394,7 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
 // --------------------------------------------------------------------------
 struct RlArgs {
   int n, m, n_e, n_c, nnzA, nnzP, max_iter, check;
+  int b0;            // launch window: workgroup g solves problem b0 + g
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   const unsigned short *off; const int *role;
   const int *srcAc, *srcAr[LNS_MAX], *pc_ptr, *pc_pos, *pc_core;
@@ -635,7 +636,7 @@ __device__ __forceinline__ int rl_tile_row(int n, int h) { return 4 * n + 2 * (h
 
 template <int TR, int TC, int CW, bool ADAPT, int NS = 2>
 __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x + a.b0, tid = threadIdx.x;
   if (a.active && !a.active[b]) return;
   const int n = a.n, m = a.m, n_e = a.n_e, n_c = a.n_c;
 
@@ -1207,7 +1208,8 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   const QpDev &d = a.d;
   RlArgs ra;
   ra.n = d.n; ra.m = d.m; ra.n_e = d.n_e; ra.n_c = d.n_c; ra.nnzA = d.nnzA; ra.nnzP = d.nnzP;
-  ra.max_iter = a.max_iter; ra.check = a.check;
+  ra.max_iter = a.max_iter; ra.check = a.check; ra.b0 = d.b0;
+  const int nwg = d.nb > 0 ? d.nb : d.batch;
   ra.sigma = a.sigma; ra.alpha = a.alpha; ra.eps_abs = a.eps_abs; ra.eps_rel = a.eps_rel;
   ra.eps_prim_inf = a.eps_prim_inf; ra.eps_dual_inf = a.eps_dual_inf;
   ra.off = rd.off; ra.role = rd.role; ra.srcAc = rd.srcAc;
@@ -1232,24 +1234,24 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
 #endif
   if (rh.NS == 3) {
     // three row slots per thread and ten operand pairs per column (velocity + joint limits at 7-DOF x 20: 1100 rows)
-    if (rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW_MAX3, 3>(ra, d.batch, rh.lds_bytes, st);
-    if (rh.TR == 5 && rh.TC == 10) return rl_launch_one<5, 10, LCW_MAX3, 3>(ra, d.batch, rh.lds_bytes, st);
+    if (rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW_MAX3, 3>(ra, nwg, rh.lds_bytes, st);
+    if (rh.TR == 5 && rh.TC == 10) return rl_launch_one<5, 10, LCW_MAX3, 3>(ra, nwg, rh.lds_bytes, st);
     sco_set_error("rl_launch: unsupported tile");
     return SCO_ERR_CAPACITY;
   }
   if (rh.CW > LCW) {
-    if (rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW_MAX>(ra, d.batch, rh.lds_bytes, st);
-    if (rh.TR == 5 && rh.TC == 10) return rl_launch_one<5, 10, LCW_MAX>(ra, d.batch, rh.lds_bytes, st);
+    if (rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW_MAX>(ra, nwg, rh.lds_bytes, st);
+    if (rh.TR == 5 && rh.TC == 10) return rl_launch_one<5, 10, LCW_MAX>(ra, nwg, rh.lds_bytes, st);
     sco_set_error("rl_launch: unsupported tile");
     return SCO_ERR_CAPACITY;
   }
   switch (rh.TR * 100 + rh.TC) {
-    case 102: return rl_launch_one<1, 2>(ra, d.batch, rh.lds_bytes, st);
-    case 204: return rl_launch_one<2, 4>(ra, d.batch, rh.lds_bytes, st);
-    case 306: return rl_launch_one<3, 6>(ra, d.batch, rh.lds_bytes, st);
-    case 408: return rl_launch_one<4, 8>(ra, d.batch, rh.lds_bytes, st);
-    case 509: return rl_launch_one<5, 9>(ra, d.batch, rh.lds_bytes, st);
-    case 510: return rl_launch_one<5, 10>(ra, d.batch, rh.lds_bytes, st);
+    case 102: return rl_launch_one<1, 2>(ra, nwg, rh.lds_bytes, st);
+    case 204: return rl_launch_one<2, 4>(ra, nwg, rh.lds_bytes, st);
+    case 306: return rl_launch_one<3, 6>(ra, nwg, rh.lds_bytes, st);
+    case 408: return rl_launch_one<4, 8>(ra, nwg, rh.lds_bytes, st);
+    case 509: return rl_launch_one<5, 9>(ra, nwg, rh.lds_bytes, st);
+    case 510: return rl_launch_one<5, 10>(ra, nwg, rh.lds_bytes, st);
   }
   sco_set_error("rl_launch: unsupported tile");
   return SCO_ERR_CAPACITY;

@@ -47,6 +47,9 @@ struct ScoDeviceGuard {
 // Device-side view of one batched QP: plans (shared) + per-problem value arrays.
 struct QpDev {
   int n, m, nnzP, nnzA, n_e, n_c, ncpl, nS, batch;
+  // launch window (stream groups of the SQP loop): the kernels that honour it work on problem blockIdx.x + b0 and are
+  // launched with nb workgroups (nb = 0: the whole batch from problem 0)
+  int b0, nb;
   // shared index plans
   const int *Ap, *Ai, *Rp, *Rj, *Rpos, *Fp, *Fi, *Fpos, *Pdiag;
   const int *elim_var, *core_var, *elim_of, *core_of;
@@ -205,7 +208,11 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
 // QP (device array, or SCO_MASK_ALL / SCO_MASK_NONE); setup then also runs for parked problems whose rho changed.
 #define SCO_MASK_ALL ((const int *)(uintptr_t)1)
 #define SCO_MASK_NONE ((const int *)(uintptr_t)2)
+// `grp` (may be null): run only problems [b0, b0 + nb) and on grp->stream instead of the handle's own (stream groups of
+// the SQP loop; row-local tier with the Gauss-Jordan inversion only, see sco_qp_supports_groups)
+struct QpGroup { int b0, nb; hipStream_t stream; };
 int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
-                         int slice, hipEvent_t mid, int *sliced);
+                         int slice, hipEvent_t mid, int *sliced, const QpGroup *grp = nullptr);
+bool sco_qp_supports_groups(const sco_qp *qp, const sco_qp_settings *st);
 int sco_qp_adaptive_interval(const sco_qp_settings *st);
 bool sco_qp_can_adapt(const sco_qp *qp);   // false: this handle sits on the dense global-memory tier, which cannot park a solve

@@ -127,7 +127,7 @@ extern "C" int sco_debug_setup_stamps(double *out) {
 
 __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
   const QpDev &d = a.d;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x + a.d.b0, tid = threadIdx.x;
   if (d.active && !d.active[b]) return;
 #ifdef SCO_STAMP
   long long sst_t = __builtin_readcyclecounter();
@@ -441,7 +441,7 @@ __device__ __forceinline__ void sweep_update(double (&t)[NT][4][4], const int (&
 // registers per thread, a tile takes 32)
 template <int SCO_SWEEP_NT>
 __global__ __launch_bounds__(SCO_FACTOR_BLOCK) void qp_sweep_kernel(QpDev d) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x + d.b0, tid = threadIdx.x;
   if (d.active && !d.active[b]) return;
   const int n = d.n_c;
   if (n == 0) return;
@@ -1037,9 +1037,19 @@ int sco_qp_adaptive_interval(const sco_qp_settings *st) {
 
 bool sco_qp_can_adapt(const sco_qp *qp) { return !(qp->use_big && !qp->use_bt); }
 
+// Launch windows (QpGroup) exist for the path the headline workload takes: row-local ADMM kernel, Gauss-Jordan
+// inversion, fixed rho.
+bool sco_qp_supports_groups(const sco_qp *qp, const sco_qp_settings *st) {
+  return qp->use_rl && !qp->use_big && !qp->factor_cholesky && !st->adaptive_rho;
+}
+
 int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
-                         int slice, hipEvent_t mid, int *sliced) {
+                         int slice, hipEvent_t mid, int *sliced, const QpGroup *grp) {
   const bool adaptive = st->adaptive_rho != 0;
+  if (grp && (!sco_qp_supports_groups(qp, st) || grp->b0 < 0 || grp->nb <= 0 || grp->b0 + grp->nb > qp->d.batch)) {
+    sco_set_error("sco_qp_launch_sliced: launch window not supported by this handle's tier"); return SCO_ERR_STATE;
+  }
+  hipStream_t stream = grp ? grp->stream : qp->stream;
   if (adaptive) {
     if (qp->use_big && !qp->use_bt) {
       sco_set_error("adaptive_rho: the dense form of the global-memory tier cannot park a solve");
@@ -1063,57 +1073,59 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
   if (sliced) *sliced = slice;
   QpDev d = qp->d; d.active = active_dev;
   QpDev dsetup = qp->d; dsetup.active = adaptive ? qp->d.smask : setup_mask;
+  if (grp) { d.b0 = dsetup.b0 = grp->b0; d.nb = dsetup.nb = grp->nb; }
+  const int nwg = grp ? grp->nb : d.batch;          // workgroups of the per-problem kernels
   SetupArgs sa{dsetup, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling, adaptive ? 1 : 0};
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
               st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0, slice,
               adaptive ? 1 : 0, adaptive ? sco_qp_adaptive_interval(st) : 0, st->adaptive_rho_tolerance};
   qp->solved_once = true;
-  SCO_HIP(hipEventRecord(qp->ev[0], qp->stream));
+  if (!grp) SCO_HIP(hipEventRecord(qp->ev[0], stream));
   if (adaptive && setup_mask != SCO_MASK_NONE) {
     // the problems that start a QP get the initial rho and their setup flag (the parked ones keep what the ADMM
     // kernel left when it parked them)
     RhoInitArgs ra{d, setup_mask == SCO_MASK_ALL ? nullptr : setup_mask, setup_mask == SCO_MASK_ALL ? 1 : 0, st->rho};
-    hipLaunchKernelGGL(qp_rho_init_kernel, dim3((d.batch + 255) / 256), dim3(256), 0, qp->stream, ra);
+    hipLaunchKernelGGL(qp_rho_init_kernel, dim3((d.batch + 255) / 256), dim3(256), 0, stream, ra);
     SCO_HIP(hipGetLastError());
   }
   if (qp->use_big) {
     int r_ = big_launch(aa, dsetup.active, st->scaling, qp->Pp_dev, qp->Pi_dev, qp->big, qp->bigd,
-                        qp->use_bt ? &qp->bt : nullptr, qp->use_bt ? &qp->btd : nullptr, qp->stream, qp->ev[1], mid);
+                        qp->use_bt ? &qp->bt : nullptr, qp->use_bt ? &qp->btd : nullptr, stream, qp->ev[1], mid);
     if (r_) return r_;
-    SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
+    SCO_HIP(hipEventRecord(qp->ev[2], stream));
     return SCO_OK;
   }
   {
     // scaling + reduced matrix (256 threads, S into the W buffer), then factor + inverse (1024 threads)
     const size_t ntri = (size_t)d.n_c * (d.n_c + 1) / 2;
-    hipLaunchKernelGGL(qp_setup_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_setup - ntri * sizeof(double), qp->stream, sa);
+    hipLaunchKernelGGL(qp_setup_kernel, dim3(nwg), dim3(SCO_BLOCK), qp->lds_setup - ntri * sizeof(double), stream, sa);
     SCO_HIP(hipGetLastError());
     if (qp->factor_cholesky)
-      hipLaunchKernelGGL(qp_factor_kernel, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), (ntri + d.n_c) * sizeof(double), qp->stream, dsetup);
+      hipLaunchKernelGGL(qp_factor_kernel, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), (ntri + d.n_c) * sizeof(double), stream, dsetup);
     else {
       const int nb = (d.n_c + 3) / 4, ntiles = nb * (nb + 1) / 2;
-      if (ntiles <= SCO_FACTOR_BLOCK) hipLaunchKernelGGL(qp_sweep_kernel<1>, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), 0, qp->stream, dsetup);
-      else if (ntiles <= 2 * SCO_FACTOR_BLOCK) hipLaunchKernelGGL(qp_sweep_kernel<2>, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), 0, qp->stream, dsetup);
-      else hipLaunchKernelGGL(qp_sweep_kernel<3>, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), 0, qp->stream, dsetup);
+      if (ntiles <= SCO_FACTOR_BLOCK) hipLaunchKernelGGL(qp_sweep_kernel<1>, dim3(nwg), dim3(SCO_FACTOR_BLOCK), 0, stream, dsetup);
+      else if (ntiles <= 2 * SCO_FACTOR_BLOCK) hipLaunchKernelGGL(qp_sweep_kernel<2>, dim3(nwg), dim3(SCO_FACTOR_BLOCK), 0, stream, dsetup);
+      else hipLaunchKernelGGL(qp_sweep_kernel<3>, dim3(nwg), dim3(SCO_FACTOR_BLOCK), 0, stream, dsetup);
     }
     SCO_HIP(hipGetLastError());
   }
-  SCO_HIP(hipEventRecord(qp->ev[1], qp->stream));
-  if (mid) SCO_HIP(hipEventRecord(mid, qp->stream));
+  if (!grp) SCO_HIP(hipEventRecord(qp->ev[1], stream));
+  if (mid) SCO_HIP(hipEventRecord(mid, stream));
   if (kern == K_RL) {
-    int r_ = rl_launch(aa, qp->rl, qp->rld, qp->stream);
+    int r_ = rl_launch(aa, qp->rl, qp->rld, stream);
     if (r_) return r_;
   } else if (kern == K_REG) {
-    int r_ = reg_launch(aa, qp->reg, qp->regd, qp->stream);
+    int r_ = reg_launch(aa, qp->reg, qp->regd, stream);
     if (r_) return r_;
   } else if (kern == K_FAST) {
-    int r_ = fast_launch(aa, qp->fast, qp->fastd, qp->stream);
+    int r_ = fast_launch(aa, qp->fast, qp->fastd, stream);
     if (r_) return r_;
   } else {
-    hipLaunchKernelGGL(qp_admm_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_admm, qp->stream, aa);
+    hipLaunchKernelGGL(qp_admm_kernel, dim3(d.batch), dim3(SCO_BLOCK), qp->lds_admm, stream, aa);
     SCO_HIP(hipGetLastError());
   }
-  SCO_HIP(hipEventRecord(qp->ev[2], qp->stream));
+  if (!grp) SCO_HIP(hipEventRecord(qp->ev[2], stream));
   return SCO_OK;
 }
 

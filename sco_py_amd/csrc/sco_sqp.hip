@@ -27,6 +27,8 @@
 // counter per round.
 #include "sco_internal.h"
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +50,11 @@ struct SqpScalars {
   int flags;      // SCO_SQP_FLAG_*
 };
 
+#define SQP_MAX_GROUPS 4
+#define SQP_DEPTH 2        // rounds kept in flight per stream group
+
 struct SqpDev {
+  int b0;            // launch window of a stream group: workgroup g of the round kernels works on problem b0 + g
   int batch, d, T, K, O, R, n_x, n_slack, n, m_lin, m_nl, m, prox_count, analytic_jac, trace_cap;
   // SCO_FAM_ARM_REACH: NE = 2 equality rows (end-effector x, y) on the last timestep, block index T;
   // NB = number of constraint blocks (T or T + 1), RM = widest block (history strides)
@@ -97,11 +103,18 @@ struct sco_sqp {
   sco_qp *qp0 = nullptr, *qp1 = nullptr;
   SqpDev d{};
   hipStream_t stream = nullptr;
+  // stream groups of the round loop (sco_sqp_solve): group 0 runs on `stream`, group g > 0 on gstream[g - 1]
+  hipStream_t gstream[SQP_MAX_GROUPS - 1] = {};
+  std::vector<hipEvent_t> gevents[SQP_MAX_GROUPS], done;
+  double *fetch_buf = nullptr;       // [2][B] merit and max violation of sco_sqp_fetch
+  int *host_active = nullptr;        // pinned: [SQP_MAX_GROUPS][SQP_DEPTH] active counts read back per round
+  int groups_used = 1;
   std::vector<void *> allocs;
   std::vector<hipEvent_t> events;
   bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false, cost_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
-  int rounds = 0;
+  int rounds = 0;          // 1 (projection) + the rounds of the group that needed most
+  int launches = 0;        // round launches over all stream groups
 };
 
 // --------------------------------------------------------------------------
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
 // SQP iteration), then the trust-region bounds (for every active problem)
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, SqpParamsDev p) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x + s.b0, tid = threadIdx.x;
   SqpScalars &sc = s.sc[b];
   const int state = sc.state;
   // a problem whose QP is parked between two ADMM slices keeps its QP untouched
@@ -681,7 +694,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
 // sqp_post: model merit, new merit, decision
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1, SqpParamsDev p) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x + s.b0, tid = threadIdx.x;
   SqpScalars &sc = s.sc[b];
   if (sc.state != ST_TRIAL) return;
   if (q1.prog && q1.prog[b] > 0) {             // its QP is parked between two ADMM slices: nothing to decide yet
@@ -922,6 +935,12 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
 
 static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc) {
   SCO_HIP(hipStreamCreate(&h->stream));
+  SCO_HIP(hipHostMalloc((void **)&h->host_active, SQP_MAX_GROUPS * SQP_DEPTH * sizeof(int)));
+  {
+    void *fb = nullptr;
+    SCO_HIP(hipMalloc(&fb, 2 * (size_t)desc->batch * sizeof(double)));
+    h->allocs.push_back(fb); h->fetch_buf = (double *)fb;
+  }
   const int B = desc->batch, d = desc->dof, T = desc->horizon, K = desc->n_points, O = desc->n_obstacles;
   const bool reach = (desc->family & 15) == SCO_FAM_ARM_REACH, vel = (desc->family & SCO_FAM_FLAG_VEL_LIMITS) != 0;
   const bool jl = (desc->family & SCO_FAM_FLAG_JOINT_LIMITS) != 0, cost = (desc->family & SCO_FAM_FLAG_EE_COST) != 0;
@@ -1014,7 +1033,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2) AL(vmax, (size_t)B) AL(jlo, (size_t)B * d) AL(jhi, (size_t)B * d)
   AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
   AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
-  AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, 1) AL(newqp, (size_t)B)
+  AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, SQP_MAX_GROUPS) AL(newqp, (size_t)B)
   s.H = 40; s.HC = 24;
   AL(hkey, (size_t)B * s.NB * s.H * d) AL(hval, (size_t)B * s.NB * s.H * s.RM) AL(ckey, (size_t)B * s.NB * s.HC * d)
   AL(cJ, (size_t)B * s.NB * s.HC * s.RM * d) AL(cb, (size_t)B * s.NB * s.HC * s.RM) AL(hn, (size_t)B * s.NB)
@@ -1051,6 +1070,10 @@ extern "C" int sco_sqp_destroy(sco_sqp *h) {
   if (h->qp1) sco_qp_destroy(h->qp1);
   for (void *p : h->allocs) (void)hipFree(p);
   for (auto e : h->events) (void)hipEventDestroy(e);
+  for (auto &ge : h->gevents) for (auto e : ge) (void)hipEventDestroy(e);
+  for (auto e : h->done) (void)hipEventDestroy(e);
+  for (auto gs : h->gstream) if (gs) { (void)hipStreamSynchronize(gs); (void)hipStreamDestroy(gs); }
+  if (h->host_active) (void)hipHostFree(h->host_active);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return SCO_OK;
@@ -1272,37 +1295,143 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   long long slices_per_qp = slice_req > 0 ? (qsl.max_iter + slice_req - 1) / slice_req : 1;
   if (qsl.adaptive_rho) slices_per_qp += qsl.max_iter / sco_qp_adaptive_interval(&qsl) + 1;    // a launch per rho change at most
   const long long round_cap = ((long long)p.max_qp_solves + 8) * slices_per_qp;
-  while (n_active > 0 && h->rounds < round_cap) {
-    SCO_HIP(hipMemsetAsync(s.n_active, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(sqp_pre_kernel, grid, block, 0, h->stream, s, h->qp1->d, p);
-    SCO_HIP(hipGetLastError());
-    mark(0);
-    mid = next_event(h, ec); stage.push_back(1);
-    rc = sco_qp_launch_sliced(h->qp1, &qsl, s.newqp, s.active, slice_req, mid, nullptr);
-    if (rc) return rc;
-    mark(2);
-    hipLaunchKernelGGL(sqp_post_kernel, grid, block, 0, h->stream, s, h->qp1->d, p);
-    SCO_HIP(hipGetLastError());
-    mark(3);
-    SCO_HIP(hipMemcpyAsync(&n_active, s.n_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    SCO_HIP(hipStreamSynchronize(h->stream));
-    h->rounds++;
-    if (getenv("SCO_SQP_TRACE_ROUNDS") && (h->rounds < 40 || h->rounds % 100 == 0))
-      fprintf(stderr, "sco_sqp_solve: round %d, %d problems active\n", h->rounds, n_active);
+  // ---- stream groups.  A lock-step round costs ceil(active / CUs) passes of workgroups, so once problems start to
+  // finish the last pass of every round is partly empty (profiles/r02_launches.txt: 737 ms per step against 630 ms of
+  // work).  The batch is therefore cut into G contiguous groups that run their rounds independently on streams of
+  // their own: while one group's launch drains, the other's fills the free CUs, and SQP_DEPTH rounds per group are
+  // enqueued ahead so the device never waits for the host (a round of a group whose problems are all done is a few
+  // empty launches).  Per problem nothing changes: same kernels, same order, same results.
+  int G = 1;
+  {
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    const char *ge = getenv("SCO_SQP_GROUPS");
+    const int want = ge ? atoi(ge) : 2;
+    if (slice_req > 0 && sco_qp_supports_groups(h->qp1, &qsl) && cus > 0 && s.batch >= 2 * cus)
+      G = std::max(1, std::min(std::min(want, SQP_MAX_GROUPS), s.batch / cus));
   }
+  h->groups_used = G;
+  for (int g = 1; g < G; g++)
+    if (!h->gstream[g - 1]) SCO_HIP(hipStreamCreate(&h->gstream[g - 1]));
+  struct Group {
+    int b0 = 0, nb = 0; hipStream_t st = nullptr;
+    int issued = 0, retired = 0, last_active = 1;      // rounds enqueued / read back; active count of the last one read
+    size_t ec = 0; std::vector<int> stage;              // event cursor and stage ids (as for the main stream)
+    double ms[5] = {0, 0, 0, 0, 0};
+  } grp[SQP_MAX_GROUPS];
+  for (int g = 0; g < G; g++) {
+    grp[g].b0 = (int)((long long)s.batch * g / G); grp[g].nb = (int)((long long)s.batch * (g + 1) / G) - grp[g].b0;
+    grp[g].st = g == 0 ? h->stream : h->gstream[g - 1];
+  }
+  auto gevent = [&](int g) -> hipEvent_t {
+    Group &r = grp[g];
+    if (r.ec == h->gevents[g].size()) { hipEvent_t e; (void)hipEventCreate(&e); h->gevents[g].push_back(e); }
+    return h->gevents[g][r.ec++];
+  };
+  auto gmark = [&](int g, int st) { hipEvent_t e = gevent(g); (void)hipEventRecord(e, grp[g].st); grp[g].stage.push_back(st); };
+  std::vector<hipEvent_t> &done = h->done;          // per (group, slot): the round's read-back has landed
+  while (done.size() < (size_t)G * SQP_DEPTH) { hipEvent_t e; SCO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); done.push_back(e); }
+  auto enqueue_round = [&](int g) -> int {
+    Group &r = grp[g];
+    SqpDev sg = s; sg.b0 = r.b0; sg.n_active = s.n_active + g;
+    const QpGroup win{r.b0, r.nb, r.st};
+    if (r.issued == 0) gmark(g, -1);
+    SCO_HIP(hipMemsetAsync(sg.n_active, 0, sizeof(int), r.st));
+    hipLaunchKernelGGL(sqp_pre_kernel, dim3(r.nb), block, 0, r.st, sg, h->qp1->d, p);
+    SCO_HIP(hipGetLastError());
+    gmark(g, 0);
+    hipEvent_t gm = gevent(g); r.stage.push_back(1);
+    const int rc_ = sco_qp_launch_sliced(h->qp1, &qsl, s.newqp, s.active, slice_req, gm, nullptr, G > 1 ? &win : nullptr);
+    if (rc_) return rc_;
+    gmark(g, 2);
+    hipLaunchKernelGGL(sqp_post_kernel, dim3(r.nb), block, 0, r.st, sg, h->qp1->d, p);
+    SCO_HIP(hipGetLastError());
+    gmark(g, 3);
+    const int slot = r.issued % SQP_DEPTH;
+    SCO_HIP(hipMemcpyAsync(h->host_active + g * SQP_DEPTH + slot, sg.n_active, sizeof(int), hipMemcpyDeviceToHost, r.st));
+    SCO_HIP(hipEventRecord(done[(size_t)g * SQP_DEPTH + slot], r.st));
+    r.issued++;
+    return SCO_OK;
+  };
+  const int depth = SQP_DEPTH;
+  bool capped = false;
   if (n_active > 0) {
+    for (int k = 0; k < depth; k++)
+      for (int g = 0; g < G; g++)
+        if ((rc = enqueue_round(g))) return rc;
+    for (bool busy = true; busy;) {
+      busy = false;
+      for (int g = 0; g < G; g++) {
+        Group &r = grp[g];
+        if (r.retired == r.issued) continue;
+        busy = true;
+        const int slot = r.retired % SQP_DEPTH;
+        SCO_HIP(hipEventSynchronize(done[(size_t)g * SQP_DEPTH + slot]));
+        r.last_active = h->host_active[g * SQP_DEPTH + slot];
+        r.retired++;
+        if (getenv("SCO_SQP_TRACE_ROUNDS") && (r.retired < 40 || r.retired % 100 == 0))
+          fprintf(stderr, "sco_sqp_solve: group %d round %d, %d problems active\n", g, r.retired, r.last_active);
+        if (r.last_active > 0) {
+          if (r.issued + 1 < round_cap) { if ((rc = enqueue_round(g))) return rc; }
+          else if (r.retired == r.issued) capped = true;
+        }
+      }
+    }
+  }
+  {
+    int total_rounds = 0;
+    for (int g = 0; g < G; g++) total_rounds = std::max(total_rounds, grp[g].retired);
+    h->rounds = 1 + total_rounds;
+    h->launches = 0;
+    for (int g = 0; g < G; g++) h->launches += grp[g].retired;
+  }
+  if (capped) {
     // the launch cap ended the loop with problems still running (it is sized so that this cannot happen while every
     // problem respects max_sqp_iters): they are reported as capped failures, never silently as finished
     hipLaunchKernelGGL(sqp_cap_kernel, dim3((s.batch + SCO_BLOCK - 1) / SCO_BLOCK), block, 0, h->stream, s);
     SCO_HIP(hipGetLastError());
     SCO_HIP(hipStreamSynchronize(h->stream));
   }
-  // ---- timing: sum the event intervals by stage
+  // ---- timing: sum the event intervals by stage.  The rounds of different stream groups overlap, so their intervals
+  // are laid on one time axis (milliseconds after the first event of the call) and every instant is charged to ONE
+  // stage: the ADMM launch if any group is inside one, else QP setup, else convexify, else the decisions -- the ADMM
+  // figure is then the wall time during which at least one ADMM launch was resident or queued behind another group's,
+  // and the stages add up to the wall time of the call.
   double ms[5] = {0, 0, 0, 0, 0};
   for (size_t i = 1; i < ec; i++) {
     float t = 0; (void)hipEventElapsedTime(&t, h->events[i - 1], h->events[i]);
     if (stage[i] >= 0) ms[stage[i]] += t;
     ms[4] += t;
+  }
+  if (G == 1) {
+    Group &r = grp[0];
+    for (size_t i = 1; i < r.ec; i++) {
+      float t = 0; (void)hipEventElapsedTime(&t, h->gevents[0][i - 1], h->gevents[0][i]);
+      if (r.stage[i] >= 0) ms[r.stage[i]] += t;
+      ms[4] += t;
+    }
+  } else {
+    struct Edge { double t; int stage, d; };
+    std::vector<Edge> edges;
+    for (int g = 0; g < G; g++) {
+      Group &r = grp[g];
+      double prev = 0.0;
+      for (size_t i = 0; i < r.ec; i++) {
+        float t = 0; (void)hipEventElapsedTime(&t, h->events[0], h->gevents[g][i]);
+        if (i > 0 && r.stage[i] >= 0 && t > prev) { edges.push_back({prev, r.stage[i], 1}); edges.push_back({(double)t, r.stage[i], -1}); }
+        prev = t;
+      }
+    }
+    std::sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) { return x.t < y.t; });
+    int open_[4] = {0, 0, 0, 0};
+    const int prio[4] = {2, 1, 0, 3};
+    for (size_t i = 0; i + 1 <= edges.size(); i++) {
+      if (i > 0) {
+        const double dt = edges[i].t - edges[i - 1].t;
+        for (int k : prio) if (open_[k] > 0) { ms[k] += dt; ms[4] += dt; break; }
+      }
+      open_[edges[i].stage] += edges[i].d;
+    }
   }
   memcpy(h->last_ms, ms, sizeof ms);
   h->solved = true;
@@ -1325,15 +1454,13 @@ extern "C" int sco_sqp_fetch(sco_sqp *h, double *x, int *success, int *sqp_iters
     if (admm_iters) admm_iters[b] = sc[b].admm_iters;
   }
   if (merit || max_violation) {
-    double *dm = nullptr, *dv = nullptr;
-    SCO_HIP(hipMalloc((void **)&dm, B * sizeof(double)));
-    SCO_HIP(hipMalloc((void **)&dv, B * sizeof(double)));
+    // result buffers of the handle (an allocation per call cost a device-wide synchronisation and now and then 70 ms)
+    double *dm = h->fetch_buf, *dv = h->fetch_buf + B;
     hipLaunchKernelGGL(sqp_final_kernel, dim3(s.batch), dim3(SCO_BLOCK), 0, h->stream, s, dm, dv);
     SCO_HIP(hipGetLastError());
     SCO_HIP(hipStreamSynchronize(h->stream));
     if (merit) SCO_HIP(hipMemcpy(merit, dm, B * sizeof(double), hipMemcpyDeviceToHost));
     if (max_violation) SCO_HIP(hipMemcpy(max_violation, dv, B * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(dm); (void)hipFree(dv);
   }
   return SCO_OK;
 }
@@ -1359,6 +1486,13 @@ extern "C" int sco_sqp_trace(sco_sqp *h, int cap, double *trace, int *n_entries)
 extern "C" int sco_sqp_last_rounds(const sco_sqp *h, int *rounds) {
   if (!h || !rounds) return SCO_ERR_ARG;
   *rounds = h->rounds;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_last_launches(const sco_sqp *h, int *launches, int *groups) {
+  if (!h) return SCO_ERR_ARG;
+  if (launches) *launches = h->launches;
+  if (groups) *groups = h->groups_used;
   return SCO_OK;
 }
 
