@@ -394,7 +394,8 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
 // --------------------------------------------------------------------------
 struct RlArgs {
   int n, m, n_e, n_c, nnzA, nnzP, max_iter, check;
-  int b0;            // launch window: workgroup g solves problem b0 + g
+  int b0;            // launch window: workgroup g solves problem b0 + g, or list[b0 + g] (< 0: none)
+  const int *list;
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   const unsigned short *off; const int *role;
   const int *srcAc, *srcAr[LNS_MAX], *pc_ptr, *pc_pos, *pc_core;
@@ -636,8 +637,8 @@ __device__ __forceinline__ int rl_tile_row(int n, int h) { return 4 * n + 2 * (h
 
 template <int TR, int TC, int CW, bool ADAPT, int NS = 2>
 __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
-  const int b = blockIdx.x + a.b0, tid = threadIdx.x;
-  if (a.active && !a.active[b]) return;
+  const int b = a.list ? a.list[blockIdx.x + a.b0] : (int)blockIdx.x + a.b0, tid = threadIdx.x;
+  if (b < 0 || (a.active && !a.active[b])) return;
   const int n = a.n, m = a.m, n_e = a.n_e, n_c = a.n_c;
 
   // row vectors are indexed by the planner's LDS position of a row (rl_plan_build), core vectors by core index;
@@ -1208,7 +1209,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   const QpDev &d = a.d;
   RlArgs ra;
   ra.n = d.n; ra.m = d.m; ra.n_e = d.n_e; ra.n_c = d.n_c; ra.nnzA = d.nnzA; ra.nnzP = d.nnzP;
-  ra.max_iter = a.max_iter; ra.check = a.check; ra.b0 = d.b0;
+  ra.max_iter = a.max_iter; ra.check = a.check; ra.b0 = d.b0; ra.list = d.list;
   const int nwg = d.nb > 0 ? d.nb : d.batch;
   ra.sigma = a.sigma; ra.alpha = a.alpha; ra.eps_abs = a.eps_abs; ra.eps_rel = a.eps_rel;
   ra.eps_prim_inf = a.eps_prim_inf; ra.eps_dual_inf = a.eps_dual_inf;

@@ -50,6 +50,7 @@ struct QpDev {
   // launch window (stream groups of the SQP loop): the kernels that honour it work on problem blockIdx.x + b0 and are
   // launched with nb workgroups (nb = 0: the whole batch from problem 0)
   int b0, nb;
+  const int *list;   // or null: workgroup g works on problem list[g + b0] (< 0: none) instead of g + b0
   // shared index plans
   const int *Ap, *Ai, *Rp, *Rj, *Rpos, *Fp, *Fi, *Fpos, *Pdiag;
   const int *elim_var, *core_var, *elim_of, *core_of;
@@ -210,7 +211,7 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
 #define SCO_MASK_NONE ((const int *)(uintptr_t)2)
 // `grp` (may be null): run only problems [b0, b0 + nb) and on grp->stream instead of the handle's own (stream groups of
 // the SQP loop; row-local tier with the Gauss-Jordan inversion only, see sco_qp_supports_groups)
-struct QpGroup { int b0, nb; hipStream_t stream; };
+struct QpGroup { int b0, nb; hipStream_t stream; const int *list; };       // list: see QpDev (null = none)
 int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
                          int slice, hipEvent_t mid, int *sliced, const QpGroup *grp = nullptr);
 bool sco_qp_supports_groups(const sco_qp *qp, const sco_qp_settings *st);

@@ -127,8 +127,8 @@ extern "C" int sco_debug_setup_stamps(double *out) {
 
 __global__ __launch_bounds__(SCO_BLOCK) void qp_setup_kernel(SetupArgs a) {
   const QpDev &d = a.d;
-  const int b = blockIdx.x + a.d.b0, tid = threadIdx.x;
-  if (d.active && !d.active[b]) return;
+  const int b = d.list ? d.list[blockIdx.x + d.b0] : (int)blockIdx.x + d.b0, tid = threadIdx.x;
+  if (b < 0 || (d.active && !d.active[b])) return;
 #ifdef SCO_STAMP
   long long sst_t = __builtin_readcyclecounter();
   if (b == 0 && tid == 0) g_setup_stamp[15] += 1.0;
@@ -441,8 +441,8 @@ __device__ __forceinline__ void sweep_update(double (&t)[NT][4][4], const int (&
 // registers per thread, a tile takes 32)
 template <int SCO_SWEEP_NT>
 __global__ __launch_bounds__(SCO_FACTOR_BLOCK) void qp_sweep_kernel(QpDev d) {
-  const int b = blockIdx.x + d.b0, tid = threadIdx.x;
-  if (d.active && !d.active[b]) return;
+  const int b = d.list ? d.list[blockIdx.x + d.b0] : (int)blockIdx.x + d.b0, tid = threadIdx.x;
+  if (b < 0 || (d.active && !d.active[b])) return;
   const int n = d.n_c;
   if (n == 0) return;
 #ifdef SCO_STAMP
@@ -1073,7 +1073,7 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
   if (sliced) *sliced = slice;
   QpDev d = qp->d; d.active = active_dev;
   QpDev dsetup = qp->d; dsetup.active = adaptive ? qp->d.smask : setup_mask;
-  if (grp) { d.b0 = dsetup.b0 = grp->b0; d.nb = dsetup.nb = grp->nb; }
+  if (grp) { d.b0 = dsetup.b0 = grp->b0; d.nb = dsetup.nb = grp->nb; d.list = dsetup.list = grp->list; }
   const int nwg = grp ? grp->nb : d.batch;          // workgroups of the per-problem kernels
   SetupArgs sa{dsetup, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling, adaptive ? 1 : 0};
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,

@@ -80,6 +80,9 @@ struct SqpDev {
   SqpScalars *sc;
   int *active, *n_active;
   int *newqp;        // [B] 1 = this round's pre kernel prepared a new QP for the problem (setup mask)
+  const int *list;   // [B] or null: workgroup g of a round kernel works on problem list[g] (< 0: none) -- the problems
+                     // sqp_select_kernel lets take part in this round; the others are not visited at all
+  int *list_buf;     // [B] storage of `list`
   const int *jpos;   // [T*d] CSC position of J[t][0][j] in qp1's A values
   const int *epos;   // [d]   CSC position of the first equality-row entry of column (T-1, j)
   // constraint groups (prob.py:81-86, 135-142): G = 0 means the default single group "all"
@@ -440,7 +443,9 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
 // SQP iteration), then the trust-region bounds (for every active problem)
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, SqpParamsDev p) {
-  const int b = blockIdx.x + s.b0, tid = threadIdx.x;
+  const int g = blockIdx.x + s.b0, tid = threadIdx.x;
+  const int b = s.list ? s.list[g] : g;        // round selection: only the listed problems are visited
+  if (b < 0) return;
   SqpScalars &sc = s.sc[b];
   const int state = sc.state;
   // a problem whose QP is parked between two ADMM slices keeps its QP untouched
@@ -694,7 +699,9 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
 // sqp_post: model merit, new merit, decision
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1, SqpParamsDev p) {
-  const int b = blockIdx.x + s.b0, tid = threadIdx.x;
+  const int g = blockIdx.x + s.b0, tid = threadIdx.x;
+  const int b = s.list ? s.list[g] : g;
+  if (b < 0) return;
   SqpScalars &sc = s.sc[b];
   if (sc.state != ST_TRIAL) return;
   if (q1.prog && q1.prog[b] > 0) {             // its QP is parked between two ADMM slices: nothing to decide yet
@@ -1033,7 +1040,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2) AL(vmax, (size_t)B) AL(jlo, (size_t)B * d) AL(jhi, (size_t)B * d)
   AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
   AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
-  AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, SQP_MAX_GROUPS) AL(newqp, (size_t)B)
+  AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, SQP_MAX_GROUPS) AL(newqp, (size_t)B) AL(list_buf, (size_t)B)
   s.H = 40; s.HC = 24;
   AL(hkey, (size_t)B * s.NB * s.H * d) AL(hval, (size_t)B * s.NB * s.H * s.RM) AL(ckey, (size_t)B * s.NB * s.HC * d)
   AL(cJ, (size_t)B * s.NB * s.HC * s.RM * d) AL(cb, (size_t)B * s.NB * s.HC * s.RM) AL(hn, (size_t)B * s.NB)
@@ -1200,6 +1207,87 @@ static hipEvent_t next_event(sco_sqp *h, size_t &cursor) {
   return h->events[cursor++];
 }
 
+// Which problems take part in the next round.  A workgroup of the ADMM kernels fills a CU and the hardware deals the
+// workgroups of a launch to XCDs and shader engines in a fixed rotation, waiting for the engine whose turn it is: a
+// workgroup that finds its problem inactive and exits at once still takes its turn, so a launch of 1024 workgroups of
+// which 768 have work costs four passes of the chip, not three (measured, scripts/experiments/trace_rounds.py), and
+// once problems start to finish the last pass of every lock-step round is partly empty.  With more active problems
+// than CUs a round therefore runs P = floor(active / CUs) whole passes as a COMPACT launch: this kernel lists the
+// P x CUs problems with most in front of them as far as the device can tell -- the slices their current QP has left if
+// it runs to max_iter, one more QP for a problem still in its first penalty QP (a step is normally followed by at
+// least one more), ties by index -- and workgroup g of the round's kernels takes problem list[g].  The host sizes the
+// launch from the active count it read back SQP_DEPTH rounds earlier (`cap`, never too small: the count only falls);
+// surplus workgroups find -1 and exit.  The others are not visited: per problem the sequence of kernels and every
+// result is unchanged, only the round it happens in moves (model on the measured chains, 1024 problems at 7x20:
+// 667 -> 636 ms per step; choosing by the true remaining work would give 629, scripts/experiments/select_sim.py).
+// n_active starts the round at the number of live problems left out (sqp_post_kernel adds those that ran and go on).
+#define SEL_T 1024
+#define SEL_BUCKETS 1024
+__global__ __launch_bounds__(SEL_T) void sqp_select_kernel(SqpDev s, QpDev q1, int cus, int slice, int max_iter, int cap) {
+  __shared__ int hist[SEL_BUCKETS];
+  __shared__ int part[SEL_T], part2[SEL_T];
+  __shared__ int s_active, s_thr, s_take;
+  const int tid = threadIdx.x, B = s.batch;
+  int *list = s.list_buf;
+  for (int k = tid; k < SEL_BUCKETS; k += SEL_T) hist[k] = 0;
+  if (tid == 0) s_active = 0;
+  __syncthreads();
+  const int per_qp = slice > 0 ? (max_iter + slice - 1) / slice : 1;
+  // bucket 0 = most in front of it; -1 = finished
+  auto key_of = [&](int b) -> int {
+    const SqpScalars &sc = s.sc[b];
+    if (sc.state == ST_DONE) return -1;
+    const int done = (q1.prog && slice > 0) ? q1.prog[b] / slice : 0;
+    const int est = max(per_qp - done, 0) + (sc.qp_solves <= 1 ? per_qp : 0);
+    return max(SEL_BUCKETS - 1 - est, 0);
+  };
+  const int per = (B + SEL_T - 1) / SEL_T, b0 = min(B, tid * per), b1 = min(B, b0 + per);
+  int mine = 0;
+  for (int b = b0; b < b1; b++) {
+    const int k = key_of(b);
+    if (k >= 0) { atomicAdd(&hist[k], 1); mine++; }
+  }
+  if (mine) atomicAdd(&s_active, mine);
+  __syncthreads();
+  const int A = s_active;
+  const int quota = min(cap, (cus <= 0 || A <= cus) ? A : (A / cus) * cus);
+  if (tid == 0) {
+    int acc = 0, k = 0;
+    for (; k < SEL_BUCKETS; k++) { if (acc + hist[k] > quota) break; acc += hist[k]; }
+    s_thr = k; s_take = quota - acc;           // every bucket below s_thr runs; of bucket s_thr the first s_take by index
+    *s.n_active = A - quota;
+  }
+  __syncthreads();
+  const int thr = s_thr, take = s_take;
+  // two exclusive scans over the threads' consecutive chunks: members of bucket thr (ties), then chosen problems
+  int cnt = 0;
+  for (int b = b0; b < b1; b++) cnt += key_of(b) == thr ? 1 : 0;
+  part[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int t = 0; t < SEL_T; t++) { const int v = part[t]; part[t] = acc; acc += v; } }
+  __syncthreads();
+  int seen = part[tid], chosen = 0;
+  for (int b = b0; b < b1; b++) {
+    const int k = key_of(b);
+    if (k >= 0 && k < thr) chosen++;
+    else if (k == thr) { if (seen < take) chosen++; seen++; }
+  }
+  part2[tid] = chosen;
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int t = 0; t < SEL_T; t++) { const int v = part2[t]; part2[t] = acc; acc += v; } }
+  __syncthreads();
+  int pos = part2[tid];
+  seen = part[tid];
+  for (int b = b0; b < b1; b++) {
+    const int k = key_of(b);
+    bool r = false;
+    if (k >= 0 && k < thr) r = true;
+    else if (k == thr) { r = seen < take; seen++; }
+    if (r) list[pos++] = b;
+  }
+  for (int g = quota + tid; g < cap; g += SEL_T) list[g] = -1;
+}
+
 // problems the host loop's launch cap left unfinished: failed + SCO_SQP_FLAG_CAPPED
 __global__ void sqp_cap_kernel(SqpDev s) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1294,22 +1382,28 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   SCO_HIP(hipMemsetAsync(h->qp1->d.prog, 0, (size_t)s.batch * sizeof(int), h->stream));
   long long slices_per_qp = slice_req > 0 ? (qsl.max_iter + slice_req - 1) / slice_req : 1;
   if (qsl.adaptive_rho) slices_per_qp += qsl.max_iter / sco_qp_adaptive_interval(&qsl) + 1;    // a launch per rho change at most
-  const long long round_cap = ((long long)p.max_qp_solves + 8) * slices_per_qp;
-  // ---- stream groups.  A lock-step round costs ceil(active / CUs) passes of workgroups, so once problems start to
-  // finish the last pass of every round is partly empty (profiles/r02_launches.txt: 737 ms per step against 630 ms of
-  // work).  The batch is therefore cut into G contiguous groups that run their rounds independently on streams of
-  // their own: while one group's launch drains, the other's fills the free CUs, and SQP_DEPTH rounds per group are
-  // enqueued ahead so the device never waits for the host (a round of a group whose problems are all done is a few
-  // empty launches).  Per problem nothing changes: same kernels, same order, same results.
-  int G = 1;
+  // (a round with selection runs at least half of the active problems, hence the factor 2)
+  const long long round_cap = 2 * ((long long)p.max_qp_solves + 8) * slices_per_qp;
+  // ---- scheduling of the rounds (results never depend on it).  A lock-step round costs ceil(active / CUs) passes of
+  // workgroups, so once problems start to finish the last pass of every round is partly empty
+  // (profiles/r02_launches.txt: 737 ms per step against 630 ms of work).  Default: ROUND SELECTION -- with more active
+  // problems than CUs a round runs a whole number of passes, the problems with most in front of them first
+  // (sqp_select_kernel), and SQP_DEPTH rounds are enqueued ahead so the device never waits for the host.
+  // Alternative (SCO_SQP_GROUPS = 2..4, then no selection): the batch is cut into contiguous STREAM GROUPS that run
+  // their lock-step rounds independently on streams of their own, one group's launch filling the CUs another's
+  // leaves free.  (Measured on the 1024-problem 7x20 step: DESIGN.md 3.3.)
+  int G = 1, cus = 0;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
   {
-    int cus = 0;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     const char *ge = getenv("SCO_SQP_GROUPS");
-    const int want = ge ? atoi(ge) : 2;
+    const int want = ge ? atoi(ge) : 1;
     if (slice_req > 0 && sco_qp_supports_groups(h->qp1, &qsl) && cus > 0 && s.batch >= 2 * cus)
       G = std::max(1, std::min(std::min(want, SQP_MAX_GROUPS), s.batch / cus));
   }
+  const char *sel_env = getenv("SCO_SQP_SELECT");
+  const bool select = G == 1 && slice_req > 0 && cus > 0 && s.batch > cus && sco_qp_supports_groups(h->qp1, &qsl) &&
+                      !(sel_env && sel_env[0] == '0');
+  if (getenv("SCO_SQP_TRACE_ROUNDS")) fprintf(stderr, "sco_sqp_solve: %d CUs, %d stream group(s), round selection %s, slice %d\n", cus, G, select ? "on" : "off", slice_req);
   h->groups_used = G;
   for (int g = 1; g < G; g++)
     if (!h->gstream[g - 1]) SCO_HIP(hipStreamCreate(&h->gstream[g - 1]));
@@ -1322,6 +1416,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   for (int g = 0; g < G; g++) {
     grp[g].b0 = (int)((long long)s.batch * g / G); grp[g].nb = (int)((long long)s.batch * (g + 1) / G) - grp[g].b0;
     grp[g].st = g == 0 ? h->stream : h->gstream[g - 1];
+    grp[g].last_active = G == 1 ? n_active : grp[g].nb;       // upper bound of the group's live problems
   }
   auto gevent = [&](int g) -> hipEvent_t {
     Group &r = grp[g];
@@ -1334,17 +1429,26 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   auto enqueue_round = [&](int g) -> int {
     Group &r = grp[g];
     SqpDev sg = s; sg.b0 = r.b0; sg.n_active = s.n_active + g;
-    const QpGroup win{r.b0, r.nb, r.st};
     if (r.issued == 0) gmark(g, -1);
-    SCO_HIP(hipMemsetAsync(sg.n_active, 0, sizeof(int), r.st));
-    hipLaunchKernelGGL(sqp_pre_kernel, dim3(r.nb), block, 0, r.st, sg, h->qp1->d, p);
+    if (!select) SCO_HIP(hipMemsetAsync(sg.n_active, 0, sizeof(int), r.st));
+    sg.list = nullptr;
+    int nwg = r.nb;                              // workgroups of this round's kernels
+    if (select) {
+      // compact launch: as many workgroups as the selection can let run, sized from the newest active count the host has
+      nwg = std::max(1, r.last_active <= cus ? r.last_active : (r.last_active / cus) * cus);
+      hipLaunchKernelGGL(sqp_select_kernel, dim3(1), dim3(SEL_T), 0, r.st, sg, h->qp1->d, cus, slice_req, qsl.max_iter, nwg);
+      SCO_HIP(hipGetLastError());
+      sg.list = s.list_buf;
+    }
+    hipLaunchKernelGGL(sqp_pre_kernel, dim3(nwg), block, 0, r.st, sg, h->qp1->d, p);
     SCO_HIP(hipGetLastError());
     gmark(g, 0);
     hipEvent_t gm = gevent(g); r.stage.push_back(1);
-    const int rc_ = sco_qp_launch_sliced(h->qp1, &qsl, s.newqp, s.active, slice_req, gm, nullptr, G > 1 ? &win : nullptr);
+    const QpGroup win{r.b0, nwg, r.st, sg.list};
+    const int rc_ = sco_qp_launch_sliced(h->qp1, &qsl, s.newqp, s.active, slice_req, gm, nullptr, (G > 1 || select) ? &win : nullptr);
     if (rc_) return rc_;
     gmark(g, 2);
-    hipLaunchKernelGGL(sqp_post_kernel, dim3(r.nb), block, 0, r.st, sg, h->qp1->d, p);
+    hipLaunchKernelGGL(sqp_post_kernel, dim3(nwg), block, 0, r.st, sg, h->qp1->d, p);
     SCO_HIP(hipGetLastError());
     gmark(g, 3);
     const int slot = r.issued % SQP_DEPTH;

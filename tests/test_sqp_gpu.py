@@ -467,6 +467,32 @@ def test_time_slicing_changes_the_schedule_not_the_results(gpu, monkeypatch, tie
         assert all(np.array_equal(a, b) for a, b in zip(r.trace, outs[0].trace))
 
 
+def test_stream_groups_change_the_schedule_not_the_results(gpu, monkeypatch):
+    """A batch of at least two problems per CU is cut into stream groups whose rounds run side by side with two rounds
+    enqueued ahead (sco_sqp_solve; SCO_SQP_GROUPS = 1 keeps one group): per problem the same kernels run in the same
+    order, so trajectories, decisions and iteration counts are bit-identical for any number of groups, the launch
+    count is the sum over the groups, and a slice length that does not divide the QPs evenly changes nothing either."""
+    nb, dims = 700, (3, 6, 2, 2)
+    arrays, probs = af.make_batch(nb, d=dims[0], T=dims[1], K=dims[2], O=dims[3])
+    outs = []
+    with sb.TrajOptBatch(nb, *dims) as tb:
+        tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                arrays["point_frac"], arrays["obstacles"])
+        for groups, sl in (("1", 400), ("2", 400), ("3", 400), ("2", 175)):
+            monkeypatch.setenv("SCO_SQP_GROUPS", groups)
+            tb.solve(_lib.default_sqp_params(admm_slice=sl))
+            r = tb.fetch(); r.trace = tb.trace(); r.timing = tb.last_timing()
+            outs.append(r)
+    assert [r.timing["groups"] for r in outs] == [1, 2, 2, 2]        # 700 problems on 256 CUs: at most two groups
+    assert outs[1].timing["launches"] > outs[0].timing["launches"] >= outs[0].timing["rounds"] - 1
+    for r in outs[1:]:
+        assert np.array_equal(r.x, outs[0].x) and np.array_equal(r.admm_iters, outs[0].admm_iters)
+        assert np.array_equal(r.success, outs[0].success) and np.array_equal(r.qp_solves, outs[0].qp_solves)
+        assert np.array_equal(r.merit, outs[0].merit) and np.array_equal(r.max_violation, outs[0].max_violation)
+        assert all(np.array_equal(a, b) for a, b in zip(r.trace, outs[0].trace))
+    _compare(outs[1], probs, range(0, nb, 97))
+
+
 def test_adaptive_rho_in_the_device_loop(gpu):
     """sco_qp_settings.adaptive_rho (solver.py:39; reference default off): the device loop parks every QP at each
     rho-update point, re-estimates rho, refactors and resumes.  Not parity mode.  Small problems follow the oracle
