@@ -1037,10 +1037,12 @@ int sco_qp_adaptive_interval(const sco_qp_settings *st) {
 
 bool sco_qp_can_adapt(const sco_qp *qp) { return !(qp->use_big && !qp->use_bt); }
 
-// Launch windows (QpGroup) exist for the path the headline workload takes: row-local ADMM kernel, Gauss-Jordan
-// inversion, fixed rho.
+// Launch windows and index lists (QpGroup) exist for the paths the bench workloads take: row-local ADMM kernel with
+// the Gauss-Jordan inversion, and the structured global-memory tier; fixed rho.
 bool sco_qp_supports_groups(const sco_qp *qp, const sco_qp_settings *st) {
-  return qp->use_rl && !qp->use_big && !qp->factor_cholesky && !st->adaptive_rho;
+  if (st->adaptive_rho) return false;
+  if (qp->use_big) return qp->use_bt;                      // structured global-memory tier
+  return qp->use_rl && !qp->factor_cholesky;
 }
 
 int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
@@ -1090,9 +1092,9 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
   }
   if (qp->use_big) {
     int r_ = big_launch(aa, dsetup.active, st->scaling, qp->Pp_dev, qp->Pi_dev, qp->big, qp->bigd,
-                        qp->use_bt ? &qp->bt : nullptr, qp->use_bt ? &qp->btd : nullptr, stream, qp->ev[1], mid);
+                        qp->use_bt ? &qp->bt : nullptr, qp->use_bt ? &qp->btd : nullptr, stream, grp ? nullptr : qp->ev[1], mid);
     if (r_) return r_;
-    SCO_HIP(hipEventRecord(qp->ev[2], stream));
+    if (!grp) SCO_HIP(hipEventRecord(qp->ev[2], stream));
     return SCO_OK;
   }
   {

@@ -117,8 +117,8 @@ struct BigArgs {
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(BT) void qp_setup_big_kernel(BigArgs a) {
   const QpDev &d = a.d;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (d.active && !d.active[b]) return;
+  const int b = d.list ? d.list[blockIdx.x + d.b0] : (int)blockIdx.x + d.b0, tid = threadIdx.x;
+  if (b < 0 || (d.active && !d.active[b])) return;
   const int n = d.n, m = d.m, nnzP = d.nnzP, nnzA = d.nnzA, n_e = d.n_e, n_c = d.n_c, ncpl = d.ncpl;
   const double rho0 = a.per_problem_rho ? d.rho_b[b] : a.rho;
   __shared__ double red[BWV * 2];
@@ -728,8 +728,8 @@ __device__ __forceinline__ void bt_invert_spd(double *M, double *rowk, double *c
 template <int BS>
 __global__ __launch_bounds__(256) void qp_bt_factor_kernel(BigArgs a) {
   const QpDev &d = a.d;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (d.active && !d.active[b]) return;
+  const int b = d.list ? d.list[blockIdx.x + d.b0] : (int)blockIdx.x + d.b0, tid = threadIdx.x;
+  if (b < 0 || (d.active && !d.active[b])) return;
   constexpr int BB = BS * BS;
   __shared__ double M[BB], Sub[BB], Ev[BB], Cb[BB], rowk[BS], colk[BS];
   double *blk = a.bt_blk + (size_t)b * a.bt_stride;
@@ -1078,8 +1078,8 @@ __device__ __forceinline__ void bt_generic_chunk(const BigArgs &a, const QpDev &
 template <int BS>
 __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   const QpDev &d = a.d;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (d.active && !d.active[b]) return;
+  const int b = d.list ? d.list[blockIdx.x + d.b0] : (int)blockIdx.x + d.b0, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (b < 0 || (d.active && !d.active[b])) return;
   const int n = d.n, m = d.m, n_e = d.n_e, n_c = d.n_c, nb = a.bt_nb, mid = a.bt_mid;
   constexpr int BB = BS * BS;
   const int ncp = nb * BS;
@@ -1469,14 +1469,15 @@ int big_launch(const AdmmArgs &a, const int *setup_mask, int scaling, const int 
   ba.slice = th ? a.slice : 0; ba.adaptive = th ? a.adaptive : 0; ba.ad_interval = a.ad_interval; ba.ad_tol = a.ad_tol;
   ba.per_problem_rho = ba.adaptive; ba.park_part = th ? td->park_part : nullptr;
   BigArgs bs = ba; bs.d.active = setup_mask;          // setup + factorisation: the problems that need them
-  hipLaunchKernelGGL(qp_setup_big_kernel, dim3(a.d.batch), dim3(BT), 0, st, bs);
+  const int nwg = (th && a.d.nb > 0) ? a.d.nb : a.d.batch;       // launch window / index list: structured form only
+  hipLaunchKernelGGL(qp_setup_big_kernel, dim3(nwg), dim3(BT), 0, st, bs);
   SCO_HIP(hipGetLastError());
   if (th) {
     switch (th->bs) {
-      case 4: return bt_launch_bs<4>(bs, ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
-      case 8: return bt_launch_bs<8>(bs, ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
-      case 12: return bt_launch_bs<12>(bs, ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
-      default: return bt_launch_bs<16>(bs, ba, a.d.batch, th->lds_bytes, st, ev_mid, mid2);
+      case 4: return bt_launch_bs<4>(bs, ba, nwg, th->lds_bytes, st, ev_mid, mid2);
+      case 8: return bt_launch_bs<8>(bs, ba, nwg, th->lds_bytes, st, ev_mid, mid2);
+      case 12: return bt_launch_bs<12>(bs, ba, nwg, th->lds_bytes, st, ev_mid, mid2);
+      default: return bt_launch_bs<16>(bs, ba, nwg, th->lds_bytes, st, ev_mid, mid2);
     }
   }
   if (ev_mid) SCO_HIP(hipEventRecord(ev_mid, st));

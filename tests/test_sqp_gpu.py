@@ -467,24 +467,31 @@ def test_time_slicing_changes_the_schedule_not_the_results(gpu, monkeypatch, tie
         assert all(np.array_equal(a, b) for a, b in zip(r.trace, outs[0].trace))
 
 
-def test_stream_groups_change_the_schedule_not_the_results(gpu, monkeypatch):
-    """A batch of at least two problems per CU is cut into stream groups whose rounds run side by side with two rounds
-    enqueued ahead (sco_sqp_solve; SCO_SQP_GROUPS = 1 keeps one group): per problem the same kernels run in the same
-    order, so trajectories, decisions and iteration counts are bit-identical for any number of groups, the launch
-    count is the sum over the groups, and a slice length that does not divide the QPs evenly changes nothing either."""
-    nb, dims = 700, (3, 6, 2, 2)
+@pytest.mark.parametrize("tier", ["row-local", "structured"])
+def test_round_selection_and_stream_groups_change_the_schedule_not_the_results(gpu, monkeypatch, tier):
+    """With more live problems than CUs a round runs whole passes only, as a compact launch over the problems with most
+    in front of them (sqp_select_kernel; SCO_SQP_SELECT=0: plain lock-step rounds), or -- opt-in, SCO_SQP_GROUPS -- the
+    batch is cut into stream groups whose rounds run side by side.  Either way every problem sees the same kernels in the
+    same order: trajectories, decisions and iteration counts are bit-identical for every schedule and slice length."""
+    if tier == "structured":
+        monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    nb, dims = (700, (3, 6, 2, 2)) if tier == "row-local" else (300, (4, 8, 8, 3))
     arrays, probs = af.make_batch(nb, d=dims[0], T=dims[1], K=dims[2], O=dims[3])
+    schedules = [("0", "1", 400), ("1", "1", 400), ("1", "1", 175), ("0", "2", 400), ("0", "3", 175)]
     outs = []
     with sb.TrajOptBatch(nb, *dims) as tb:
         tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
                 arrays["point_frac"], arrays["obstacles"])
-        for groups, sl in (("1", 400), ("2", 400), ("3", 400), ("2", 175)):
-            monkeypatch.setenv("SCO_SQP_GROUPS", groups)
+        for select, groups, sl in schedules:
+            monkeypatch.setenv("SCO_SQP_SELECT", select); monkeypatch.setenv("SCO_SQP_GROUPS", groups)
             tb.solve(_lib.default_sqp_params(admm_slice=sl))
             r = tb.fetch(); r.trace = tb.trace(); r.timing = tb.last_timing()
             outs.append(r)
-    assert [r.timing["groups"] for r in outs] == [1, 2, 2, 2]        # 700 problems on 256 CUs: at most two groups
-    assert outs[1].timing["launches"] > outs[0].timing["launches"] >= outs[0].timing["rounds"] - 1
+    # 700 problems on 256 CUs: at most two groups; 300: one
+    assert [r.timing["groups"] for r in outs] == ([1, 1, 1, 2, 2] if nb >= 512 else [1] * 5)
+    if nb >= 512:
+        assert outs[3].timing["launches"] > outs[0].timing["launches"] >= outs[0].timing["rounds"] - 1
+    assert outs[1].timing["rounds"] >= outs[0].timing["rounds"]        # problems that sit rounds out need more of them
     for r in outs[1:]:
         assert np.array_equal(r.x, outs[0].x) and np.array_equal(r.admm_iters, outs[0].admm_iters)
         assert np.array_equal(r.success, outs[0].success) and np.array_equal(r.qp_solves, outs[0].qp_solves)
