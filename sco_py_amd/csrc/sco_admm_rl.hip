@@ -560,6 +560,12 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 template <int N>
 __device__ __forceinline__ double rl_dot(const double *V, unsigned int *o, const double *vec) {
   constexpr int NP = N / 2;
+  if constexpr (NP > 6) {
+    // the wide instantiations (8 and 10 pairs per column): two halves, so that at most half of the operands are in
+    // registers at once (the three-row-slot kernel spilled 141 VGPRs with all twenty loaded ahead of the arithmetic)
+    constexpr int H = (NP / 2 + 1) & ~1;          // even: the packed offsets of the second half start on a register
+    return rl_dot<2 * H>(V, o, vec) + rl_dot<2 * (NP - H)>(V + 128 * H, o + H / 2, vec);
+  }
   dbl2 val[NP], g[NP];
 #pragma unroll
   for (int h = 0; h < NP; h++) {

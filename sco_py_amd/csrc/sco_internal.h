@@ -155,7 +155,9 @@ struct BtHost {
   size_t blk_doubles = 0, ws_doubles = 0, lds_bytes = 0;
   std::vector<int> ch_desc, it;     // it: 8 ints per chunk slot (e, j, r0, r1, ep0, ep1, core idx, core pos)
 };
-struct BtDev { const int *ch_desc, *it, *cent; double *blk, *ws, *park_part; };   // park_part: [batch][npart] of a parked solve
+// park_part: [batch][npart] of a parked solve; cflag: [batch][nchunks] flags of the per-row constants that are known values
+// for all rows of a dense chunk, ccon: [batch] the common row weight they refer to (written by qp_setup_big_kernel)
+struct BtDev { const int *ch_desc, *it, *cent; double *blk, *ws, *park_part; int *cflag; double *ccon; };
 bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th);
 int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &td);
 // th/td null = dense route

@@ -92,6 +92,9 @@ __device__ __forceinline__ double blimit(double v) {
   return v > SCO_MAX_SCALING ? SCO_MAX_SCALING : v;
 }
 
+// chunk descriptor of the structured form (bt_plan_build): 16 ints per chunk
+#define CH_STRIDE 16      // kind, nact, ncols, r0, c0, pos0, col stride, e0, j0, r1, ep0, ep0 stride, ep1, ep1 stride, partial base, pad
+
 struct BigArgs {
   QpDev d;
   const int *Pp, *Pi;
@@ -109,6 +112,9 @@ struct BigArgs {
   int slice, adaptive, ad_interval, per_problem_rho;
   double ad_tol;
   double *park_part;
+  // per problem and dense chunk: which of the per-row constants (l, u, rho, weight of the primary and of the secondary rows)
+  // are known values for every row of the chunk (flags [batch][nchunks]); ccon[batch]: the common weight the flags refer to
+  int *cflag; double *ccon;
   double *stamp;     // diagnostic build only (SCO_STAMP)
 };
 
@@ -188,6 +194,42 @@ __global__ __launch_bounds__(BT) void qp_setup_big_kernel(BigArgs a) {
     if (tid == 0) d.cscale[b] = c;
   }
   __syncthreads();
+  if (a.bt_bs && a.cflag) {
+    // Constants shared by the rows of a dense chunk.  A hinge block's rows all have l = -inf, the base rho and one
+    // weight, their slack rows l = 0, u = +inf, the base rho and weight 1: six of the eight per-row constants of such a
+    // chunk are known without a load, and the ADMM kernel streams every one it does load per row from L2 / MALL / HBM
+    // in every iteration (48 of 232 bytes per row pair).  Flag bits of the primary rows (secondary rows: << 8):
+    //   1 l = -inf   2 l = 0   4 u = +inf   8 rho = the problem's base rho   16 weight = 1   32 weight = ccon[b]
+    // (ccon[b] = the weight of the first dense chunk's first row: the duplication count of the penalty rows).  A bound
+    // beyond the infinity threshold counts as infinite whatever its scaling (the row update only clamps with it).
+    const double *ls = d.ls + (size_t)b * m, *us = d.us + (size_t)b * m, *rho = d.rho + (size_t)b * m;
+    const int *w = d.w + (size_t)b * m;
+    const double BIGV = SCO_INFTY * SCO_MIN_SCALING;
+    int wk = 1;
+    for (int ch = 0; ch < a.nchunks; ch++)
+      if (a.ch_desc[(size_t)ch * CH_STRIDE] == 0) { wk = w[a.ch_desc[(size_t)ch * CH_STRIDE + 3]]; break; }
+    if (tid == 0) a.ccon[b] = (double)wk;
+    for (int ch = tid; ch < a.nchunks; ch += BT) {
+      const int *dsc = a.ch_desc + (size_t)ch * CH_STRIDE;
+      int fl = 0;
+      if (dsc[0] == 0) {
+        const int cnt = dsc[1];
+        for (int side = 0; side < 2; side++) {
+          const int r0 = side == 0 ? dsc[3] : dsc[9];
+          if (r0 < 0) continue;
+          bool l_inf = true, l_zero = true, u_inf = true, r_base = true, w_one = true, w_k = true;
+          for (int k = 0; k < cnt; k++) {
+            const int i = r0 + k;
+            l_inf = l_inf && ls[i] < -BIGV; l_zero = l_zero && ls[i] == 0.0; u_inf = u_inf && us[i] > BIGV;
+            r_base = r_base && rho[i] == rho0; w_one = w_one && w[i] == 1; w_k = w_k && w[i] == wk;
+          }
+          const int f = (l_inf ? 1 : 0) | (l_zero ? 2 : 0) | (u_inf ? 4 : 0) | (r_base ? 8 : 0) | (w_one ? 16 : 0) | (w_k ? 32 : 0);
+          fl |= f << (8 * side);
+        }
+      }
+      a.cflag[(size_t)b * a.nchunks + ch] = fl;
+    }
+  }
   double *kinv = d.kee_inv + (size_t)b * n_e, *cpl = d.cpl + (size_t)b * ncpl;
   for (int e = tid; e < n_e; e += BT) {
     const int ve = d.elim_var[e];
@@ -561,7 +603,6 @@ __global__ __launch_bounds__(BT) void qp_admm_big_kernel(BigArgs a) {
 // A reads coalesced lines and no index arrays.  A' t' is formed by scattering the
 // products A_ic t'_i into CSC order (coalesced for the same reason) and summing every
 // core column's contiguous segment with 16 lanes.
-#define CH_STRIDE 16      // kind, nact, ncols, r0, c0, pos0, col stride, e0, j0, r1, ep0, ep0 stride, ep1, ep1 stride, partial base, pad
 #define BT_MAXBS 16
 #define BTT 512           // threads of the structured ADMM kernel (256 VGPRs per thread)
 #define BTWV (BTT / 64)
@@ -690,7 +731,7 @@ bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th) {
   }
   if (!th.use_part) th.npart = 0;
   // factors; r/y, z/x~ (+ 64 zeros), x, q; partial sums; column metadata; chunk descriptors
-  th.lds_bytes = 8 * (th.blk_doubles + 4 * ncp + 64 + th.npart) + 4 * (4 * ncp + th.ch_desc.size());
+  th.lds_bytes = 8 * (th.blk_doubles + 4 * ncp + 64 + th.npart) + 4 * (4 * ncp + th.ch_desc.size() + th.nchunks);
   if (th.lds_bytes + 1024 > 160 * 1024) return false;
   th.ws_doubles = 3 * (size_t)m + pl.n_e + pl.n + pl.nnzA + 64;
   return true;
@@ -826,6 +867,8 @@ struct BtPtrs {
   const double *s_xc;
   double *s_part;       // partial column sums of the dense chunks (LDS) or null: products go to `prod`
   double alpha, sigma;
+  const int *s_cflag;       // LDS: this problem's chunk flags (qp_setup_big_kernel), all zero if there are none
+  double rho0, wk;          // the constants the flags refer to: base rho, common weight
 };
 struct BtRow { double zc, ae, rh, w, z, y, l, u; };
 // one row of the ADMM update; returns t_i = w (rho z+ - y+)
@@ -903,7 +946,7 @@ struct BtDenseRegs {
   bool two, on;
 };
 template <int NC>
-__device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int lane, const BtPtrs &q, BtDenseRegs<NC> &R) {
+__device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int ch, int lane, const BtPtrs &q, BtDenseRegs<NC> &R) {
   R.on = lane < dsc[1];
   R.ln = R.on ? lane : dsc[1] - 1;
   R.ncols = dsc[2]; R.pos0 = dsc[5]; R.cs = dsc[6]; R.c0 = dsc[4]; R.pbase = dsc[14];
@@ -913,8 +956,21 @@ __device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int l
 #pragma unroll
   for (int k = 0; k < NC; k++) R.av[k] = q.As[R.pos0 + (k < R.ncols ? k : 0) * R.cs + R.ln];
   const int ep0 = dsc[10] + dsc[11] * R.ln, ep1 = R.two ? dsc[12] + dsc[13] * R.ln : ep0;
-  R.p = BtRow{0.0, q.As[ep0], q.rho[R.r0], (double)q.w[R.r0], q.z[R.r0], q.y[R.r0], q.ls[R.r0], q.us[R.r0]};
-  R.s = BtRow{0.0, q.As[ep1], q.rho[R.r1], (double)q.w[R.r1], q.z[R.r1], q.y[R.r1], q.ls[R.r1], q.us[R.r1]};
+  // per-row constants the chunk's rows are known to share are not loaded (flags: qp_setup_big_kernel; wave-uniform)
+  const int fl = __builtin_amdgcn_readfirstlane(q.s_cflag[ch]), fs = fl >> 8;
+  R.p.zc = 0.0; R.p.ae = q.As[ep0]; R.p.z = q.z[R.r0]; R.p.y = q.y[R.r0];
+  R.s.zc = 0.0; R.s.ae = q.As[ep1]; R.s.z = q.z[R.r1]; R.s.y = q.y[R.r1];
+  if (fl & 1) R.p.l = -SCO_INFTY; else if (fl & 2) R.p.l = 0.0; else R.p.l = q.ls[R.r0];
+  if (fl & 4) R.p.u = SCO_INFTY; else R.p.u = q.us[R.r0];
+  if (fl & 8) R.p.rh = q.rho0; else R.p.rh = q.rho[R.r0];
+  if (fl & 16) R.p.w = 1.0; else if (fl & 32) R.p.w = q.wk; else R.p.w = (double)q.w[R.r0];
+  if (!R.two) { R.s.l = R.p.l; R.s.u = R.p.u; R.s.rh = R.p.rh; R.s.w = R.p.w; }      // r1 = r0: never used
+  else {
+    if (fs & 1) R.s.l = -SCO_INFTY; else if (fs & 2) R.s.l = 0.0; else R.s.l = q.ls[R.r1];
+    if (fs & 4) R.s.u = SCO_INFTY; else R.s.u = q.us[R.r1];
+    if (fs & 8) R.s.rh = q.rho0; else R.s.rh = q.rho[R.r1];
+    if (fs & 16) R.s.w = 1.0; else if (fs & 32) R.s.w = q.wk; else R.s.w = (double)q.w[R.r1];
+  }
   R.g = q.ge[R.e]; R.ki = q.kinv[R.e]; R.xo = q.x[R.j]; R.qj = q.qs[R.j];
 }
 template <int NC>
@@ -958,11 +1014,11 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
 }
 // chunks A and, if hasB, B: loads of both before the arithmetic of either
 template <int NC>
-__device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const int (&dB)[CH_STRIDE], bool hasB, int lane, bool chk,
-                                              const BtPtrs &q) {
+__device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const int (&dB)[CH_STRIDE], int chA, int chB, bool hasB, int lane,
+                                              bool chk, const BtPtrs &q) {
   BtDenseRegs<NC> RA, RB;
-  bt_dense_load<NC>(dA, lane, q, RA);
-  if (hasB) bt_dense_load<NC>(dB, lane, q, RB);
+  bt_dense_load<NC>(dA, chA, lane, q, RA);
+  if (hasB) bt_dense_load<NC>(dB, chB, lane, q, RB);
   bt_dense_compute<NC>(RA, lane, chk, q);
   if (hasB) bt_dense_compute<NC>(RB, lane, chk, q);
 }
@@ -1094,6 +1150,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   double *s_part = s_q + ncp;                  // partial column sums of the dense chunks
   int *s_cent = (int *)(s_part + a.npart);     // use_part: [ncp][4] column contributions; else: segment start, length
   int *s_dsc = s_cent + 4 * ncp;
+  int *s_cflag = s_dsc + a.nchunks * CH_STRIDE;      // chunk flags (shared per-row constants)
   const double *As = d.As + (size_t)b * d.nnzA, *Ps = d.Ps + (size_t)b * d.nnzP;
   const double *qs = d.qs + (size_t)b * n, *ls = d.ls + (size_t)b * m, *us = d.us + (size_t)b * m;
   const double *rho = d.rho + (size_t)b * m, *kinv = d.kee_inv + (size_t)b * n_e;
@@ -1103,7 +1160,8 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   double *ws = a.ws + (size_t)b * a.ws_stride;
   double *z = ws, *tp = z + m, *sdy = tp + m, *ge = sdy + m, *sdx = ge + n_e, *prod = sdx + n;
   const double cscale = d.cscale[b], alpha = a.alpha, sigma = a.sigma;
-  const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, use_part ? s_part : nullptr, alpha, sigma};
+  const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, use_part ? s_part : nullptr, alpha, sigma,
+                  s_cflag, a.per_problem_rho ? d.rho_b[b] : a.rho, a.ccon ? a.ccon[b] : 1.0};
 
   {
     const double *blk = a.bt_blk + (size_t)b * a.bt_stride;
@@ -1119,6 +1177,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
       }
     }
     for (int t = tid; t < a.nchunks * CH_STRIDE; t += BTT) s_dsc[t] = a.ch_desc[t];
+    for (int t = tid; t < a.nchunks; t += BTT) s_cflag[t] = a.cflag ? a.cflag[(size_t)b * a.nchunks + t] : 0;
   }
   // a parked solve (time slicing, adaptive rho) resumes from its scaled x, y (left in place) and z, t', g_e and the
   // partial column sums (save area); when rho has changed meanwhile only x, y, z carry over and t, g_e, t' are
@@ -1283,17 +1342,17 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
 #pragma unroll
       for (int k = 0; k < CH_STRIDE; k++) dsc[k] = __builtin_amdgcn_readfirstlane(s_dsc[ch * CH_STRIDE + k]);
       if (dsc[0] == 0) {
-        const int ncols = dsc[2], chb = ch + BTWV;
+        const int ncols = dsc[2], chb = ch + BTWV, cha = ch;
         bool hasB = false;
         if (chb < a.nchunks) {
 #pragma unroll
           for (int k = 0; k < CH_STRIDE; k++) dsb[k] = __builtin_amdgcn_readfirstlane(s_dsc[chb * CH_STRIDE + k]);
           if (dsb[0] == 0 && (dsb[2] + 3) / 4 == (ncols + 3) / 4) { hasB = true; ch = chb; }
         }
-        if (ncols <= 4) bt_dense_pair<4>(dsc, dsb, hasB, lane, chk, bp);
-        else if (ncols <= 8) bt_dense_pair<8>(dsc, dsb, hasB, lane, chk, bp);
-        else if (ncols <= 12) bt_dense_pair<12>(dsc, dsb, hasB, lane, chk, bp);
-        else bt_dense_pair<16>(dsc, dsb, hasB, lane, chk, bp);
+        if (ncols <= 4) bt_dense_pair<4>(dsc, dsb, cha, chb, hasB, lane, chk, bp);
+        else if (ncols <= 8) bt_dense_pair<8>(dsc, dsb, cha, chb, hasB, lane, chk, bp);
+        else if (ncols <= 12) bt_dense_pair<12>(dsc, dsb, cha, chb, hasB, lane, chk, bp);
+        else bt_dense_pair<16>(dsc, dsb, cha, chb, hasB, lane, chk, bp);
         BSTAMP(7)
         continue;
       }
@@ -1416,6 +1475,13 @@ int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &t
   SCO_HIP(hipMalloc(&p, (size_t)batch * std::max(th.npart, 1) * sizeof(double)));
   allocs.push_back(p);
   td.park_part = (double *)p;
+  SCO_HIP(hipMalloc(&p, (size_t)batch * std::max(th.nchunks, 1) * sizeof(int)));
+  SCO_HIP(hipMemset(p, 0, (size_t)batch * std::max(th.nchunks, 1) * sizeof(int)));
+  allocs.push_back(p);
+  td.cflag = (int *)p;
+  SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(double)));
+  allocs.push_back(p);
+  td.ccon = (double *)p;
   return SCO_OK;
 }
 
@@ -1451,7 +1517,7 @@ int big_launch(const AdmmArgs &a, const int *setup_mask, int scaling, const int 
   }
 #endif
   ba.bt_bs = 0; ba.bt_nb = 0; ba.bt_mid = 0; ba.bt_blk = nullptr; ba.bt_stride = 0; ba.nchunks = 0;
-  ba.ch_desc = ba.it = ba.cent = nullptr; ba.npart = 0; ba.use_part = 0;
+  ba.ch_desc = ba.it = ba.cent = nullptr; ba.npart = 0; ba.use_part = 0; ba.cflag = nullptr; ba.ccon = nullptr;
   ba.d = a.d; ba.Pp = Pp; ba.Pi = Pi;
   ba.row_elim = bd.row_elim; ba.row_epos = bd.row_epos; ba.er_ptr = bd.er_ptr; ba.er_row = bd.er_row;
   ba.free_rows = bd.free_rows; ba.pc_ptr = bd.pc_ptr; ba.pc_pos = bd.pc_pos; ba.pc_core = bd.pc_core;
@@ -1465,6 +1531,7 @@ int big_launch(const AdmmArgs &a, const int *setup_mask, int scaling, const int 
     ba.ch_desc = td->ch_desc; ba.it = td->it; ba.cent = td->cent; ba.nchunks = th->nchunks;
     ba.npart = th->npart; ba.use_part = th->use_part ? 1 : 0;
     ba.ws = td->ws; ba.ws_stride = th->ws_doubles;
+    ba.cflag = td->cflag; ba.ccon = td->ccon;
   }
   ba.slice = th ? a.slice : 0; ba.adaptive = th ? a.adaptive : 0; ba.ad_interval = a.ad_interval; ba.ad_tol = a.ad_tol;
   ba.per_problem_rho = ba.adaptive; ba.park_part = th ? td->park_part : nullptr;
