@@ -187,6 +187,12 @@ void sco_sqp_default_params(sco_sqp_params *p);
                                   NON-LINEAR EQUALITY ee(theta[horizon-1]) = target (2 rows, end-effector
                                   position): EqExpr on an Expr, lowered to the abs penalty with two slack
                                   variables per row (prob.py:280-315); target via sco_sqp_load_target */
+#define SCO_FAM_POINT_CIRCLES 3 /* a point robot in the plane instead of the arm: the state of a timestep is dof >= 2
+                                  numbers, the first two its position, and g[o](x) = r_o - || x[0:2] - c_o || <= 0
+                                  (n_points must be 1; link_len / point_link / point_frac of sco_sqp_load are not
+                                  read).  Objective, pins and the linear-row flags below work as for the arm
+                                  (velocity limits = longest step per axis, joint limits = workspace box); the
+                                  objective-term flag SCO_FAM_FLAG_EE_COST is not available for it */
 
 /* Structure of a batch of trajectory problems (shared by all `batch` problems):
  * variables theta[t][j], t < horizon, j < dof, flattened time-major (n_x = horizon*dof);

@@ -503,9 +503,13 @@ def trajopt_flat(prob, analytic_jac=False):
     blocks = []
     R = prob["K"] * prob["O"]
     for t in range(T):
-        f = (lambda th, pr=prob: af.arm_dist(th, pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"]))
-        jac = None
-        if analytic_jac:
+        if prob.get("point"):                   # SCO_FAM_POINT_CIRCLES: a point robot, K = 1
+            f = (lambda th, pr=prob: af.point_dist(th, pr["obstacles"]))
+            jac = (lambda th, pr=prob: af.point_dist_jac(th, pr["obstacles"])) if analytic_jac else None
+        else:
+            f = (lambda th, pr=prob: af.arm_dist(th, pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"]))
+            jac = None
+        if analytic_jac and not prob.get("point"):
             jac = (lambda th, pr=prob: af.arm_dist_jac(th, pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"]))
         blocks.append(Block("leq", f, np.arange(t * d, (t + 1) * d), np.zeros(R), jac=jac,
                             groups=prob["groups"][t] if prob.get("groups") is not None else None))

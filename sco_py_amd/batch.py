@@ -17,6 +17,7 @@ from . import _lib
 
 SCO_FAM_ARM_CIRCLES = 1
 SCO_FAM_ARM_REACH = 2
+SCO_FAM_POINT_CIRCLES = 3
 SCO_FAM_FLAG_VEL_LIMITS = 16
 SCO_FAM_FLAG_JOINT_LIMITS = 32
 SCO_FAM_FLAG_EE_COST = 64
@@ -36,6 +37,8 @@ class TrajOptBatch(object):
     linear rows lo <= theta[t] <= hi, SCO_FAM_FLAG_JOINT_LIMITS; ``ee_cost=True``: a non-quadratic objective term
     weight * ||ee(theta[t]) - target||^2 per timestep, convexified to degree 2 like ``Prob.add_obj_expr`` on a plain
     ``Expr`` (numeric Hessian + eigenvalue shift), SCO_FAM_FLAG_EE_COST)
+    ``point=True``: SCO_FAM_POINT_CIRCLES, a point robot in the plane (state of a timestep: dof >= 2 numbers, the first
+    two its position; n_points = 1; link data are not read) instead of the arm)
     solved per problem exactly like ``Solver().solve(prob, method="penalty_sqp")``.
     ``prox_count`` says how many Variables hold each atom in the equivalent object-API
     construction (it scales the projection QP of find_closest_feasible_point,
@@ -44,7 +47,7 @@ class TrajOptBatch(object):
     """
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
-                 prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False):
+                 prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False, point=False):
         self.B, self.d, self.T, self.K, self.O = int(batch), int(dof), int(horizon), int(n_points), int(n_obstacles)
         self.n_x = self.d * self.T
         self.device = int(device)
@@ -53,8 +56,11 @@ class TrajOptBatch(object):
         self.vel_limits = bool(vel_limits)
         self.joint_limits = bool(joint_limits)
         self.ee_cost = bool(ee_cost)
+        self.point = bool(point)          # SCO_FAM_POINT_CIRCLES: a point robot in the plane instead of the arm
+        if self.point and (self.reach or self.ee_cost):
+            raise ValueError("the point-robot family has neither the reach equality nor the objective term")
         desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O,
-                                (SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES) |
+                                (SCO_FAM_POINT_CIRCLES if self.point else SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES) |
                                 (SCO_FAM_FLAG_VEL_LIMITS if self.vel_limits else 0) |
                                 (SCO_FAM_FLAG_JOINT_LIMITS if self.joint_limits else 0) |
                                 (SCO_FAM_FLAG_EE_COST if self.ee_cost else 0),
@@ -186,7 +192,8 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
     a = batch_arrays
     with TrajOptBatch(a["B"], a["d"], a["T"], a["K"], a["O"], device=device, analytic_jac=analytic_jac,
                       prox_count=prox_count, reach=bool(a.get("reach")), vel_limits=a.get("vmax") is not None,
-                      joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None) as tb:
+                      joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
+                      point=bool(a.get("point"))) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                 target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
                 cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"))

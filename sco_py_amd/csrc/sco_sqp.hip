@@ -59,6 +59,7 @@ struct SqpDev {
   // SCO_FAM_ARM_REACH: NE = 2 equality rows (end-effector x, y) on the last timestep, block index T;
   // NB = number of constraint blocks (T or T + 1), RM = widest block (history strides)
   int NE, NB, RM;
+  int point;         // SCO_FAM_POINT_CIRCLES: the rows are distances of the point x[0:2] itself (no arm kinematics)
   // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows, then m_jl joint-limit
   // rows (theta <= hi for every trajectory variable, then -theta <= -lo)
   int m_pin, m_vel, m_jl;
@@ -287,17 +288,26 @@ __device__ __forceinline__ RowRef row_ref(int e, int T, int R) {
   return q;
 }
 
-struct RowCtx { const double *len, *obs, *target; const int *point_link; const double *point_frac; int d, O; };
+struct RowCtx { const double *len, *obs, *target; const int *point_link; const double *point_frac; int d, O, point; };
 // f of row q at th (the raw function value: the right-hand side val is 0 for hinge rows and
 // target[r] for equality rows and is applied by the callers, in the reference's order)
 __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, const double *th, int pert, double h) {
   if (q.eq) return arm_ee(th, c.len, c.d, q.r, pert, h);
   const int kp = q.r / c.O, o = q.r % c.O;
+  if (c.point) {                               // SCO_FAM_POINT_CIRCLES: r_o - || x[0:2] - c_o ||
+    const double dx = th[0] + (pert == 0 ? h : 0.0) - c.obs[3 * o], dy = th[1] + (pert == 1 ? h : 0.0) - c.obs[3 * o + 1];
+    return c.obs[3 * o + 2] - sqrt(dx * dx + dy * dy);
+  }
   return arm_row(th, c.len, c.point_link[kp], c.point_frac[kp], c.obs[3 * o], c.obs[3 * o + 1], c.obs[3 * o + 2], pert, h);
 }
 __device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, const double *th, int j) {
   if (q.eq) return arm_ee_grad(th, c.len, c.d, q.r, j);
   const int kp = q.r / c.O, o = q.r % c.O;
+  if (c.point) {
+    if (j > 1) return 0.0;
+    const double dx = th[0] - c.obs[3 * o], dy = th[1] - c.obs[3 * o + 1];
+    return -(j == 0 ? dx : dy) / sqrt(dx * dx + dy * dy);
+  }
   return arm_row_grad(th, c.len, c.point_link[kp], c.point_frac[kp], c.obs[3 * o], c.obs[3 * o + 1], j);
 }
 __device__ __forceinline__ double row_rhs(const RowCtx &c, const RowRef &q) { return q.eq ? c.target[q.r] : 0.0; }
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     // Q3: which blocks sit on an already-seen / already-convexified rounded point
     __shared__ int ev_hit[260], cv_hit[260];
     const int H = s.H, HC = s.HC, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
-    const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O};
+    const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point};
     double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
     double *ckey = s.ckey + (size_t)b * NB * HC * d, *cJ = s.cJ + (size_t)b * NB * HC * RM * d, *cb = s.cb + (size_t)b * NB * HC * RM;
     int *hn = s.hn + (size_t)b * NB, *cn = s.cn + (size_t)b * NB;
@@ -723,7 +733,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   // Q3: blocks of the trial point that round onto an already-seen point reuse its f values
   __shared__ int ev_hit[260];
   const int H = s.H, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
-  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O};
+  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point};
   double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
   int *hn = s.hn + (size_t)b * NB;
   for (int t = tid; t < NB; t += SCO_BLOCK)
@@ -877,7 +887,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *
   const double *x = s.x + (size_t)b * n_x;
   const double *len = s.link_len + (size_t)b * d;
   const double *obs = s.obstacles + (size_t)b * O * 3;
-  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O};
+  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point};
   double v[3] = {traj_obj_partial(x, d, T, tid), 0.0, 0.0};
   if (s.cost)
     for (int t = tid; t < T; t += SCO_BLOCK)
@@ -921,7 +931,8 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
       desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS | SCO_FAM_FLAG_EE_COST)) ||
       ((desc->family & SCO_FAM_FLAG_EE_COST) && desc->dof > OBJ_DMAX) ||
-      ((desc->family & 15) != SCO_FAM_ARM_CIRCLES && (desc->family & 15) != SCO_FAM_ARM_REACH)) {
+      ((desc->family & 15) != SCO_FAM_ARM_CIRCLES && (desc->family & 15) != SCO_FAM_ARM_REACH && (desc->family & 15) != SCO_FAM_POINT_CIRCLES) ||
+      ((desc->family & 15) == SCO_FAM_POINT_CIRCLES && (desc->n_points != 1 || desc->dof < 2 || (desc->family & SCO_FAM_FLAG_EE_COST)))) {
     sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
   }
   int ndev = 0;
@@ -1032,6 +1043,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   s.batch = B; s.d = d; s.T = T; s.K = K; s.O = O; s.R = R; s.n_x = n_x; s.n_slack = n_slack; s.n = n;
   s.m_lin = m_lin; s.m_nl = m_nl; s.m = m; s.prox_count = desc->prox_count > 0 ? desc->prox_count : 1;
   s.analytic_jac = desc->analytic_jac; s.trace_cap = 64;
+  s.point = (desc->family & 15) == SCO_FAM_POINT_CIRCLES ? 1 : 0;
   s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE) + (cost ? 1 : 0);     // + the objective term's value
   s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl; s.cost = cost ? 1 : 0;
   int rc = 0;

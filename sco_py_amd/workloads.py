@@ -4,7 +4,7 @@ The reference ships no benchmark problems; this module defines the
 seeded planar-arm workload of SURVEY.md 8(d) in NumPy so that bench.py, the tests,
 the oracle and the golden-vector generators all hand the device kernels the same
 inputs.  The NumPy forward kinematics below are the definition of the device
-constraint families (SCO_FAM_ARM_CIRCLES / SCO_FAM_ARM_REACH, csrc/sco_sqp.hip) and
+constraint families (SCO_FAM_ARM_CIRCLES / SCO_FAM_ARM_REACH / SCO_FAM_POINT_CIRCLES, csrc/sco_sqp.hip) and
 what a host-side `Expr(f)` of the same constraint evaluates.
 
 Problem i (``make_problem(i, ...)``):
@@ -86,6 +86,24 @@ def ee_jac(theta, link_len):
     return J
 
 
+def point_dist(x, obstacles):
+    """SCO_FAM_POINT_CIRCLES: g (O,) with g[o] = r_o - ||x[:2] - c_o|| for a point robot at x[:2] (further coordinates of the
+    state, if any, are unconstrained)."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    dx, dy = x[0] - obstacles[:, 0], x[1] - obstacles[:, 1]
+    return obstacles[:, 2] - np.sqrt(dx * dx + dy * dy)
+
+
+def point_dist_jac(x, obstacles):
+    """Analytic Jacobian (O, d) of point_dist."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    dx, dy = x[0] - obstacles[:, 0], x[1] - obstacles[:, 1]
+    dist = np.sqrt(dx * dx + dy * dy)
+    J = np.zeros((obstacles.shape[0], x.shape[0]))
+    J[:, 0] = -dx / dist; J[:, 1] = -dy / dist
+    return J
+
+
 def velocity_rows(d, T):
     """V (2 d (T-1), d T): rows theta[t+1][j] - theta[t][j] (t-major), then their negatives."""
     D = np.zeros((d * (T - 1), d * T))
@@ -139,11 +157,38 @@ def ee_cost(theta, link_len, target, weight):
     return float(weight) * float(e[0] * e[0] + e[1] * e[1])
 
 
+def make_point_problem(i, d=2, T=20, O=3, noise=0.03, groups=None, vel_limit=None, joint_limit=None):
+    """Seeded problem i of the point-robot family (SCO_FAM_POINT_CIRCLES): a point in the plane (state dimension d >= 2, the
+    first two coordinates are its position) goes from start to goal past O discs that sit on its straight path.  Same
+    dictionary layout as make_problem (K = 1: the point itself; link data are placeholders the family does not read)."""
+    rng = np.random.default_rng(5000 + i)
+    start = rng.uniform(-1.0, 1.0, size=d)
+    goal = -start + 0.3 * rng.standard_normal(d)                 # roughly across the origin
+    s = np.linspace(0.0, 1.0, T)[:, None]
+    x0 = (1 - s) * start[None, :] + s * goal[None, :] + noise * rng.standard_normal((T, d))
+    along = np.sort(rng.uniform(0.2, 0.8, size=O))               # discs near the straight path, off-centre
+    centre = (1 - along[:, None]) * start[None, :2] + along[:, None] * goal[None, :2] + 0.08 * rng.standard_normal((O, 2))
+    radius = rng.uniform(0.08, 0.2, size=O)
+    obstacles = np.concatenate([centre, radius[:, None]], axis=1)
+    out = dict(d=d, T=T, K=1, O=O, x0=x0.ravel(), start=start, goal=goal, link_len=np.ones(d),
+               point_link=np.zeros(1, dtype=np.int32), point_frac=np.ones(1), obstacles=obstacles, reach=False, point=True)
+    if groups is not None:
+        out["groups"] = block_groups(T, False, groups)
+    if vel_limit is not None:
+        out["vmax"] = float(vel_limit)
+    if joint_limit is not None:                                   # workspace box around the straight path
+        out["jlo"] = np.minimum(start, goal) - float(joint_limit)
+        out["jhi"] = np.maximum(start, goal) + float(joint_limit)
+    return out
+
+
 def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None,
-                 ee_cost_weight=None):
+                 ee_cost_weight=None, point=False):
     """Seeded problem i of the batch.  reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
+    if point:
+        return make_point_problem(i, d=d, T=T, O=O, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
     is_reach = bool(reach)
     rng = np.random.default_rng(1000 + i)
     start = rng.uniform(-np.pi / 2, np.pi / 2, size=d)
@@ -186,6 +231,8 @@ def make_batch(B, first=0, **kw):
     probs = [make_problem(first + i, **kw) for i in range(B)]
     p0 = probs[0]
     extra = dict(reach=True, target=np.stack([p["target"] for p in probs])) if p0.get("reach") else {}
+    if p0.get("point"):
+        extra["point"] = True
     if p0.get("groups") is not None:
         extra["groups"] = p0["groups"]
     if p0.get("vmax") is not None:

@@ -467,8 +467,8 @@ def test_time_slicing_changes_the_schedule_not_the_results(gpu, monkeypatch, tie
         assert all(np.array_equal(a, b) for a, b in zip(r.trace, outs[0].trace))
 
 
-@pytest.mark.parametrize("tier", ["row-local", "structured"])
-def test_round_selection_and_stream_groups_change_the_schedule_not_the_results(gpu, monkeypatch, tier):
+@pytest.mark.parametrize("tier,quirks", [("row-local", True), ("row-local", False), ("structured", True)])
+def test_round_selection_and_stream_groups_change_the_schedule_not_the_results(gpu, monkeypatch, tier, quirks):
     """With more live problems than CUs a round runs whole passes only, as a compact launch over the problems with most
     in front of them (sqp_select_kernel; SCO_SQP_SELECT=0: plain lock-step rounds), or -- opt-in, SCO_SQP_GROUPS -- the
     batch is cut into stream groups whose rounds run side by side.  Either way every problem sees the same kernels in the
@@ -482,9 +482,11 @@ def test_round_selection_and_stream_groups_change_the_schedule_not_the_results(g
     with sb.TrajOptBatch(nb, *dims) as tb:
         tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
                 arrays["point_frac"], arrays["obstacles"])
+        # quirks off: up to 20 penalty QPs per problem, accepted steps, shrinks and escalations (many transitions)
+        kw = {} if quirks else dict(compound_penalty=0, duplicate_rows=0, max_sqp_iters=20)
         for select, groups, sl in schedules:
             monkeypatch.setenv("SCO_SQP_SELECT", select); monkeypatch.setenv("SCO_SQP_GROUPS", groups)
-            tb.solve(_lib.default_sqp_params(admm_slice=sl))
+            tb.solve(_lib.default_sqp_params(admm_slice=sl, **kw))
             r = tb.fetch(); r.trace = tb.trace(); r.timing = tb.last_timing()
             outs.append(r)
     # 700 problems on 256 CUs: at most two groups; 300: one
@@ -497,7 +499,8 @@ def test_round_selection_and_stream_groups_change_the_schedule_not_the_results(g
         assert np.array_equal(r.success, outs[0].success) and np.array_equal(r.qp_solves, outs[0].qp_solves)
         assert np.array_equal(r.merit, outs[0].merit) and np.array_equal(r.max_violation, outs[0].max_violation)
         assert all(np.array_equal(a, b) for a, b in zip(r.trace, outs[0].trace))
-    _compare(outs[1], probs, range(0, nb, 97))
+    _compare(outs[1], probs, range(0, nb, 97),
+             None if quirks else sr.SolverParams(compound_penalty=False, duplicate_rows=False, max_qp_solves=20))
 
 
 def test_adaptive_rho_in_the_device_loop(gpu):
@@ -573,6 +576,49 @@ def test_joint_limits_match_reference_golden_runs(gpu):
         nq = int(g[prefix + "n_qp"])
         assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix
         assert [int(v) for v in res.trace[0][:, 7]] == [int(g["%sqp%d_iters" % (prefix, k)]) for k in range(nq)], prefix
+
+
+def test_point_robot_family_matches_oracle(gpu):
+    """SCO_FAM_POINT_CIRCLES: a point robot in the plane instead of the arm (rows r_o - ||x[0:2] - c_o||; a third state
+    coordinate stays unconstrained), alone, with velocity limits, a workspace box and constraint groups; numeric and
+    analytic Jacobians."""
+    for kw, analytic in ((dict(d=2, T=8, O=3), False), (dict(d=2, T=8, O=3), True), (dict(d=3, T=6, O=2), False),
+                         (dict(d=2, T=8, O=3, vel_limit=0.45), False), (dict(d=2, T=8, O=3, joint_limit=0.15, groups="split"), False)):
+        arrays, probs = af.make_batch(8, K=1, point=True, **kw)
+        res = sb.solve_batch(arrays, analytic_jac=analytic)
+        _compare(res, probs, range(8), analytic=analytic)
+    arrays, probs = af.make_batch(300, d=2, T=20, K=1, O=3, point=True)           # more problems than CUs: round selection
+    res = sb.solve_batch(arrays)
+    _compare(res, probs, range(0, 300, 43))
+    ok = res.success
+    assert ok.sum() > 100
+    x = res.x.reshape(300, 20, 2)
+    for b in np.nonzero(ok)[0][:50]:
+        dist = np.linalg.norm(x[b][:, None, :] - arrays["obstacles"][b][None, :, :2], axis=2)
+        assert np.all(dist >= arrays["obstacles"][b][None, :, 2] - 1e-3)          # success = outside every disc
+
+
+def test_point_robot_family_matches_reference_golden_runs(gpu):
+    import sys
+    sys.path.insert(0, GOLD)
+    from point_cases import CASES
+    g = np.load(os.path.join(GOLD, "trajopt_point.npz"))
+    for prefix, kw, i in CASES:
+        arrays, _ = af.make_batch(1, first=i, **kw)
+        res = sb.solve_batch(arrays)
+        assert np.abs(res.x[0] - g[prefix + "x"]).max() < TOL, prefix
+        assert bool(res.success[0]) == bool(g[prefix + "success"]), prefix
+        nq = int(g[prefix + "n_qp"])
+        assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix
+        assert [int(v) for v in res.trace[0][:, 7]] == [int(g["%sqp%d_iters" % (prefix, k)]) for k in range(nq)], prefix
+
+
+def test_point_robot_family_descriptor_rules(gpu):
+    for bad in (dict(n_points=2), dict(dof=1), dict(ee_cost=True)):
+        kw = dict(batch=2, dof=2, horizon=6, n_points=1, n_obstacles=2, point=True); kw.update(bad)
+        with pytest.raises((_lib.ScoHipError, ValueError)):
+            sb.TrajOptBatch(kw["batch"], kw["dof"], kw["horizon"], kw["n_points"], kw["n_obstacles"], point=True,
+                            ee_cost=bool(kw.get("ee_cost")))
 
 
 def test_joint_limits_7x20_batch_and_validation(gpu):

@@ -60,12 +60,16 @@ def build_prob(mods, pr, analytic_jac=False):
         step_vars.append(sv)
 
         def f(x, pr=pr):
+            if pr.get("point"):                 # point-robot family: distance of the point itself to the discs
+                return af.point_dist(x.ravel(), pr["obstacles"]).reshape(-1, 1)
             return af.arm_dist(x.ravel(), pr["link_len"], pr["point_link"], pr["point_frac"],
                                pr["obstacles"]).reshape(-1, 1)
 
         grad = None
         if analytic_jac:
             def grad(x, pr=pr):
+                if pr.get("point"):
+                    return af.point_dist_jac(x.ravel(), pr["obstacles"])
                 return af.arm_dist_jac(x.ravel(), pr["link_len"], pr["point_link"], pr["point_frac"],
                                        pr["obstacles"])
         e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
