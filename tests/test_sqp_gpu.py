@@ -503,6 +503,35 @@ def test_round_selection_and_stream_groups_change_the_schedule_not_the_results(g
              None if quirks else sr.SolverParams(compound_penalty=False, duplicate_rows=False, max_qp_solves=20))
 
 
+@pytest.mark.parametrize("kw", [dict(reach=True, vel_limit=0.6, groups="halves"), dict(joint_limit=0.3, vel_limit=0.6),
+                                dict(ee_cost_weight=0.5)], ids=["reach+vel+groups", "jl+vel", "objective terms"])
+def test_round_selection_with_every_family_feature(gpu, kw):
+    """A batch just above the CU count (one problem sits out every round until the first finishes) and very short
+    slices (many rounds, many park / resume cycles): reach equality, velocity and joint limits, constraint groups and
+    non-quadratic objective terms under round selection against the oracle."""
+    nb = 260
+    arrays, probs = af.make_batch(nb, d=3, T=6, K=2, O=2, **kw)
+    with sb.TrajOptBatch(nb, 3, 6, 2, 2, reach=bool(kw.get("reach")), vel_limits="vel_limit" in kw,
+                         joint_limits="joint_limit" in kw, ee_cost="ee_cost_weight" in kw) as tb:
+        tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                arrays["point_frac"], arrays["obstacles"], target=arrays.get("target"), vmax=arrays.get("vmax"),
+                jlo=arrays.get("jlo"), jhi=arrays.get("jhi"), cost_weight=arrays.get("cost_weight"),
+                cost_target=arrays.get("cost_target"))
+        if arrays.get("groups") is not None:
+            tb.set_groups(arrays["groups"])
+        tb.solve(_lib.default_sqp_params(admm_slice=75))
+        res = tb.fetch(); res.trace = tb.trace(); tm = tb.last_timing()
+    assert tm["groups"] == 1 and tm["rounds"] > 20
+    if "ee_cost_weight" in kw:
+        # numeric Hessians amplify last-bit differences (DESIGN.md 4): decisions, statuses and trajectories only
+        for b in range(0, nb, 37):
+            ref = sr.penalty_sqp(sr.trajopt_flat(probs[b]), emulate_memo=True)
+            assert np.array_equal(res.trace[b][:, 0], ref.trace[:64, 0]) and np.array_equal(res.trace[b][:, 6], ref.trace[:64, 6])
+            assert np.abs(res.x[b] - ref.x).max() < TOL
+    else:
+        _compare(res, probs, range(0, nb, 37))
+
+
 def test_adaptive_rho_in_the_device_loop(gpu):
     """sco_qp_settings.adaptive_rho (solver.py:39; reference default off): the device loop parks every QP at each
     rho-update point, re-estimates rho, refactors and resumes.  Not parity mode.  Small problems follow the oracle
