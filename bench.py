@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--workload", choices=["7x20", "12x50"], default="7x20",
                     help="7x20 = BASELINE configs[2] (headline); 12x50 = configs[4] shape (structured global-memory tier)")
     ap.add_argument("--cpu-problems", type=int, default=16, help="size of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--aux-12x50", type=int, default=512,
+    ap.add_argument("--aux-12x50", type=int, default=1024,
                     help="batch of the 12-DOF x 50 line reported under aux in a default 7x20 run (0 = skip)")
     ap.add_argument("--intended", action="store_true",
                     help="disable reference quirks Q1/Q2 (NOT the headline number)")
