@@ -867,6 +867,7 @@ struct BtPtrs {
   const double *s_xc;
   double *s_part;       // partial column sums of the dense chunks (LDS) or null: products go to `prod`
   double alpha, sigma;
+  double *v;                // pre-clamp value of every dense-chunk row (bt_row_step_v)
   const int *s_cflag;       // LDS: this problem's chunk flags (qp_setup_big_kernel), all zero if there are none
   double rho0, wk;          // the constants the flags refer to: base rho, common weight
 };
@@ -881,6 +882,29 @@ __device__ __forceinline__ double bt_row_step(const BtRow &r, double alpha, doub
   yn = r.y + dy;
   return r.w * (r.rh * zn - yn);
 }
+// t_i = w (rho z - y) and g_e = ((sigma x_e - q_e) + a_0 t_0 + a_1 t_1) / K_ee.  (Re-deriving g_e at the next iteration from v and
+// x instead of storing it saves 16 B per row pair and costs more VALU than it gains: 70.1 -> 69.6 us per iteration with 256
+// problems resident, 58.2 -> 60.1 with 128; not kept.)
+__device__ __forceinline__ double bt_tq(const BtRow &r, double z, double y) { return r.w * (r.rh * z - y); }
+__device__ __forceinline__ double bt_ge(double sigma, double x, double qj, double ae0, double tq0, double ae1, double tq1, double ki) {
+  return ((sigma * x - qj) + ae0 * tq0 + ae1 * tq1) * ki;
+}
+// The same update for the rows of dense chunks, which keep ONE number per row between iterations: v = z~ + y / rho, the
+// value before the clamp.  The iterates are z = clamp(v, l, u) and y = rho (v - z) -- what OSQP's update produces in
+// exact arithmetic (y+ = y + rho (z~ - z+) = rho (v - z+)) -- so z and y need not be stored and loaded separately
+// (16 B less per row and iteration in each direction); they are written out on the iterations the termination test,
+// a park or the end of the solve read them.  r.z / r.y come from bt_row_zy on all but the first iteration of a launch.
+__device__ __forceinline__ double bt_row_step_v(const BtRow &r, double alpha, double xte, double &zn, double &yn, double &dy, double &v) {
+  const double zt = r.zc + r.ae * xte;
+  const double zr = alpha * zt + (1.0 - alpha) * r.z;
+  v = zr + (1.0 / r.rh) * r.y;
+  zn = fmin(fmax(v, r.l), r.u);
+  dy = r.rh * (zr - zn);
+  yn = r.rh * (v - zn);
+  return bt_tq(r, zn, yn);
+}
+__device__ __forceinline__ void bt_row_zy(BtRow &r, double v) { r.z = fmin(fmax(v, r.l), r.u); r.y = r.rh * (v - r.z); }
+
 // sum over the wavefront, valid in lane 63; fixed association order (16-lane rows by
 // row_shr 1,2,4,8, then row_bcast15 into rows 1 and 3, then row_bcast31 into rows 2 and 3)
 __device__ __forceinline__ double bt_wave_sum63(double v) {
@@ -946,7 +970,7 @@ struct BtDenseRegs {
   bool two, on;
 };
 template <int NC>
-__device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int ch, int lane, const BtPtrs &q, BtDenseRegs<NC> &R) {
+__device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int ch, int lane, bool first, const BtPtrs &q, BtDenseRegs<NC> &R) {
   R.on = lane < dsc[1];
   R.ln = R.on ? lane : dsc[1] - 1;
   R.ncols = dsc[2]; R.pos0 = dsc[5]; R.cs = dsc[6]; R.c0 = dsc[4]; R.pbase = dsc[14];
@@ -958,8 +982,11 @@ __device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int c
   const int ep0 = dsc[10] + dsc[11] * R.ln, ep1 = R.two ? dsc[12] + dsc[13] * R.ln : ep0;
   // per-row constants the chunk's rows are known to share are not loaded (flags: qp_setup_big_kernel; wave-uniform)
   const int fl = __builtin_amdgcn_readfirstlane(q.s_cflag[ch]), fs = fl >> 8;
-  R.p.zc = 0.0; R.p.ae = q.As[ep0]; R.p.z = q.z[R.r0]; R.p.y = q.y[R.r0];
-  R.s.zc = 0.0; R.s.ae = q.As[ep1]; R.s.z = q.z[R.r1]; R.s.y = q.y[R.r1];
+  // first iteration of a launch: z and y as the start / the previous launch left them; afterwards one number per row
+  double vp = 0.0, vs = 0.0;
+  R.p.zc = 0.0; R.p.ae = q.As[ep0]; R.s.zc = 0.0; R.s.ae = q.As[ep1];
+  if (first) { R.p.z = q.z[R.r0]; R.p.y = q.y[R.r0]; R.s.z = q.z[R.r1]; R.s.y = q.y[R.r1]; }
+  else { vp = q.v[R.r0]; vs = q.v[R.r1]; }
   if (fl & 1) R.p.l = -SCO_INFTY; else if (fl & 2) R.p.l = 0.0; else R.p.l = q.ls[R.r0];
   if (fl & 4) R.p.u = SCO_INFTY; else R.p.u = q.us[R.r0];
   if (fl & 8) R.p.rh = q.rho0; else R.p.rh = q.rho[R.r0];
@@ -971,6 +998,7 @@ __device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int c
     if (fs & 8) R.s.rh = q.rho0; else R.s.rh = q.rho[R.r1];
     if (fs & 16) R.s.w = 1.0; else if (fs & 32) R.s.w = q.wk; else R.s.w = (double)q.w[R.r1];
   }
+  if (!first) { bt_row_zy(R.p, vp); bt_row_zy(R.s, vs); }
   R.g = q.ge[R.e]; R.ki = q.kinv[R.e]; R.xo = q.x[R.j]; R.qj = q.qs[R.j];
 }
 template <int NC>
@@ -989,16 +1017,16 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
   if (!R.two) { R.s.ae = 0.0; R.s.w = 0.0; }
   const double rwp = R.p.w * R.p.rh;
   const double xte = R.g - R.ki * (rwp * R.p.ae * R.p.zc);         // the second row has no core entry
-  double zn, yn, dy;
-  const double tq0 = bt_row_step(R.p, q.alpha, xte, zn, yn, dy);
-  if (R.on) { q.z[R.r0] = zn; q.y[R.r0] = yn; if (chk) q.sdy[R.r0] = dy; }
+  double zn, yn, dy, vv;
+  const double tq0 = bt_row_step_v(R.p, q.alpha, xte, zn, yn, dy, vv);
+  if (R.on) { q.v[R.r0] = vv; if (chk) { q.z[R.r0] = zn; q.y[R.r0] = yn; q.sdy[R.r0] = dy; } }
   double tq1 = 0.0;
   if (R.two) {
-    tq1 = bt_row_step(R.s, q.alpha, xte, zn, yn, dy);
-    if (R.on) { q.z[R.r1] = zn; q.y[R.r1] = yn; if (chk) q.sdy[R.r1] = dy; }
+    tq1 = bt_row_step_v(R.s, q.alpha, xte, zn, yn, dy, vv);
+    if (R.on) { q.v[R.r1] = vv; if (chk) { q.z[R.r1] = zn; q.y[R.r1] = yn; q.sdy[R.r1] = dy; } }
   }
   const double xn = q.alpha * xte + (1.0 - q.alpha) * R.xo;
-  const double gn = ((q.sigma * xn - R.qj) + R.p.ae * tq0 + R.s.ae * tq1) * R.ki;
+  const double gn = bt_ge(q.sigma, xn, R.qj, R.p.ae, tq0, R.s.ae, tq1, R.ki);
   if (R.on) { if (chk) q.sdx[R.j] = xn - R.xo; q.x[R.j] = xn; q.ge[R.e] = gn; }
   const double t0 = R.on ? tq0 - rwp * R.p.ae * gn : 0.0;
   if (q.s_part) {
@@ -1015,10 +1043,10 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
 // chunks A and, if hasB, B: loads of both before the arithmetic of either
 template <int NC>
 __device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const int (&dB)[CH_STRIDE], int chA, int chB, bool hasB, int lane,
-                                              bool chk, const BtPtrs &q) {
+                                              bool chk, bool first, const BtPtrs &q) {
   BtDenseRegs<NC> RA, RB;
-  bt_dense_load<NC>(dA, chA, lane, q, RA);
-  if (hasB) bt_dense_load<NC>(dB, chB, lane, q, RB);
+  bt_dense_load<NC>(dA, chA, lane, first, q, RA);
+  if (hasB) bt_dense_load<NC>(dB, chB, lane, first, q, RB);
   bt_dense_compute<NC>(RA, lane, chk, q);
   if (hasB) bt_dense_compute<NC>(RB, lane, chk, q);
 }
@@ -1160,8 +1188,9 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   double *ws = a.ws + (size_t)b * a.ws_stride;
   double *z = ws, *tp = z + m, *sdy = tp + m, *ge = sdy + m, *sdx = ge + n_e, *prod = sdx + n;
   const double cscale = d.cscale[b], alpha = a.alpha, sigma = a.sigma;
+  // v shares the storage of t': the start point's t' is only read by the prologue below
   const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, use_part ? s_part : nullptr, alpha, sigma,
-                  s_cflag, a.per_problem_rho ? d.rho_b[b] : a.rho, a.ccon ? a.ccon[b] : 1.0};
+                  tp, s_cflag, a.per_problem_rho ? d.rho_b[b] : a.rho, a.ccon ? a.ccon[b] : 1.0};
 
   {
     const double *blk = a.bt_blk + (size_t)b * a.bt_stride;
@@ -1268,6 +1297,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
 #endif
   for (iter = it0 + 1; iter <= a.max_iter; iter++) {
     const bool chk = (a.check > 0 && iter % a.check == 0) || iter == a.max_iter;
+    const bool first = iter == it0 + 1;       // dense rows: z, y from their arrays (start, resume); afterwards from v
     BSTAMP(11)
     // (1) core right-hand side r_c = sigma x_c - q_c + (A' t)_c
     if (use_part) {
@@ -1349,10 +1379,10 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
           for (int k = 0; k < CH_STRIDE; k++) dsb[k] = __builtin_amdgcn_readfirstlane(s_dsc[chb * CH_STRIDE + k]);
           if (dsb[0] == 0 && (dsb[2] + 3) / 4 == (ncols + 3) / 4) { hasB = true; ch = chb; }
         }
-        if (ncols <= 4) bt_dense_pair<4>(dsc, dsb, cha, chb, hasB, lane, chk, bp);
-        else if (ncols <= 8) bt_dense_pair<8>(dsc, dsb, cha, chb, hasB, lane, chk, bp);
-        else if (ncols <= 12) bt_dense_pair<12>(dsc, dsb, cha, chb, hasB, lane, chk, bp);
-        else bt_dense_pair<16>(dsc, dsb, cha, chb, hasB, lane, chk, bp);
+        if (ncols <= 4) bt_dense_pair<4>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
+        else if (ncols <= 8) bt_dense_pair<8>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
+        else if (ncols <= 12) bt_dense_pair<12>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
+        else bt_dense_pair<16>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
         BSTAMP(7)
         continue;
       }
