@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--cpu-problems", type=int, default=16, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--aux-12x50", type=int, default=1024,
                     help="batch of the 12-DOF x 50 line reported under aux in a default 7x20 run (0 = skip)")
+    ap.add_argument("--aux-b4096", type=int, default=1, help="also report a 4096-problem 7x20 step under aux (0 = skip)")
     ap.add_argument("--intended", action="store_true",
                     help="disable reference quirks Q1/Q2 (NOT the headline number)")
     ap.add_argument("--beyond", action="store_true",
@@ -376,6 +377,13 @@ def main():
                  "admm_problem_iterations_per_s": (r12["it_proj"] + r12["it_pen"]) / (r12["admm_ms"] * 1e-3),
                  "roofline": {k: rf12[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}}
 
+    aux4096 = None
+    if world == 1 and not big and B == 1024 and not (args.intended or args.beyond) and args.aux_b4096:
+        # the north_star's batch (4096 problems on one GPU): one warm-up, one step, reported under aux
+        r4 = run("7x20", 4096, 1, 1)
+        aux4096 = {"workload": "batch=4096 x 7-DOF x 20-timestep on one GPU, parity mode, 1 step", "sco_iters_per_s": r4["sco_iters"] / r4["elapsed"],
+                   "ms_per_step": 1e3 * r4["elapsed"], "admm_ms": r4["admm_ms"], "onchip_frac": roofline(r4, False)["frac"]}
+
     if rank == 0:
         dims = r["dims"]
         out = {
@@ -409,11 +417,15 @@ def main():
         }
         if aux12 is not None:
             out["aux"]["config4_12x50"] = aux12
+        if aux4096 is not None:
+            out["aux"]["batch_4096"] = aux4096
         if world == 1 and args.cpu_problems > 0:
             v, dt, it = cpu_baseline(args.cpu_problems, 0, dims)
             out["cpu_baseline"] = {"value": v, "unit": "sco_iters/s", "cores": 1, "kind": "port",
                                    "sample": "problems 0..%d of the same batch, oracle/sco_ref.py + "
                                              "oracle/osqp_ref.c, %.1f s" % (args.cpu_problems - 1, dt)}
+            if aux4096 is not None:
+                aux4096["vs_cpu_1core"] = aux4096["sco_iters_per_s"] / v
         if cpu_all is not None:
             out["aux"]["cpu_baseline_all_cores"] = cpu_all
         print(json.dumps(out))
