@@ -371,8 +371,9 @@ def main():
         # BASELINE configs[4] shape on the structured global-memory tier: a small batch, one step, reported under aux
         r12 = run("12x50", args.aux_12x50, 1, 0)
         rf12 = roofline(r12, True)
-        aux12 = {"workload": "batch=%d x 12-DOF x 50-timestep (n=5600, m=10624, 5000 nonlinear rows) per GPU, parity mode, 1 step"
-                             % args.aux_12x50,
+        aux12 = {"workload": "batch=%d x 12-DOF x 50-timestep (n=5600, m=10624, 5000 nonlinear rows) per GPU, parity mode, 1 step; "
+                             "structured global-memory ADMM tier on the f64 vector ALU (the dense batched-Jacobian MFMA path "
+                             "north_star sketches is waived: block-diagonal Jacobian, DESIGN.md 5)" % args.aux_12x50,
                  "sco_iters_per_s": r12["sco_iters"] / r12["elapsed"], "ms_per_step": 1e3 * r12["elapsed"],
                  "admm_problem_iterations_per_s": (r12["it_proj"] + r12["it_pen"]) / (r12["admm_ms"] * 1e-3),
                  "roofline": {k: rf12[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}}
