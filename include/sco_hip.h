@@ -193,6 +193,11 @@ void sco_sqp_default_params(sco_sqp_params *p);
                                   read).  Objective, pins and the linear-row flags below work as for the arm
                                   (velocity limits = longest step per axis, joint limits = workspace box); the
                                   objective-term flag SCO_FAM_FLAG_EE_COST is not available for it */
+#define SCO_FAM_STATE_QUADRATIC 4 /* general quadratic rows on the state of a timestep (no kinematics): n_obstacles rows
+                                  g[r](x) = 1/2 x' Q_r x + a_r' x + c_r <= 0 per timestep with per-problem coefficients
+                                  (sco_sqp_load_quadratic), Q_r symmetric and of either sign -- keep-out ellipses, keep-in
+                                  discs, half-planes, products of coordinates ...; dof <= 16, n_points must be 1; link_len /
+                                  point_* / obstacles of sco_sqp_load are not read.  Flags as for SCO_FAM_POINT_CIRCLES */
 
 /* Structure of a batch of trajectory problems (shared by all `batch` problems):
  * variables theta[t][j], t < horizon, j < dof, flattened time-major (n_x = horizon*dof);
@@ -246,6 +251,9 @@ int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, const double
 /* SCO_FAM_ARM_REACH only, after sco_sqp_load: target[batch][2] end-effector position the last
  * timestep must reach (`goal` of sco_sqp_load is then unused and may repeat `start`). */
 int sco_sqp_load_target(sco_sqp *h, const double *target);
+/* SCO_FAM_STATE_QUADRATIC only, after sco_sqp_load: Q[batch][n_obstacles][dof*dof] (symmetric), a[batch][n_obstacles][dof],
+ * c[batch][n_obstacles]. */
+int sco_sqp_load_quadratic(sco_sqp *h, const double *Q, const double *a, const double *c);
 /* SCO_FAM_FLAG_VEL_LIMITS only, after sco_sqp_load: vmax[batch] > 0, one limit per problem. */
 int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax);
 /* SCO_FAM_FLAG_JOINT_LIMITS only, after sco_sqp_load: lo[batch][dof] < hi[batch][dof]. */

@@ -79,6 +79,7 @@ ABI = {
     "sco_sqp_destroy": (C.c_int, [C.c_void_p]),
     "sco_sqp_load": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, _IP, _DP, _DP]),
     "sco_sqp_load_target": (C.c_int, [C.c_void_p, _DP]),
+    "sco_sqp_load_quadratic": (C.c_int, [C.c_void_p, _DP, _DP, _DP]),
     "sco_sqp_load_vel_limit": (C.c_int, [C.c_void_p, _DP]),
     "sco_sqp_load_joint_limits": (C.c_int, [C.c_void_p, _DP, _DP]),
     "sco_sqp_load_ee_cost": (C.c_int, [C.c_void_p, _DP, _DP]),

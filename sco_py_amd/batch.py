@@ -18,6 +18,7 @@ from . import _lib
 SCO_FAM_ARM_CIRCLES = 1
 SCO_FAM_ARM_REACH = 2
 SCO_FAM_POINT_CIRCLES = 3
+SCO_FAM_STATE_QUADRATIC = 4
 SCO_FAM_FLAG_VEL_LIMITS = 16
 SCO_FAM_FLAG_JOINT_LIMITS = 32
 SCO_FAM_FLAG_EE_COST = 64
@@ -38,7 +39,9 @@ class TrajOptBatch(object):
     weight * ||ee(theta[t]) - target||^2 per timestep, convexified to degree 2 like ``Prob.add_obj_expr`` on a plain
     ``Expr`` (numeric Hessian + eigenvalue shift), SCO_FAM_FLAG_EE_COST)
     ``point=True``: SCO_FAM_POINT_CIRCLES, a point robot in the plane (state of a timestep: dof >= 2 numbers, the first
-    two its position; n_points = 1; link data are not read) instead of the arm)
+    two its position; n_points = 1; link data are not read) instead of the arm; ``quadratic=True``:
+    SCO_FAM_STATE_QUADRATIC, n_obstacles rows 1/2 x' Q_r x + a_r' x + c_r <= 0 on the state of every timestep with
+    per-problem coefficients (``load(..., quad_Q=, quad_a=, quad_c=)``))
     solved per problem exactly like ``Solver().solve(prob, method="penalty_sqp")``.
     ``prox_count`` says how many Variables hold each atom in the equivalent object-API
     construction (it scales the projection QP of find_closest_feasible_point,
@@ -47,7 +50,8 @@ class TrajOptBatch(object):
     """
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
-                 prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False, point=False):
+                 prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False, point=False,
+                 quadratic=False):
         self.B, self.d, self.T, self.K, self.O = int(batch), int(dof), int(horizon), int(n_points), int(n_obstacles)
         self.n_x = self.d * self.T
         self.device = int(device)
@@ -57,10 +61,14 @@ class TrajOptBatch(object):
         self.joint_limits = bool(joint_limits)
         self.ee_cost = bool(ee_cost)
         self.point = bool(point)          # SCO_FAM_POINT_CIRCLES: a point robot in the plane instead of the arm
-        if self.point and (self.reach or self.ee_cost):
-            raise ValueError("the point-robot family has neither the reach equality nor the objective term")
+        self.quadratic = bool(quadratic)   # SCO_FAM_STATE_QUADRATIC: n_obstacles general quadratic rows per timestep
+        if (self.point or self.quadratic) and (self.reach or self.ee_cost):
+            raise ValueError("the point-robot and quadratic-row families have neither the reach equality nor the objective term")
+        if self.point and self.quadratic:
+            raise ValueError("one family per batch")
         desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O,
-                                (SCO_FAM_POINT_CIRCLES if self.point else SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES) |
+                                (SCO_FAM_STATE_QUADRATIC if self.quadratic else SCO_FAM_POINT_CIRCLES if self.point else
+                                 SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES) |
                                 (SCO_FAM_FLAG_VEL_LIMITS if self.vel_limits else 0) |
                                 (SCO_FAM_FLAG_JOINT_LIMITS if self.joint_limits else 0) |
                                 (SCO_FAM_FLAG_EE_COST if self.ee_cost else 0),
@@ -85,7 +93,7 @@ class TrajOptBatch(object):
         self.close()
 
     def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles, target=None, vmax=None,
-             jlo=None, jhi=None, cost_weight=None, cost_target=None):
+             jlo=None, jhi=None, cost_weight=None, cost_target=None, quad_Q=None, quad_a=None, quad_c=None):
         """Upload per-problem data (host arrays, copied).  ``target`` (B, 2): end-effector
         position of the reach variant (``goal`` is then ignored by the device)."""
         B, d, K, O = self.B, self.d, self.K, self.O
@@ -102,6 +110,11 @@ class TrajOptBatch(object):
         _lib.check(_lib.load().sco_sqp_load(self._h, _lib.dptr(x0), _lib.dptr(start), _lib.dptr(goal),
                                             _lib.dptr(link_len), _lib.iptr(point_link), _lib.dptr(point_frac),
                                             _lib.dptr(obstacles)))
+        if self.quadratic:
+            if quad_Q is None or quad_a is None or quad_c is None:
+                raise ValueError("the quadratic-row family needs quad_Q (B, O, d, d), quad_a (B, O, d), quad_c (B, O)")
+            qQ = arr(quad_Q, (B, O, d, d)); qa = arr(quad_a, (B, O, d)); qc = arr(quad_c, (B, O))
+            _lib.check(_lib.load().sco_sqp_load_quadratic(self._h, _lib.dptr(qQ), _lib.dptr(qa), _lib.dptr(qc)))
         if self.reach:
             if target is None:
                 raise ValueError("the reach variant needs target (B, 2)")
@@ -193,10 +206,11 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
     with TrajOptBatch(a["B"], a["d"], a["T"], a["K"], a["O"], device=device, analytic_jac=analytic_jac,
                       prox_count=prox_count, reach=bool(a.get("reach")), vel_limits=a.get("vmax") is not None,
                       joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
-                      point=bool(a.get("point"))) as tb:
+                      point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                 target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
-                cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"))
+                cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),
+                quad_Q=a.get("quad_Q"), quad_a=a.get("quad_a"), quad_c=a.get("quad_c"))
         if a.get("groups") is not None:
             tb.set_groups(a["groups"])
         tb.solve(params, qp_settings)

@@ -59,7 +59,9 @@ struct SqpDev {
   // SCO_FAM_ARM_REACH: NE = 2 equality rows (end-effector x, y) on the last timestep, block index T;
   // NB = number of constraint blocks (T or T + 1), RM = widest block (history strides)
   int NE, NB, RM;
-  int point;         // SCO_FAM_POINT_CIRCLES: the rows are distances of the point x[0:2] itself (no arm kinematics)
+  int point;         // 1 SCO_FAM_POINT_CIRCLES: the rows are distances of the point x[0:2] itself (no arm kinematics);
+                     // 2 SCO_FAM_STATE_QUADRATIC: general quadratic rows with the coefficients below
+  double *qQ, *qa, *qc;   // [B][O][d*d], [B][O][d], [B][O]
   // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows, then m_jl joint-limit
   // rows (theta <= hi for every trajectory variable, then -theta <= -lo)
   int m_pin, m_vel, m_jl;
@@ -115,7 +117,7 @@ struct sco_sqp {
   int groups_used = 1;
   std::vector<void *> allocs;
   std::vector<hipEvent_t> events;
-  bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false, cost_loaded = false;
+  bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false, cost_loaded = false, quad_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   int rounds = 0;          // 1 (projection) + the rounds of the group that needed most
   int launches = 0;        // round launches over all stream groups
@@ -288,12 +290,24 @@ __device__ __forceinline__ RowRef row_ref(int e, int T, int R) {
   return q;
 }
 
-struct RowCtx { const double *len, *obs, *target; const int *point_link; const double *point_frac; int d, O, point; };
+struct RowCtx { const double *len, *obs, *target; const int *point_link; const double *point_frac; int d, O, point;
+                const double *qQ, *qa, *qc; };      // SCO_FAM_STATE_QUADRATIC: this problem's row coefficients (point == 2)
 // f of row q at th (the raw function value: the right-hand side val is 0 for hinge rows and
 // target[r] for equality rows and is applied by the callers, in the reference's order)
 __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, const double *th, int pert, double h) {
   if (q.eq) return arm_ee(th, c.len, c.d, q.r, pert, h);
   const int kp = q.r / c.O, o = q.r % c.O;
+  if (c.point == 2) {                          // SCO_FAM_STATE_QUADRATIC: 1/2 x' Q x + a' x + c of row o
+    const double *Q = c.qQ + (size_t)o * c.d * c.d, *av = c.qa + (size_t)o * c.d;
+    double val = c.qc[o];
+    for (int i = 0; i < c.d; i++) {
+      const double xi = th[i] + (i == pert ? h : 0.0);
+      double qx = 0.0;
+      for (int j2 = 0; j2 < c.d; j2++) qx += Q[i * c.d + j2] * (th[j2] + (j2 == pert ? h : 0.0));
+      val += xi * (av[i] + 0.5 * qx);
+    }
+    return val;
+  }
   if (c.point) {                               // SCO_FAM_POINT_CIRCLES: r_o - || x[0:2] - c_o ||
     const double dx = th[0] + (pert == 0 ? h : 0.0) - c.obs[3 * o], dy = th[1] + (pert == 1 ? h : 0.0) - c.obs[3 * o + 1];
     return c.obs[3 * o + 2] - sqrt(dx * dx + dy * dy);
@@ -303,6 +317,12 @@ __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, co
 __device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, const double *th, int j) {
   if (q.eq) return arm_ee_grad(th, c.len, c.d, q.r, j);
   const int kp = q.r / c.O, o = q.r % c.O;
+  if (c.point == 2) {                          // a_j + sum_i Q_ji x_i  (Q symmetric)
+    const double *Q = c.qQ + (size_t)o * c.d * c.d;
+    double g = c.qa[(size_t)o * c.d + j];
+    for (int i = 0; i < c.d; i++) g += Q[j * c.d + i] * th[i];
+    return g;
+  }
   if (c.point) {
     if (j > 1) return 0.0;
     const double dx = th[0] - c.obs[3 * o], dy = th[1] - c.obs[3 * o + 1];
@@ -479,7 +499,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     // Q3: which blocks sit on an already-seen / already-convexified rounded point
     __shared__ int ev_hit[260], cv_hit[260];
     const int H = s.H, HC = s.HC, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
-    const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point};
+    const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point,
+                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O};
     double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
     double *ckey = s.ckey + (size_t)b * NB * HC * d, *cJ = s.cJ + (size_t)b * NB * HC * RM * d, *cb = s.cb + (size_t)b * NB * HC * RM;
     int *hn = s.hn + (size_t)b * NB, *cn = s.cn + (size_t)b * NB;
@@ -733,7 +754,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   // Q3: blocks of the trial point that round onto an already-seen point reuse its f values
   __shared__ int ev_hit[260];
   const int H = s.H, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
-  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point};
+  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point,
+                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O};
   double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
   int *hn = s.hn + (size_t)b * NB;
   for (int t = tid; t < NB; t += SCO_BLOCK)
@@ -887,7 +909,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *
   const double *x = s.x + (size_t)b * n_x;
   const double *len = s.link_len + (size_t)b * d;
   const double *obs = s.obstacles + (size_t)b * O * 3;
-  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point};
+  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point,
+                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O};
   double v[3] = {traj_obj_partial(x, d, T, tid), 0.0, 0.0};
   if (s.cost)
     for (int t = tid; t < T; t += SCO_BLOCK)
@@ -931,8 +954,10 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
       desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS | SCO_FAM_FLAG_EE_COST)) ||
       ((desc->family & SCO_FAM_FLAG_EE_COST) && desc->dof > OBJ_DMAX) ||
-      ((desc->family & 15) != SCO_FAM_ARM_CIRCLES && (desc->family & 15) != SCO_FAM_ARM_REACH && (desc->family & 15) != SCO_FAM_POINT_CIRCLES) ||
-      ((desc->family & 15) == SCO_FAM_POINT_CIRCLES && (desc->n_points != 1 || desc->dof < 2 || (desc->family & SCO_FAM_FLAG_EE_COST)))) {
+      ((desc->family & 15) != SCO_FAM_ARM_CIRCLES && (desc->family & 15) != SCO_FAM_ARM_REACH && (desc->family & 15) != SCO_FAM_POINT_CIRCLES &&
+       (desc->family & 15) != SCO_FAM_STATE_QUADRATIC) ||
+      ((desc->family & 15) == SCO_FAM_POINT_CIRCLES && (desc->n_points != 1 || desc->dof < 2 || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
+      ((desc->family & 15) == SCO_FAM_STATE_QUADRATIC && (desc->n_points != 1 || desc->dof > OBJ_DMAX || (desc->family & SCO_FAM_FLAG_EE_COST)))) {
     sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
   }
   int ndev = 0;
@@ -1043,13 +1068,17 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   s.batch = B; s.d = d; s.T = T; s.K = K; s.O = O; s.R = R; s.n_x = n_x; s.n_slack = n_slack; s.n = n;
   s.m_lin = m_lin; s.m_nl = m_nl; s.m = m; s.prox_count = desc->prox_count > 0 ? desc->prox_count : 1;
   s.analytic_jac = desc->analytic_jac; s.trace_cap = 64;
-  s.point = (desc->family & 15) == SCO_FAM_POINT_CIRCLES ? 1 : 0;
+  s.point = (desc->family & 15) == SCO_FAM_POINT_CIRCLES ? 1 : (desc->family & 15) == SCO_FAM_STATE_QUADRATIC ? 2 : 0;
   s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE) + (cost ? 1 : 0);     // + the objective term's value
   s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl; s.cost = cost ? 1 : 0;
   int rc = 0;
 #define AL(f, cnt) if ((rc = sq_alloc(h, (cnt), &s.f))) return rc;
   AL(x0, (size_t)B * n_x) AL(start, (size_t)B * d) AL(goal, (size_t)B * d) AL(link_len, (size_t)B * d)
   AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2) AL(vmax, (size_t)B) AL(jlo, (size_t)B * d) AL(jhi, (size_t)B * d)
+  {
+    const bool quadf = (desc->family & 15) == SCO_FAM_STATE_QUADRATIC;
+    AL(qQ, quadf ? (size_t)B * O * d * d : 1) AL(qa, quadf ? (size_t)B * O * d : 1) AL(qc, quadf ? (size_t)B * O : 1)
+  }
   AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
   AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
   AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, SQP_MAX_GROUPS) AL(newqp, (size_t)B) AL(list_buf, (size_t)B)
@@ -1171,6 +1200,24 @@ extern "C" int sco_sqp_load_joint_limits(sco_sqp *h, const double *lo, const dou
   SCO_HIP(hipMemcpyAsync(h->d.jhi, hi, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
   SCO_HIP(hipStreamSynchronize(h->stream));
   h->jl_loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_load_quadratic(sco_sqp *h, const double *Q, const double *a, const double *c) {
+  if (!h || !Q || !a || !c) { sco_set_error("sco_sqp_load_quadratic: null pointer"); return SCO_ERR_ARG; }
+  if ((h->desc.family & 15) != SCO_FAM_STATE_QUADRATIC) { sco_set_error("sco_sqp_load_quadratic: family has no quadratic rows"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_load_quadratic: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  const size_t B = h->d.batch, O = h->d.O, d = h->d.d;
+  for (size_t k = 0; k < B * O; k++)
+    for (size_t i = 0; i < d; i++)
+      for (size_t j = 0; j < i; j++)
+        if (Q[k * d * d + i * d + j] != Q[k * d * d + j * d + i]) { sco_set_error("sco_sqp_load_quadratic: Q must be symmetric"); return SCO_ERR_ARG; }
+  SCO_ON_DEVICE(h->device);
+  SCO_HIP(hipMemcpyAsync(h->d.qQ, Q, B * O * d * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync(h->d.qa, a, B * O * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipMemcpyAsync(h->d.qc, c, B * O * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  SCO_HIP(hipStreamSynchronize(h->stream));
+  h->quad_loaded = true; h->solved = false;
   return SCO_OK;
 }
 
@@ -1322,6 +1369,9 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   }
   if ((h->desc.family & SCO_FAM_FLAG_JOINT_LIMITS) && !h->jl_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_joint_limits first"); return SCO_ERR_STATE;
+  }
+  if ((h->desc.family & 15) == SCO_FAM_STATE_QUADRATIC && !h->quad_loaded) {
+    sco_set_error("sco_sqp_solve: call sco_sqp_load_quadratic first"); return SCO_ERR_STATE;
   }
   h->solved = false;            // a failed call must not leave an older result readable through fetch / trace
   // settings are checked before the first launch: nothing on the device is touched by a call that is going to fail

@@ -104,6 +104,18 @@ def point_dist_jac(x, obstacles):
     return J
 
 
+def quad_rows(x, Q, a, c):
+    """SCO_FAM_STATE_QUADRATIC: g (R,) with g[r] = 1/2 x' Q_r x + a_r' x + c_r."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    return 0.5 * np.einsum("i,rij,j->r", x, Q, x) + a @ x + c
+
+
+def quad_rows_jac(x, Q, a, c):
+    """Analytic Jacobian (R, d) of quad_rows (Q_r symmetric)."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    return a + np.einsum("rij,j->ri", Q, x)
+
+
 def velocity_rows(d, T):
     """V (2 d (T-1), d T): rows theta[t+1][j] - theta[t][j] (t-major), then their negatives."""
     D = np.zeros((d * (T - 1), d * T))
@@ -182,11 +194,52 @@ def make_point_problem(i, d=2, T=20, O=3, noise=0.03, groups=None, vel_limit=Non
     return out
 
 
+def make_quadratic_problem(i, d=2, T=20, O=3, noise=0.03, groups=None, vel_limit=None, joint_limit=None):
+    """Seeded problem i of the quadratic-row family (SCO_FAM_STATE_QUADRATIC): a state x_t in R^d moves from start to goal;
+    per timestep O rows 1/2 x' Q_r x + a_r' x + c_r <= 0: keep-OUT ellipsoids on the straight path (concave rows,
+    1 - (x - m)' M (x - m) <= 0), for O >= 3 the last row a keep-IN ball around the path's midpoint (convex) and for O >= 4
+    the row before it a half-space.  Same dictionary layout as make_problem (K = 1; link data and obstacles are placeholders)."""
+    rng = np.random.default_rng(7000 + i)
+    start = rng.uniform(-1.0, 1.0, size=d)
+    goal = -start + 0.3 * rng.standard_normal(d)
+    s = np.linspace(0.0, 1.0, T)[:, None]
+    x0 = (1 - s) * start[None, :] + s * goal[None, :] + noise * rng.standard_normal((T, d))
+    Q = np.zeros((O, d, d)); a = np.zeros((O, d)); c = np.zeros(O)
+    n_out = O - (1 if O >= 3 else 0) - (1 if O >= 4 else 0)
+    along = np.sort(rng.uniform(0.25, 0.75, size=n_out))
+    for r in range(n_out):
+        m = (1 - along[r]) * start + along[r] * goal + 0.06 * rng.standard_normal(d)
+        axes = rng.uniform(0.1, 0.25, size=d)                         # semi-axes of the keep-out ellipsoid
+        R_, _ = np.linalg.qr(rng.standard_normal((d, d)))
+        M = R_ @ np.diag(1.0 / axes ** 2) @ R_.T
+        M = 0.5 * (M + M.T)
+        Q[r] = -2.0 * M; a[r] = 2.0 * M @ m; c[r] = 1.0 - m @ M @ m    # 1 - (x - m)' M (x - m)
+    if O >= 4:                                                          # half-space n' x <= n' mid + 0.6
+        nrm = rng.standard_normal(d); nrm /= np.linalg.norm(nrm)
+        a[O - 2] = nrm; c[O - 2] = -(nrm @ (0.5 * (start + goal)) + 0.6)
+    if O >= 3:                                                          # keep-in ball |x - mid|^2 <= rad^2
+        mid = 0.5 * (start + goal); rad = 0.75 * np.linalg.norm(goal - start) + 0.4
+        Q[O - 1] = 2.0 * np.eye(d); a[O - 1] = -2.0 * mid; c[O - 1] = mid @ mid - rad ** 2
+    out = dict(d=d, T=T, K=1, O=O, x0=x0.ravel(), start=start, goal=goal, link_len=np.ones(d),
+               point_link=np.zeros(1, dtype=np.int32), point_frac=np.ones(1), obstacles=np.zeros((O, 3)), reach=False,
+               quad_Q=Q, quad_a=a, quad_c=c)
+    if groups is not None:
+        out["groups"] = block_groups(T, False, groups)
+    if vel_limit is not None:
+        out["vmax"] = float(vel_limit)
+    if joint_limit is not None:
+        out["jlo"] = np.minimum(start, goal) - float(joint_limit)
+        out["jhi"] = np.maximum(start, goal) + float(joint_limit)
+    return out
+
+
 def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None,
-                 ee_cost_weight=None, point=False):
+                 ee_cost_weight=None, point=False, quadratic=False):
     """Seeded problem i of the batch.  reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
+    if quadratic:
+        return make_quadratic_problem(i, d=d, T=T, O=O, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
     if point:
         return make_point_problem(i, d=d, T=T, O=O, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
     is_reach = bool(reach)
@@ -233,6 +286,9 @@ def make_batch(B, first=0, **kw):
     extra = dict(reach=True, target=np.stack([p["target"] for p in probs])) if p0.get("reach") else {}
     if p0.get("point"):
         extra["point"] = True
+    if p0.get("quad_Q") is not None:
+        extra["quad_Q"] = np.stack([p["quad_Q"] for p in probs]); extra["quad_a"] = np.stack([p["quad_a"] for p in probs])
+        extra["quad_c"] = np.stack([p["quad_c"] for p in probs])
     if p0.get("groups") is not None:
         extra["groups"] = p0["groups"]
     if p0.get("vmax") is not None:

@@ -411,3 +411,38 @@ def test_mirror_api_reproduces_reference_for_the_point_robot_family(oracle_qp_ba
         assert [a["status"] for a in gold] == [r["status"] for r in oracle_qp_backend]
         assert ok == bool(g[prefix + "success"])
         assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 1e-9
+
+
+def _quad_cases():
+    import sys
+    sys.path.insert(0, GOLD)
+    from quad_cases import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("case", _quad_cases(), ids=lambda c: c[0])
+def test_flat_oracle_reproduces_reference_for_the_quadratic_row_family(case):
+    """SCO_FAM_STATE_QUADRATIC (rows 1/2 x' Q x + a' x + c on the state of a timestep: keep-out ellipsoids, a half-space,
+    a keep-in ball): every QP the reference assembled for it, the statuses, iteration counts and the answer."""
+    prefix, kw, i = case
+    g = np.load(os.path.join(GOLD, "trajopt_quad.npz"))
+    pr = af.make_problem(i, **kw)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr), record_qps=True)
+    _compare_sequence(ct.load_golden_qps(g, prefix), out.qps, prefix)
+    assert out.success == bool(g[prefix + "success"])
+    assert np.abs(out.x - g[prefix + "x"]).max() < 1e-9
+    assert abs(out.max_violation - float(g[prefix + "max_violation"])) < 1e-9
+
+
+def test_mirror_api_reproduces_reference_for_the_quadratic_row_family(oracle_qp_backend):
+    g = np.load(os.path.join(GOLD, "trajopt_quad.npz"))
+    for prefix, kw, i in _quad_cases()[1:3] + _quad_cases()[4:5]:
+        del oracle_qp_backend[:]
+        mods = ct.mirror_mods()
+        prob, traj, _, _ = tb.build_prob(mods, af.make_problem(i, **kw))
+        ok = mods.Solver().solve(prob, method="penalty_sqp")
+        gold = ct.load_golden_qps(g, prefix)
+        assert [a["iters"] for a in gold] == [r["iters"] for r in oracle_qp_backend]
+        assert [a["status"] for a in gold] == [r["status"] for r in oracle_qp_backend]
+        assert ok == bool(g[prefix + "success"])
+        assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 1e-9

@@ -650,6 +650,65 @@ def test_point_robot_family_descriptor_rules(gpu):
                             ee_cost=bool(kw.get("ee_cost")))
 
 
+def test_quadratic_row_family_matches_oracle(gpu):
+    """SCO_FAM_STATE_QUADRATIC: general quadratic rows on the state of a timestep (keep-out ellipsoids = concave rows, a
+    half-space, a keep-in ball; no kinematics), numeric and analytic Jacobians, with velocity limits, a box and groups, in 2
+    to 5 dimensions; a batch above the CU count runs under round selection."""
+    for kw, analytic in ((dict(d=2, T=8, O=3), False), (dict(d=2, T=8, O=3), True), (dict(d=3, T=6, O=4), False),
+                         (dict(d=5, T=5, O=4), False), (dict(d=2, T=8, O=3, vel_limit=0.5), False),
+                         (dict(d=2, T=8, O=3, joint_limit=0.2, groups="halves"), False)):
+        arrays, probs = af.make_batch(8, K=1, quadratic=True, **kw)
+        res = sb.solve_batch(arrays, analytic_jac=analytic)
+        _compare(res, probs, range(8), analytic=analytic)
+    arrays, probs = af.make_batch(280, d=2, T=12, K=1, O=3, quadratic=True)
+    res = sb.solve_batch(arrays)
+    _compare(res, probs, range(0, 280, 41))
+    for b in np.nonzero(res.success)[0][:40]:                                     # success = every row satisfied
+        x = res.x[b].reshape(12, 2)
+        g = np.array([af.quad_rows(x[t], arrays["quad_Q"][b], arrays["quad_a"][b], arrays["quad_c"][b]) for t in range(12)])
+        assert g.max() < 1e-3
+
+
+def test_quadratic_row_family_matches_reference_golden_runs(gpu):
+    import sys
+    sys.path.insert(0, GOLD)
+    from quad_cases import CASES
+    g = np.load(os.path.join(GOLD, "trajopt_quad.npz"))
+    for prefix, kw, i in CASES:
+        arrays, _ = af.make_batch(1, first=i, **kw)
+        res = sb.solve_batch(arrays)
+        assert np.abs(res.x[0] - g[prefix + "x"]).max() < TOL, prefix
+        assert bool(res.success[0]) == bool(g[prefix + "success"]), prefix
+        nq = int(g[prefix + "n_qp"])
+        assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix
+        assert [int(v) for v in res.trace[0][:, 7]] == [int(g["%sqp%d_iters" % (prefix, k)]) for k in range(nq)], prefix
+
+
+def test_quadratic_row_family_call_order_and_validation(gpu):
+    arrays, _ = af.make_batch(2, d=2, T=6, K=1, O=3, quadratic=True)
+    with sb.TrajOptBatch(2, 2, 6, 1, 3, quadratic=True) as tb:
+        with pytest.raises(ValueError):
+            tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                    arrays["point_frac"], arrays["obstacles"])                    # coefficients missing
+        lib = _lib.load()
+        tb2 = sb.TrajOptBatch(2, 2, 6, 1, 3, quadratic=True)
+        assert lib.sco_sqp_load(tb2._h, _lib.dptr(arrays["x0"]), _lib.dptr(arrays["start"]), _lib.dptr(arrays["goal"]),
+                                _lib.dptr(arrays["link_len"]), _lib.iptr(arrays["point_link"]), _lib.dptr(arrays["point_frac"]),
+                                _lib.dptr(arrays["obstacles"])) == 0
+        with pytest.raises(_lib.ScoHipError):
+            tb2.solve()                                                           # sco_sqp_load_quadratic not called yet
+        Q = arrays["quad_Q"].copy(); Q[0, 0, 0, 1] += 1.0                         # not symmetric
+        assert lib.sco_sqp_load_quadratic(tb2._h, _lib.dptr(Q), _lib.dptr(arrays["quad_a"]), _lib.dptr(arrays["quad_c"])) != 0
+        tb2.close()
+    with sb.TrajOptBatch(2, 7, 6, 2, 2) as arm:                                   # an arm batch has no quadratic rows
+        assert _lib.load().sco_sqp_load_quadratic(arm._h, _lib.dptr(arrays["quad_Q"]), _lib.dptr(arrays["quad_a"]),
+                                                  _lib.dptr(arrays["quad_c"])) != 0
+    for bad in (dict(n_points=2), dict(dof=17)):
+        kw = dict(dof=2, n_points=1); kw.update(bad)
+        with pytest.raises(_lib.ScoHipError):
+            sb.TrajOptBatch(2, kw["dof"], 6, kw["n_points"], 3, quadratic=True)
+
+
 def test_joint_limits_7x20_batch_and_validation(gpu):
     arrays, probs = af.make_batch(4, joint_limit=0.2)
     res = sb.solve_batch(arrays)

@@ -60,6 +60,8 @@ def build_prob(mods, pr, analytic_jac=False):
         step_vars.append(sv)
 
         def f(x, pr=pr):
+            if pr.get("quad_Q") is not None:    # quadratic-row family
+                return af.quad_rows(x.ravel(), pr["quad_Q"], pr["quad_a"], pr["quad_c"]).reshape(-1, 1)
             if pr.get("point"):                 # point-robot family: distance of the point itself to the discs
                 return af.point_dist(x.ravel(), pr["obstacles"]).reshape(-1, 1)
             return af.arm_dist(x.ravel(), pr["link_len"], pr["point_link"], pr["point_frac"],
@@ -68,6 +70,8 @@ def build_prob(mods, pr, analytic_jac=False):
         grad = None
         if analytic_jac:
             def grad(x, pr=pr):
+                if pr.get("quad_Q") is not None:
+                    return af.quad_rows_jac(x.ravel(), pr["quad_Q"], pr["quad_a"], pr["quad_c"])
                 if pr.get("point"):
                     return af.point_dist_jac(x.ravel(), pr["obstacles"])
                 return af.arm_dist_jac(x.ravel(), pr["link_len"], pr["point_link"], pr["point_frac"],
