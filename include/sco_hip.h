@@ -172,9 +172,11 @@ typedef struct sco_sqp_params {
                                the solution of its previous one (sco_qp_settings.warm_start); beyond parity   */
   int admm_slice;           /* scheduling only, results are bit-identical: ADMM iterations per device launch.
                                Problems whose QP ends inside a slice go on to their next QP while the others
-                               continue (no waiting for the slowest QP of a round).  0 = default (6250; 2000
-                               with adaptive rho; off when the batch has at most one problem per CU),
-                               < 0 = off (one launch per QP, lock-step rounds)                               */
+                               continue (no waiting for the slowest QP of a round).  With more live problems
+                               than CUs a round runs whole passes of the chip as a compact launch over the problems
+                               with most in front of them, the others sit the round out.
+                               0 = default (6250; 2000 with adaptive rho; off when the batch has at most one
+                               problem per CU), < 0 = off (one launch per QP, lock-step rounds)              */
 } sco_sqp_params;
 
 void sco_sqp_default_params(sco_sqp_params *p);
