@@ -1,6 +1,9 @@
+"""Scheduling model of the rounds of one 1024-problem step on the measured per-problem QP chains (profiles/r02_qp_iters_1024.npy,
+written by scripts/gpu_dump_traces.py): 8 XCDs of 32 CUs, workgroup g on XCD g mod 8, one workgroup per CU, in-order dispatch.
+Compares lock-step rounds with whole-pass selection under several priorities.  No GPU needed."""
 import heapq, numpy as np
 US=1.014e-3; OVH=0.25; CUS=256; NX=8; CPX=CUS//NX
-a=np.load('gpurun_out/qp_iters_1024.npy')
+a=np.load('profiles/r02_qp_iters_1024.npy')
 chains=[[int(v) for v in row[1:] if v>0] for row in a]
 B=len(chains)
 tot=sum(sum(c) for c in chains); print("ideal",tot*US/CUS)
