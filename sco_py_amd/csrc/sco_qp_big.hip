@@ -869,9 +869,9 @@ struct BtPtrs {
   double alpha, sigma;
   double *v;                // pre-clamp value of every dense-chunk row (bt_row_step_v)
   const int *s_cflag;       // LDS: this problem's chunk flags (qp_setup_big_kernel), all zero if there are none
-  double rho0, wk;          // the constants the flags refer to: base rho, common weight
+  double rho0, wk, rinv0;   // the constants the flags refer to: base rho, common weight; 1 / base rho
 };
-struct BtRow { double zc, ae, rh, w, z, y, l, u; };
+struct BtRow { double zc, ae, rh, w, z, y, l, u, ri; };     // ri = 1 / rh (dense chunks: formed once per problem where rho is the base rho)
 // one row of the ADMM update; returns t_i = w (rho z+ - y+)
 __device__ __forceinline__ double bt_row_step(const BtRow &r, double alpha, double xte, double &zn, double &yn, double &dy) {
   const double zt = r.zc + r.ae * xte;
@@ -897,7 +897,7 @@ __device__ __forceinline__ double bt_ge(double sigma, double x, double qj, doubl
 __device__ __forceinline__ double bt_row_step_v(const BtRow &r, double alpha, double xte, double &zn, double &yn, double &dy, double &v) {
   const double zt = r.zc + r.ae * xte;
   const double zr = alpha * zt + (1.0 - alpha) * r.z;
-  v = zr + (1.0 / r.rh) * r.y;
+  v = zr + r.ri * r.y;
   zn = fmin(fmax(v, r.l), r.u);
   dy = r.rh * (zr - zn);
   yn = r.rh * (v - zn);
@@ -989,13 +989,13 @@ __device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int c
   else { vp = q.v[R.r0]; vs = q.v[R.r1]; }
   if (fl & 1) R.p.l = -SCO_INFTY; else if (fl & 2) R.p.l = 0.0; else R.p.l = q.ls[R.r0];
   if (fl & 4) R.p.u = SCO_INFTY; else R.p.u = q.us[R.r0];
-  if (fl & 8) R.p.rh = q.rho0; else R.p.rh = q.rho[R.r0];
+  if (fl & 8) { R.p.rh = q.rho0; R.p.ri = q.rinv0; } else { R.p.rh = q.rho[R.r0]; R.p.ri = 1.0 / R.p.rh; }
   if (fl & 16) R.p.w = 1.0; else if (fl & 32) R.p.w = q.wk; else R.p.w = (double)q.w[R.r0];
-  if (!R.two) { R.s.l = R.p.l; R.s.u = R.p.u; R.s.rh = R.p.rh; R.s.w = R.p.w; }      // r1 = r0: never used
+  if (!R.two) { R.s.l = R.p.l; R.s.u = R.p.u; R.s.rh = R.p.rh; R.s.ri = R.p.ri; R.s.w = R.p.w; }      // r1 = r0: never used
   else {
     if (fs & 1) R.s.l = -SCO_INFTY; else if (fs & 2) R.s.l = 0.0; else R.s.l = q.ls[R.r1];
     if (fs & 4) R.s.u = SCO_INFTY; else R.s.u = q.us[R.r1];
-    if (fs & 8) R.s.rh = q.rho0; else R.s.rh = q.rho[R.r1];
+    if (fs & 8) { R.s.rh = q.rho0; R.s.ri = q.rinv0; } else { R.s.rh = q.rho[R.r1]; R.s.ri = 1.0 / R.s.rh; }
     if (fs & 16) R.s.w = 1.0; else if (fs & 32) R.s.w = q.wk; else R.s.w = (double)q.w[R.r1];
   }
   if (!first) { bt_row_zy(R.p, vp); bt_row_zy(R.s, vs); }
@@ -1190,7 +1190,8 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   const double cscale = d.cscale[b], alpha = a.alpha, sigma = a.sigma;
   // v shares the storage of t': the start point's t' is only read by the prologue below
   const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, use_part ? s_part : nullptr, alpha, sigma,
-                  tp, s_cflag, a.per_problem_rho ? d.rho_b[b] : a.rho, a.ccon ? a.ccon[b] : 1.0};
+                  tp, s_cflag, a.per_problem_rho ? d.rho_b[b] : a.rho, a.ccon ? a.ccon[b] : 1.0,
+                  1.0 / (a.per_problem_rho ? d.rho_b[b] : a.rho)};
 
   {
     const double *blk = a.bt_blk + (size_t)b * a.bt_stride;
