@@ -12,6 +12,8 @@ for tok in sys.argv[4:]:                                         # reach, vel, g
     if tok == "vel": KW["vel_limit"] = 0.4
     if tok == "groups": KW["groups"] = "split"
     if tok == "jl": KW["joint_limit"] = 0.2
+    if tok == "point": KW.update(point=True, d=2, T=20, K=1, O=3)
+    if tok == "quad": KW.update(quadratic=True, d=3, T=12, K=1, O=4)
 
 
 def ref_one(i):
