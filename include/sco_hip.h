@@ -200,6 +200,27 @@ void sco_sqp_default_params(sco_sqp_params *p);
                                   (sco_sqp_load_quadratic), Q_r symmetric and of either sign -- keep-out ellipses, keep-in
                                   discs, half-planes, products of coordinates ...; dof <= 16, n_points must be 1; link_len /
                                   point_* / obstacles of sco_sqp_load are not read.  Flags as for SCO_FAM_POINT_CIRCLES */
+#define SCO_FAM_STATE_PROGRAM 5 /* closed-form rows given as small postfix programs over the state of a timestep and a
+                                  per-problem parameter vector (sco_sqp_load_program) -- what the reference's Expr(f) is for
+                                  any f one can write down with + - * / sin cos sqrt exp: n_obstacles rows g[r](x, p) <= 0 per
+                                  timestep, Jacobians by the device's central differences (analytic_jac must be 0); dof <= 16,
+                                  n_points must be 1.  Flags as for SCO_FAM_POINT_CIRCLES.
+                                  Program words are pairs (op, arg): */
+#define SCO_OP_END 0      /* end of a row's program: its value is the one number left on the stack */
+#define SCO_OP_X 1        /* push x[arg] (state coordinate)        */
+#define SCO_OP_P 2        /* push params[problem][arg]             */
+#define SCO_OP_C 3        /* push consts[arg]                      */
+#define SCO_OP_ADD 4      /* a b -> a + b                          */
+#define SCO_OP_SUB 5      /* a b -> a - b                          */
+#define SCO_OP_MUL 6      /* a b -> a * b                          */
+#define SCO_OP_DIV 7      /* a b -> a / b                          */
+#define SCO_OP_NEG 8      /* a -> -a                               */
+#define SCO_OP_SIN 9
+#define SCO_OP_COS 10
+#define SCO_OP_SQRT 11
+#define SCO_OP_EXP 12
+#define SCO_OP_SQUARE 13  /* a -> a * a                            */
+#define SCO_PROGRAM_STACK 16   /* deepest stack a row's program may need */
 
 /* Structure of a batch of trajectory problems (shared by all `batch` problems):
  * variables theta[t][j], t < horizon, j < dof, flattened time-major (n_x = horizon*dof);
@@ -256,6 +277,11 @@ int sco_sqp_load_target(sco_sqp *h, const double *target);
 /* SCO_FAM_STATE_QUADRATIC only, after sco_sqp_load: Q[batch][n_obstacles][dof*dof] (symmetric), a[batch][n_obstacles][dof],
  * c[batch][n_obstacles]. */
 int sco_sqp_load_quadratic(sco_sqp *h, const double *Q, const double *a, const double *c);
+/* SCO_FAM_STATE_PROGRAM only, after sco_sqp_load: row r's program is words[2 * row_ptr[r] .. 2 * row_ptr[r+1]) as (op, arg)
+ * pairs, the last one SCO_OP_END (row_ptr[n_obstacles] = n_words); consts[n_consts]; params[batch][n_params]
+ * (n_params may be 0).  The programs are checked (stack depth, indices) before anything is uploaded. */
+int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts, const double *consts,
+                         int n_params, const double *params);
 /* SCO_FAM_FLAG_VEL_LIMITS only, after sco_sqp_load: vmax[batch] > 0, one limit per problem. */
 int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax);
 /* SCO_FAM_FLAG_JOINT_LIMITS only, after sco_sqp_load: lo[batch][dof] < hi[batch][dof]. */

@@ -5,5 +5,6 @@ sco_py_amd/workloads.py (shared by bench.py, the tests and this oracle: the prod
 never imports oracle/, the oracle may import the product's input generator).  This
 module only re-exports them under the name the oracle and the golden generators use."""
 from sco_py_amd.workloads import (arm_dist, arm_dist_jac, block_groups, default_points, ee_cost, ee_jac, ee_pos,  # noqa: F401
-                                  joint_limit_rows, link_points, make_batch, make_point_problem, make_problem, make_quadratic_problem,
+                                  joint_limit_rows, link_points, make_batch, corridor_program, make_point_problem, make_problem,
+                                  make_program_problem, make_quadratic_problem,
                                   point_dist, point_dist_jac, quad_rows, quad_rows_jac, velocity_rows)

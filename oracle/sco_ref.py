@@ -503,7 +503,10 @@ def trajopt_flat(prob, analytic_jac=False):
     blocks = []
     R = prob["K"] * prob["O"]
     for t in range(T):
-        if prob.get("quad_Q") is not None:      # SCO_FAM_STATE_QUADRATIC: general quadratic rows on the state
+        if prob.get("row_program") is not None:  # SCO_FAM_STATE_PROGRAM: closed-form rows (numeric Jacobian only)
+            f = prob["row_program"].numpy_fn(prob["row_params"])
+            jac = None
+        elif prob.get("quad_Q") is not None:    # SCO_FAM_STATE_QUADRATIC: general quadratic rows on the state
             f = (lambda th, pr=prob: af.quad_rows(th, pr["quad_Q"], pr["quad_a"], pr["quad_c"]))
             jac = (lambda th, pr=prob: af.quad_rows_jac(th, pr["quad_Q"], pr["quad_a"], pr["quad_c"])) if analytic_jac else None
         elif prob.get("point"):                 # SCO_FAM_POINT_CIRCLES: a point robot, K = 1
@@ -512,7 +515,7 @@ def trajopt_flat(prob, analytic_jac=False):
         else:
             f = (lambda th, pr=prob: af.arm_dist(th, pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"]))
             jac = None
-        if analytic_jac and not prob.get("point") and prob.get("quad_Q") is None:
+        if analytic_jac and not prob.get("point") and prob.get("quad_Q") is None and prob.get("row_program") is None:
             jac = (lambda th, pr=prob: af.arm_dist_jac(th, pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"]))
         blocks.append(Block("leq", f, np.arange(t * d, (t + 1) * d), np.zeros(R), jac=jac,
                             groups=prob["groups"][t] if prob.get("groups") is not None else None))

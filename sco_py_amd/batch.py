@@ -19,6 +19,7 @@ SCO_FAM_ARM_CIRCLES = 1
 SCO_FAM_ARM_REACH = 2
 SCO_FAM_POINT_CIRCLES = 3
 SCO_FAM_STATE_QUADRATIC = 4
+SCO_FAM_STATE_PROGRAM = 5
 SCO_FAM_FLAG_VEL_LIMITS = 16
 SCO_FAM_FLAG_JOINT_LIMITS = 32
 SCO_FAM_FLAG_EE_COST = 64
@@ -41,7 +42,9 @@ class TrajOptBatch(object):
     ``point=True``: SCO_FAM_POINT_CIRCLES, a point robot in the plane (state of a timestep: dof >= 2 numbers, the first
     two its position; n_points = 1; link data are not read) instead of the arm; ``quadratic=True``:
     SCO_FAM_STATE_QUADRATIC, n_obstacles rows 1/2 x' Q_r x + a_r' x + c_r <= 0 on the state of every timestep with
-    per-problem coefficients (``load(..., quad_Q=, quad_a=, quad_c=)``))
+    per-problem coefficients (``load(..., quad_Q=, quad_a=, quad_c=)``); ``program=True``: SCO_FAM_STATE_PROGRAM, rows
+    given as closed-form expressions over the state and a per-problem parameter vector, compiled by
+    ``sco_py_amd.rowexpr.compile_rows`` (``load(..., row_program=, row_params=)``))
     solved per problem exactly like ``Solver().solve(prob, method="penalty_sqp")``.
     ``prox_count`` says how many Variables hold each atom in the equivalent object-API
     construction (it scales the projection QP of find_closest_feasible_point,
@@ -51,7 +54,7 @@ class TrajOptBatch(object):
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
                  prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False, point=False,
-                 quadratic=False):
+                 quadratic=False, program=False):
         self.B, self.d, self.T, self.K, self.O = int(batch), int(dof), int(horizon), int(n_points), int(n_obstacles)
         self.n_x = self.d * self.T
         self.device = int(device)
@@ -64,10 +67,14 @@ class TrajOptBatch(object):
         self.quadratic = bool(quadratic)   # SCO_FAM_STATE_QUADRATIC: n_obstacles general quadratic rows per timestep
         if (self.point or self.quadratic) and (self.reach or self.ee_cost):
             raise ValueError("the point-robot and quadratic-row families have neither the reach equality nor the objective term")
-        if self.point and self.quadratic:
-            raise ValueError("one family per batch")
+        self.program = bool(program)       # SCO_FAM_STATE_PROGRAM: rows as closed-form programs (sco_py_amd.rowexpr)
+        if sum((self.point, self.quadratic, self.program)) > 1 or (self.program and (self.reach or self.ee_cost)):
+            raise ValueError("one family per batch; the program family has neither the reach equality nor the objective term")
+        if self.program and analytic_jac:
+            raise ValueError("program rows are differentiated numerically")
         desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O,
-                                (SCO_FAM_STATE_QUADRATIC if self.quadratic else SCO_FAM_POINT_CIRCLES if self.point else
+                                (SCO_FAM_STATE_PROGRAM if self.program else SCO_FAM_STATE_QUADRATIC if self.quadratic else
+                                 SCO_FAM_POINT_CIRCLES if self.point else
                                  SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES) |
                                 (SCO_FAM_FLAG_VEL_LIMITS if self.vel_limits else 0) |
                                 (SCO_FAM_FLAG_JOINT_LIMITS if self.joint_limits else 0) |
@@ -93,7 +100,8 @@ class TrajOptBatch(object):
         self.close()
 
     def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles, target=None, vmax=None,
-             jlo=None, jhi=None, cost_weight=None, cost_target=None, quad_Q=None, quad_a=None, quad_c=None):
+             jlo=None, jhi=None, cost_weight=None, cost_target=None, quad_Q=None, quad_a=None, quad_c=None,
+             row_program=None, row_params=None):
         """Upload per-problem data (host arrays, copied).  ``target`` (B, 2): end-effector
         position of the reach variant (``goal`` is then ignored by the device)."""
         B, d, K, O = self.B, self.d, self.K, self.O
@@ -115,6 +123,18 @@ class TrajOptBatch(object):
                 raise ValueError("the quadratic-row family needs quad_Q (B, O, d, d), quad_a (B, O, d), quad_c (B, O)")
             qQ = arr(quad_Q, (B, O, d, d)); qa = arr(quad_a, (B, O, d)); qc = arr(quad_c, (B, O))
             _lib.check(_lib.load().sco_sqp_load_quadratic(self._h, _lib.dptr(qQ), _lib.dptr(qa), _lib.dptr(qc)))
+        if self.program:
+            if row_program is None:
+                raise ValueError("the program family needs row_program (sco_py_amd.rowexpr.compile_rows) and row_params (B, n_params)")
+            if row_program.n_rows != O or row_program.n_state > d:
+                raise ValueError("the program has %d rows over %d state coordinates; the batch has %d rows per timestep and dof %d"
+                                 % (row_program.n_rows, row_program.n_state, O, d))
+            npar = row_program.n_params
+            par = arr(row_params if row_params is not None else np.zeros((B, 0)), (B, npar)) if npar else np.zeros((B, 0))
+            _lib.check(_lib.load().sco_sqp_load_program(
+                self._h, len(row_program.words), _lib.iptr(np.ascontiguousarray(row_program.words.ravel())), _lib.iptr(row_program.row_ptr),
+                len(row_program.consts), _lib.dptr(row_program.consts) if len(row_program.consts) else None,
+                npar, _lib.dptr(par) if npar else None))
         if self.reach:
             if target is None:
                 raise ValueError("the reach variant needs target (B, 2)")
@@ -206,11 +226,13 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
     with TrajOptBatch(a["B"], a["d"], a["T"], a["K"], a["O"], device=device, analytic_jac=analytic_jac,
                       prox_count=prox_count, reach=bool(a.get("reach")), vel_limits=a.get("vmax") is not None,
                       joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
-                      point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None) as tb:
+                      point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None,
+                      program=a.get("row_program") is not None) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                 target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
                 cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),
-                quad_Q=a.get("quad_Q"), quad_a=a.get("quad_a"), quad_c=a.get("quad_c"))
+                quad_Q=a.get("quad_Q"), quad_a=a.get("quad_a"), quad_c=a.get("quad_c"),
+                row_program=a.get("row_program"), row_params=a.get("row_params"))
         if a.get("groups") is not None:
             tb.set_groups(a["groups"])
         tb.solve(params, qp_settings)

@@ -62,6 +62,8 @@ struct SqpDev {
   int point;         // 1 SCO_FAM_POINT_CIRCLES: the rows are distances of the point x[0:2] itself (no arm kinematics);
                      // 2 SCO_FAM_STATE_QUADRATIC: general quadratic rows with the coefficients below
   double *qQ, *qa, *qc;   // [B][O][d*d], [B][O][d], [B][O]
+                     // 3 SCO_FAM_STATE_PROGRAM: rows as postfix programs (shared) over the state and per-problem parameters
+  const int *pw, *pptr; const double *pconst; const double *ppar; int n_par;
   // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows, then m_jl joint-limit
   // rows (theta <= hi for every trajectory variable, then -theta <= -lo)
   int m_pin, m_vel, m_jl;
@@ -117,7 +119,7 @@ struct sco_sqp {
   int groups_used = 1;
   std::vector<void *> allocs;
   std::vector<hipEvent_t> events;
-  bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false, cost_loaded = false, quad_loaded = false;
+  bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false, cost_loaded = false, quad_loaded = false, prog_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   int rounds = 0;          // 1 (projection) + the rounds of the group that needed most
   int launches = 0;        // round launches over all stream groups
@@ -291,12 +293,37 @@ __device__ __forceinline__ RowRef row_ref(int e, int T, int R) {
 }
 
 struct RowCtx { const double *len, *obs, *target; const int *point_link; const double *point_frac; int d, O, point;
-                const double *qQ, *qa, *qc; };      // SCO_FAM_STATE_QUADRATIC: this problem's row coefficients (point == 2)
+                const double *qQ, *qa, *qc;         // SCO_FAM_STATE_QUADRATIC: this problem's row coefficients (point == 2)
+                const int *pw, *pptr; const double *pconst, *ppar; };   // SCO_FAM_STATE_PROGRAM (point == 3): words, row starts, constants, this problem's parameters
 // f of row q at th (the raw function value: the right-hand side val is 0 for hinge rows and
 // target[r] for equality rows and is applied by the callers, in the reference's order)
 __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, const double *th, int pert, double h) {
   if (q.eq) return arm_ee(th, c.len, c.d, q.r, pert, h);
   const int kp = q.r / c.O, o = q.r % c.O;
+  if (c.point == 3) {                          // SCO_FAM_STATE_PROGRAM: the row's postfix program
+    double st[SCO_PROGRAM_STACK];
+    int sp = 0;
+    for (int w = c.pptr[o];; w++) {
+      const int op = c.pw[2 * w], arg = c.pw[2 * w + 1];
+      if (op == SCO_OP_END) break;
+      switch (op) {
+        case SCO_OP_X: st[sp++] = th[arg] + (arg == pert ? h : 0.0); break;
+        case SCO_OP_P: st[sp++] = c.ppar[arg]; break;
+        case SCO_OP_C: st[sp++] = c.pconst[arg]; break;
+        case SCO_OP_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+        case SCO_OP_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+        case SCO_OP_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+        case SCO_OP_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+        case SCO_OP_NEG: st[sp - 1] = -st[sp - 1]; break;
+        case SCO_OP_SIN: st[sp - 1] = sin(st[sp - 1]); break;
+        case SCO_OP_COS: st[sp - 1] = cos(st[sp - 1]); break;
+        case SCO_OP_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
+        case SCO_OP_EXP: st[sp - 1] = exp(st[sp - 1]); break;
+        default: st[sp - 1] = st[sp - 1] * st[sp - 1]; break;       // SCO_OP_SQUARE
+      }
+    }
+    return st[0];
+  }
   if (c.point == 2) {                          // SCO_FAM_STATE_QUADRATIC: 1/2 x' Q x + a' x + c of row o
     const double *Q = c.qQ + (size_t)o * c.d * c.d, *av = c.qa + (size_t)o * c.d;
     double val = c.qc[o];
@@ -317,6 +344,7 @@ __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, co
 __device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, const double *th, int j) {
   if (q.eq) return arm_ee_grad(th, c.len, c.d, q.r, j);
   const int kp = q.r / c.O, o = q.r % c.O;
+  if (c.point == 3) return 0.0;                // programs are differentiated numerically (sco_sqp_create refuses analytic_jac)
   if (c.point == 2) {                          // a_j + sum_i Q_ji x_i  (Q symmetric)
     const double *Q = c.qQ + (size_t)o * c.d * c.d;
     double g = c.qa[(size_t)o * c.d + j];
@@ -500,7 +528,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     __shared__ int ev_hit[260], cv_hit[260];
     const int H = s.H, HC = s.HC, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
     const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point,
-                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O};
+                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O,
+                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par};
     double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
     double *ckey = s.ckey + (size_t)b * NB * HC * d, *cJ = s.cJ + (size_t)b * NB * HC * RM * d, *cb = s.cb + (size_t)b * NB * HC * RM;
     int *hn = s.hn + (size_t)b * NB, *cn = s.cn + (size_t)b * NB;
@@ -755,7 +784,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   __shared__ int ev_hit[260];
   const int H = s.H, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
   const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point,
-                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O};
+                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O,
+                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par};
   double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
   int *hn = s.hn + (size_t)b * NB;
   for (int t = tid; t < NB; t += SCO_BLOCK)
@@ -910,7 +940,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *
   const double *len = s.link_len + (size_t)b * d;
   const double *obs = s.obstacles + (size_t)b * O * 3;
   const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point,
-                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O};
+                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O,
+                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par};
   double v[3] = {traj_obj_partial(x, d, T, tid), 0.0, 0.0};
   if (s.cost)
     for (int t = tid; t < T; t += SCO_BLOCK)
@@ -955,9 +986,11 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
       desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS | SCO_FAM_FLAG_EE_COST)) ||
       ((desc->family & SCO_FAM_FLAG_EE_COST) && desc->dof > OBJ_DMAX) ||
       ((desc->family & 15) != SCO_FAM_ARM_CIRCLES && (desc->family & 15) != SCO_FAM_ARM_REACH && (desc->family & 15) != SCO_FAM_POINT_CIRCLES &&
-       (desc->family & 15) != SCO_FAM_STATE_QUADRATIC) ||
+       (desc->family & 15) != SCO_FAM_STATE_QUADRATIC && (desc->family & 15) != SCO_FAM_STATE_PROGRAM) ||
       ((desc->family & 15) == SCO_FAM_POINT_CIRCLES && (desc->n_points != 1 || desc->dof < 2 || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
-      ((desc->family & 15) == SCO_FAM_STATE_QUADRATIC && (desc->n_points != 1 || desc->dof > OBJ_DMAX || (desc->family & SCO_FAM_FLAG_EE_COST)))) {
+      ((desc->family & 15) == SCO_FAM_STATE_QUADRATIC && (desc->n_points != 1 || desc->dof > OBJ_DMAX || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
+      ((desc->family & 15) == SCO_FAM_STATE_PROGRAM && (desc->n_points != 1 || desc->dof > OBJ_DMAX || desc->analytic_jac ||
+                                                        (desc->family & SCO_FAM_FLAG_EE_COST)))) {
     sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
   }
   int ndev = 0;
@@ -1068,7 +1101,8 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   s.batch = B; s.d = d; s.T = T; s.K = K; s.O = O; s.R = R; s.n_x = n_x; s.n_slack = n_slack; s.n = n;
   s.m_lin = m_lin; s.m_nl = m_nl; s.m = m; s.prox_count = desc->prox_count > 0 ? desc->prox_count : 1;
   s.analytic_jac = desc->analytic_jac; s.trace_cap = 64;
-  s.point = (desc->family & 15) == SCO_FAM_POINT_CIRCLES ? 1 : (desc->family & 15) == SCO_FAM_STATE_QUADRATIC ? 2 : 0;
+  s.point = (desc->family & 15) == SCO_FAM_POINT_CIRCLES ? 1 : (desc->family & 15) == SCO_FAM_STATE_QUADRATIC ? 2 :
+            (desc->family & 15) == SCO_FAM_STATE_PROGRAM ? 3 : 0;
   s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE) + (cost ? 1 : 0);     // + the objective term's value
   s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl; s.cost = cost ? 1 : 0;
   int rc = 0;
@@ -1221,6 +1255,51 @@ extern "C" int sco_sqp_load_quadratic(sco_sqp *h, const double *Q, const double 
   return SCO_OK;
 }
 
+extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts, const double *consts,
+                                    int n_params, const double *params) {
+  if (!h || !words || !row_ptr || (n_consts > 0 && !consts) || (n_params > 0 && !params)) {
+    sco_set_error("sco_sqp_load_program: null pointer"); return SCO_ERR_ARG;
+  }
+  if ((h->desc.family & 15) != SCO_FAM_STATE_PROGRAM) { sco_set_error("sco_sqp_load_program: family has no row programs"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_load_program: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  const int R = h->d.O, d = h->d.d;
+  if (n_words <= 0 || n_consts < 0 || n_params < 0 || row_ptr[0] != 0 || row_ptr[R] != n_words) {
+    sco_set_error("sco_sqp_load_program: bad program layout"); return SCO_ERR_ARG;
+  }
+  // every row's program is run on the host once, symbolically: stack depth and operand indices
+  for (int r = 0; r < R; r++) {
+    if (row_ptr[r + 1] <= row_ptr[r] || words[2 * (row_ptr[r + 1] - 1)] != SCO_OP_END) {
+      sco_set_error("sco_sqp_load_program: a row's program must end with SCO_OP_END"); return SCO_ERR_ARG;
+    }
+    int sp = 0;
+    for (int w = row_ptr[r]; w < row_ptr[r + 1] - 1; w++) {
+      const int op = words[2 * w], arg = words[2 * w + 1];
+      bool ok = true;
+      if (op == SCO_OP_X) { ok = arg >= 0 && arg < d; sp++; }
+      else if (op == SCO_OP_P) { ok = arg >= 0 && arg < n_params; sp++; }
+      else if (op == SCO_OP_C) { ok = arg >= 0 && arg < n_consts; sp++; }
+      else if (op >= SCO_OP_ADD && op <= SCO_OP_DIV) { ok = sp >= 2; sp--; }
+      else if (op >= SCO_OP_NEG && op <= SCO_OP_SQUARE) ok = sp >= 1;
+      else ok = false;
+      if (!ok || sp > SCO_PROGRAM_STACK) { sco_set_error("sco_sqp_load_program: malformed program (operand index, stack depth or opcode)"); return SCO_ERR_ARG; }
+    }
+    if (sp != 1) { sco_set_error("sco_sqp_load_program: a row's program must leave exactly one value"); return SCO_ERR_ARG; }
+  }
+  SCO_ON_DEVICE(h->device);
+  SqpDev &s = h->d;
+  int rc;
+  int *pw = nullptr, *pptr = nullptr; double *pc = nullptr, *pp = nullptr;
+  if ((rc = sq_alloc(h, (size_t)2 * n_words, &pw)) || (rc = sq_alloc(h, (size_t)R + 1, &pptr)) ||
+      (rc = sq_alloc(h, (size_t)n_consts, &pc)) || (rc = sq_alloc(h, (size_t)s.batch * n_params, &pp))) return rc;
+  SCO_HIP(hipMemcpy(pw, words, (size_t)2 * n_words * sizeof(int), hipMemcpyHostToDevice));
+  SCO_HIP(hipMemcpy(pptr, row_ptr, ((size_t)R + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (n_consts) SCO_HIP(hipMemcpy(pc, consts, (size_t)n_consts * sizeof(double), hipMemcpyHostToDevice));
+  if (n_params) SCO_HIP(hipMemcpy(pp, params, (size_t)s.batch * n_params * sizeof(double), hipMemcpyHostToDevice));
+  s.pw = pw; s.pptr = pptr; s.pconst = pc; s.ppar = pp; s.n_par = n_params;
+  h->prog_loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
 extern "C" int sco_sqp_set_groups(sco_sqp *h, int n_groups, const unsigned int *block_mask) {
   if (!h || !block_mask) { sco_set_error("sco_sqp_set_groups: null pointer"); return SCO_ERR_ARG; }
   if (n_groups < 1 || n_groups > 32) { sco_set_error("sco_sqp_set_groups: 1..32 groups"); return SCO_ERR_ARG; }
@@ -1369,6 +1448,9 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   }
   if ((h->desc.family & SCO_FAM_FLAG_JOINT_LIMITS) && !h->jl_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_joint_limits first"); return SCO_ERR_STATE;
+  }
+  if ((h->desc.family & 15) == SCO_FAM_STATE_PROGRAM && !h->prog_loaded) {
+    sco_set_error("sco_sqp_solve: call sco_sqp_load_program first"); return SCO_ERR_STATE;
   }
   if ((h->desc.family & 15) == SCO_FAM_STATE_QUADRATIC && !h->quad_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_quadratic first"); return SCO_ERR_STATE;

@@ -1,0 +1,121 @@
+"""Closed-form constraint rows for the device family SCO_FAM_STATE_PROGRAM (include/sco_hip.h).
+
+The reference differentiates and evaluates arbitrary Python callables (`Expr(f)`, /root/reference/sco_py/expr.py:22-41);
+a GPU cannot call Python.  Whatever can be written down with + - * / sin cos sqrt exp over the state x of a timestep and
+a per-problem parameter vector p can be handed to the device as a small postfix program instead:
+
+    from sco_py_amd.rowexpr import X, P, sin, sqrt, compile_rows
+    rows = [P(2) - sqrt((X(0) - P(0)) ** 2 + (X(1) - P(1)) ** 2),       # keep out of a disc (centre, radius in p)
+            X(1) - (0.3 * sin(2.0 * X(0)) + 0.8)]                        # stay below a wavy wall
+    prog = compile_rows(rows)                     # .words, .row_ptr, .consts  ->  sco_sqp_load_program
+    f = prog.numpy_fn(p)                          # the same rows as a NumPy callable x -> g(x): what Expr(f) gets
+
+Both forms run the SAME operation sequence in double precision, so the host callable (reference, mirror API, oracle)
+and the device program agree to the last bits of sin / cos / sqrt / exp.
+"""
+import numpy as np
+
+OP_END, OP_X, OP_P, OP_C, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_SQRT, OP_EXP, OP_SQUARE = range(14)
+STACK = 16
+
+
+class Node(object):
+    """Expression tree node; build with X(i), P(k), numbers and the operators / functions below."""
+
+    def __init__(self, op, arg=0, kids=(), const=None):
+        self.op, self.arg, self.kids, self.const = op, arg, tuple(kids), const
+
+    @staticmethod
+    def lift(v):
+        return v if isinstance(v, Node) else Node(OP_C, const=float(v))
+
+    def __add__(self, o): return Node(OP_ADD, kids=(self, Node.lift(o)))
+    def __radd__(self, o): return Node(OP_ADD, kids=(Node.lift(o), self))
+    def __sub__(self, o): return Node(OP_SUB, kids=(self, Node.lift(o)))
+    def __rsub__(self, o): return Node(OP_SUB, kids=(Node.lift(o), self))
+    def __mul__(self, o): return Node(OP_MUL, kids=(self, Node.lift(o)))
+    def __rmul__(self, o): return Node(OP_MUL, kids=(Node.lift(o), self))
+    def __truediv__(self, o): return Node(OP_DIV, kids=(self, Node.lift(o)))
+    def __rtruediv__(self, o): return Node(OP_DIV, kids=(Node.lift(o), self))
+    def __neg__(self): return Node(OP_NEG, kids=(self,))
+
+    def __pow__(self, k):
+        if k != 2:
+            raise ValueError("only ** 2 is available (write products for other powers)")
+        return Node(OP_SQUARE, kids=(self,))
+
+    def emit(self, words, consts):
+        for k in self.kids:
+            k.emit(words, consts)
+        if self.op == OP_C:
+            if self.const not in consts:
+                consts.append(self.const)
+            words.append((OP_C, consts.index(self.const)))
+        else:
+            words.append((self.op, self.arg))
+
+
+def X(i): return Node(OP_X, int(i))
+def P(k): return Node(OP_P, int(k))
+def sin(a): return Node(OP_SIN, kids=(Node.lift(a),))
+def cos(a): return Node(OP_COS, kids=(Node.lift(a),))
+def sqrt(a): return Node(OP_SQRT, kids=(Node.lift(a),))
+def exp(a): return Node(OP_EXP, kids=(Node.lift(a),))
+
+
+class Program(object):
+    """Rows compiled to the wire format of sco_sqp_load_program."""
+
+    def __init__(self, words, row_ptr, consts):
+        self.words = np.ascontiguousarray(words, dtype=np.int32).reshape(-1, 2)
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        self.consts = np.ascontiguousarray(consts, dtype=np.float64)
+        self.n_rows = len(self.row_ptr) - 1
+        ops = self.words
+        self.n_params = int(ops[ops[:, 0] == OP_P, 1].max()) + 1 if np.any(ops[:, 0] == OP_P) else 0
+        self.n_state = int(ops[ops[:, 0] == OP_X, 1].max()) + 1 if np.any(ops[:, 0] == OP_X) else 0
+
+    def evaluate(self, x, p=()):
+        """g (n_rows,) at state x with parameters p: the interpreter the device runs, in NumPy scalars."""
+        x = np.asarray(x, dtype=np.float64).ravel(); p = np.asarray(p, dtype=np.float64).ravel()
+        out = np.zeros(self.n_rows)
+        for r in range(self.n_rows):
+            st = []
+            for op, arg in self.words[self.row_ptr[r]:self.row_ptr[r + 1] - 1]:
+                if op == OP_X: st.append(np.float64(x[arg]))
+                elif op == OP_P: st.append(np.float64(p[arg]))
+                elif op == OP_C: st.append(np.float64(self.consts[arg]))
+                elif op == OP_NEG: st[-1] = -st[-1]
+                elif op == OP_SIN: st[-1] = np.sin(st[-1])
+                elif op == OP_COS: st[-1] = np.cos(st[-1])
+                elif op == OP_SQRT: st[-1] = np.sqrt(st[-1])
+                elif op == OP_EXP: st[-1] = np.exp(st[-1])
+                elif op == OP_SQUARE: st[-1] = st[-1] * st[-1]
+                else:
+                    b = st.pop(); a = st[-1]
+                    st[-1] = a + b if op == OP_ADD else a - b if op == OP_SUB else a * b if op == OP_MUL else a / b
+            out[r] = st[0]
+        return out
+
+    def numpy_fn(self, p=()):
+        """x -> g(x) for fixed parameters: the callable to wrap in the reference's / the mirror's Expr(f)."""
+        p = np.array(p, dtype=np.float64)
+        return lambda x: self.evaluate(x, p)
+
+
+def compile_rows(rows):
+    """List of Node expressions (one per constraint row g_r(x, p) <= 0) -> Program."""
+    words, row_ptr, consts = [], [0], []
+    for r in rows:
+        Node.lift(r).emit(words, consts)
+        words.append((OP_END, 0))
+        row_ptr.append(len(words))
+    prog = Program(words, row_ptr, consts)
+    for r in range(prog.n_rows):                      # the same checks the C side makes, with Python errors
+        sp = 0
+        for op, arg in prog.words[prog.row_ptr[r]:prog.row_ptr[r + 1] - 1]:
+            if op in (OP_X, OP_P, OP_C): sp += 1
+            elif OP_ADD <= op <= OP_DIV: sp -= 1
+            if sp > STACK:
+                raise ValueError("row %d needs a deeper stack than %d" % (r, STACK))
+    return prog

@@ -233,11 +233,65 @@ def make_quadratic_problem(i, d=2, T=20, O=3, noise=0.03, groups=None, vel_limit
     return out
 
 
+_PROGRAMS = {}
+
+
+def corridor_program(d):
+    """The rows of the program-family workload, compiled once per state dimension: two keep-out discs whose radius
+    breathes with the angle around them (parameters: centre, radius, ripple), a wavy wall above the path and a soft
+    exponential bump from below -- nothing of it quadratic, all of it closed form."""
+    if d not in _PROGRAMS:
+        from .rowexpr import X, P, sin, cos, sqrt, exp, compile_rows
+        rows = []
+        for o in range(2):
+            cx, cy, rad, rip = P(4 * o), P(4 * o + 1), P(4 * o + 2), P(4 * o + 3)
+            dx, dy = X(0) - cx, X(1) - cy
+            dist = sqrt(dx ** 2 + dy ** 2 + 1e-12)
+            rows.append(rad * (1.0 + rip * (dx / dist) * (dy / dist)) - dist)          # disc with a sin(2 phi) ripple
+        rows.append(X(1) - (P(8) + P(9) * sin(P(10) * X(0))))                          # below a wavy wall
+        rows.append(P(11) - 0.5 * exp(-((X(0) - P(12)) ** 2) * 4.0) - X(1))            # above a floor with a bump
+        if d > 2:
+            rows[-1] = rows[-1] + 0.05 * cos(X(2))                                     # a third coordinate enters one row
+        _PROGRAMS[d] = compile_rows(rows)
+    return _PROGRAMS[d]
+
+
+def make_program_problem(i, d=2, T=20, noise=0.03, groups=None, vel_limit=None, joint_limit=None):
+    """Seeded problem i of the program family (SCO_FAM_STATE_PROGRAM): the rows of corridor_program(d) with per-problem
+    parameters.  Same dictionary layout as make_problem (K = 1, O = 4 rows per timestep)."""
+    rng = np.random.default_rng(9000 + i)
+    start = np.concatenate([[-1.0, rng.uniform(-0.2, 0.2)], rng.uniform(-0.3, 0.3, size=d - 2)])
+    goal = np.concatenate([[1.0, rng.uniform(-0.2, 0.2)], rng.uniform(-0.3, 0.3, size=d - 2)])
+    s = np.linspace(0.0, 1.0, T)[:, None]
+    x0 = (1 - s) * start[None, :] + s * goal[None, :] + noise * rng.standard_normal((T, d))
+    par = np.zeros(13)
+    for o in range(2):
+        a = rng.uniform(0.25, 0.75)
+        par[4 * o:4 * o + 2] = (1 - a) * start[:2] + a * goal[:2] + 0.05 * rng.standard_normal(2)
+        par[4 * o + 2] = rng.uniform(0.12, 0.22); par[4 * o + 3] = rng.uniform(-0.3, 0.3)
+    par[8:11] = (rng.uniform(0.55, 0.75), rng.uniform(0.05, 0.15), rng.uniform(2.0, 4.0))
+    par[11:13] = (-rng.uniform(0.6, 0.8), rng.uniform(-0.3, 0.3))
+    prog = corridor_program(d)
+    out = dict(d=d, T=T, K=1, O=prog.n_rows, x0=x0.ravel(), start=start, goal=goal, link_len=np.ones(d),
+               point_link=np.zeros(1, dtype=np.int32), point_frac=np.ones(1), obstacles=np.zeros((prog.n_rows, 3)), reach=False,
+               row_program=prog, row_params=par)
+    if groups is not None:
+        out["groups"] = block_groups(T, False, groups)
+    if vel_limit is not None:
+        out["vmax"] = float(vel_limit)
+    if joint_limit is not None:
+        out["jlo"] = np.minimum(start, goal) - float(joint_limit)
+        out["jhi"] = np.maximum(start, goal) + float(joint_limit)
+    return out
+
+
 def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None,
-                 ee_cost_weight=None, point=False, quadratic=False):
+                 ee_cost_weight=None, point=False, quadratic=False, program=False):
     """Seeded problem i of the batch.  reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
+    if program:
+        return make_program_problem(i, d=d, T=T, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
     if quadratic:
         return make_quadratic_problem(i, d=d, T=T, O=O, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
     if point:
@@ -286,6 +340,8 @@ def make_batch(B, first=0, **kw):
     extra = dict(reach=True, target=np.stack([p["target"] for p in probs])) if p0.get("reach") else {}
     if p0.get("point"):
         extra["point"] = True
+    if p0.get("row_program") is not None:
+        extra["row_program"] = p0["row_program"]; extra["row_params"] = np.stack([p["row_params"] for p in probs])
     if p0.get("quad_Q") is not None:
         extra["quad_Q"] = np.stack([p["quad_Q"] for p in probs]); extra["quad_a"] = np.stack([p["quad_a"] for p in probs])
         extra["quad_c"] = np.stack([p["quad_c"] for p in probs])

@@ -446,3 +446,46 @@ def test_mirror_api_reproduces_reference_for_the_quadratic_row_family(oracle_qp_
         assert [a["status"] for a in gold] == [r["status"] for r in oracle_qp_backend]
         assert ok == bool(g[prefix + "success"])
         assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 1e-9
+
+
+def _prog_cases():
+    import sys
+    sys.path.insert(0, GOLD)
+    from prog_cases import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("case", _prog_cases(), ids=lambda c: c[0])
+def test_flat_oracle_reproduces_reference_for_the_program_family(case):
+    """SCO_FAM_STATE_PROGRAM (closed-form rows compiled by sco_py_amd.rowexpr and handed to the reference as an ordinary
+    Expr(f)): every QP the reference assembled, the statuses, iteration counts and the answer."""
+    prefix, kw, i = case
+    g = np.load(os.path.join(GOLD, "trajopt_prog.npz"))
+    pr = af.make_problem(i, **kw)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr), record_qps=True)
+    _compare_sequence(ct.load_golden_qps(g, prefix), out.qps, prefix)
+    assert out.success == bool(g[prefix + "success"])
+    assert np.abs(out.x - g[prefix + "x"]).max() < 1e-9
+    assert abs(out.max_violation - float(g[prefix + "max_violation"])) < 1e-9
+
+
+def test_row_expression_compiler():
+    """sco_py_amd.rowexpr: the compiled program evaluates to what the expression says, shares constants, counts state
+    coordinates and parameters, and refuses what the device's 16-deep stack cannot run."""
+    from sco_py_amd.rowexpr import X, P, sin, cos, sqrt, exp, compile_rows, OP_END
+    rows = [P(2) - sqrt((X(0) - P(0)) ** 2 + (X(1) - P(1)) ** 2), X(1) - (0.3 * sin(2.0 * X(0)) + 0.8) / cos(0.3 * X(2)),
+            -exp(-X(0)) * 2.0 + 0.3]
+    pr = compile_rows(rows)
+    assert pr.n_rows == 3 and pr.n_params == 3 and pr.n_state == 3 and list(pr.consts).count(0.3) == 1
+    assert all(pr.words[pr.row_ptr[r + 1] - 1, 0] == OP_END for r in range(3))
+    x = np.array([0.3, -0.2, 0.5]); p = np.array([0.1, 0.1, 0.25])
+    want = [0.25 - np.hypot(0.2, 0.3), -0.2 - (0.3 * np.sin(0.6) + 0.8) / np.cos(0.15), -np.exp(-0.3) * 2.0 + 0.3]
+    assert np.allclose(pr.evaluate(x, p), want, rtol=0, atol=1e-15)
+    assert np.array_equal(pr.numpy_fn(p)(x), pr.evaluate(x, p))
+    deep = X(0)
+    for k in range(20):
+        deep = X(0) + (X(1) * deep)            # right-nested: operands pile up on the stack
+    with pytest.raises(ValueError):
+        compile_rows([deep])
+    with pytest.raises(ValueError):
+        compile_rows([X(0) ** 3])

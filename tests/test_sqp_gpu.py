@@ -709,6 +709,70 @@ def test_quadratic_row_family_call_order_and_validation(gpu):
             sb.TrajOptBatch(2, kw["dof"], 6, kw["n_points"], 3, quadratic=True)
 
 
+def test_program_family_matches_oracle(gpu):
+    """SCO_FAM_STATE_PROGRAM: rows as closed-form postfix programs over the state and per-problem parameters (rippled
+    discs, a wavy wall, an exponential bump; sco_py_amd.rowexpr), Jacobians by the device's central differences -- in 2
+    and 3 dimensions, with velocity limits, a box and groups, and above the CU count under round selection."""
+    for kw in (dict(d=2, T=8), dict(d=3, T=6), dict(d=2, T=8, vel_limit=0.5), dict(d=2, T=8, joint_limit=0.25, groups="split")):
+        arrays, probs = af.make_batch(8, K=1, program=True, **kw)
+        res = sb.solve_batch(arrays)
+        _compare(res, probs, range(8))
+    arrays, probs = af.make_batch(270, d=2, T=10, K=1, program=True)
+    res = sb.solve_batch(arrays)
+    _compare(res, probs, range(0, 270, 53))
+    prog = arrays["row_program"]
+    for b in np.nonzero(res.success)[0][:30]:                                     # success = every row satisfied
+        x = res.x[b].reshape(10, 2)
+        assert max(prog.evaluate(x[t], arrays["row_params"][b]).max() for t in range(10)) < 1e-3
+
+
+def test_program_family_matches_reference_golden_runs(gpu):
+    import sys
+    sys.path.insert(0, GOLD)
+    from prog_cases import CASES
+    g = np.load(os.path.join(GOLD, "trajopt_prog.npz"))
+    for prefix, kw, i in CASES:
+        arrays, _ = af.make_batch(1, first=i, **kw)
+        res = sb.solve_batch(arrays)
+        assert np.abs(res.x[0] - g[prefix + "x"]).max() < TOL, prefix
+        assert bool(res.success[0]) == bool(g[prefix + "success"]), prefix
+        nq = int(g[prefix + "n_qp"])
+        assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix
+        assert [int(v) for v in res.trace[0][:, 7]] == [int(g["%sqp%d_iters" % (prefix, k)]) for k in range(nq)], prefix
+
+
+def test_program_family_validation(gpu):
+    import ctypes as C
+    arrays, _ = af.make_batch(2, d=2, T=6, K=1, program=True)
+    prog = arrays["row_program"]
+    with pytest.raises(ValueError):
+        sb.TrajOptBatch(2, 2, 6, 1, prog.n_rows, program=True, analytic_jac=True)
+    with sb.TrajOptBatch(2, 2, 6, 1, prog.n_rows, program=True) as tb:
+        lib = _lib.load()
+        assert lib.sco_sqp_load(tb._h, _lib.dptr(arrays["x0"]), _lib.dptr(arrays["start"]), _lib.dptr(arrays["goal"]),
+                                _lib.dptr(arrays["link_len"]), _lib.iptr(arrays["point_link"]), _lib.dptr(arrays["point_frac"]),
+                                _lib.dptr(arrays["obstacles"])) == 0
+        with pytest.raises(_lib.ScoHipError):
+            tb.solve()                                                            # no program yet
+        par = np.ascontiguousarray(arrays["row_params"])
+
+        def load(words, row_ptr=prog.row_ptr, npar=prog.n_params):
+            w = np.ascontiguousarray(words, dtype=np.int32)
+            return lib.sco_sqp_load_program(tb._h, len(w), _lib.iptr(np.ascontiguousarray(w.ravel())), _lib.iptr(np.ascontiguousarray(row_ptr, dtype=np.int32)),
+                                            len(prog.consts), _lib.dptr(prog.consts), npar, _lib.dptr(par))
+        bad = prog.words.copy(); bad[0] = (1, 7)                                  # x[7] of a 2-dimensional state
+        assert load(bad) != 0
+        bad = prog.words.copy(); bad[0] = (4, 0)                                  # ADD on an empty stack
+        assert load(bad) != 0
+        bad = prog.words.copy(); bad[prog.row_ptr[1] - 1] = (8, 0)                # a row without its END
+        assert load(bad) != 0
+        bad = prog.words.copy(); bad[1] = (99, 0)                                 # unknown opcode
+        assert load(bad) != 0
+        assert load(prog.words, npar=3) != 0                                      # the program reads parameter 12
+        assert load(prog.words) == 0
+        tb.solve()
+
+
 def test_joint_limits_7x20_batch_and_validation(gpu):
     arrays, probs = af.make_batch(4, joint_limit=0.2)
     res = sb.solve_batch(arrays)

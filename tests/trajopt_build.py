@@ -60,6 +60,8 @@ def build_prob(mods, pr, analytic_jac=False):
         step_vars.append(sv)
 
         def f(x, pr=pr):
+            if pr.get("row_program") is not None:    # program family: the compiled rows as a NumPy callable
+                return pr["row_program"].evaluate(x.ravel(), pr["row_params"]).reshape(-1, 1)
             if pr.get("quad_Q") is not None:    # quadratic-row family
                 return af.quad_rows(x.ravel(), pr["quad_Q"], pr["quad_a"], pr["quad_c"]).reshape(-1, 1)
             if pr.get("point"):                 # point-robot family: distance of the point itself to the discs
