@@ -489,3 +489,17 @@ def test_row_expression_compiler():
         compile_rows([deep])
     with pytest.raises(ValueError):
         compile_rows([X(0) ** 3])
+
+
+def test_mirror_api_reproduces_reference_for_the_program_family(oracle_qp_backend):
+    g = np.load(os.path.join(GOLD, "trajopt_prog.npz"))
+    for prefix, kw, i in _prog_cases()[:2] + _prog_cases()[4:5]:
+        del oracle_qp_backend[:]
+        mods = ct.mirror_mods()
+        prob, traj, _, _ = tb.build_prob(mods, af.make_problem(i, **kw))
+        ok = mods.Solver().solve(prob, method="penalty_sqp")
+        gold = ct.load_golden_qps(g, prefix)
+        assert [a["iters"] for a in gold] == [r["iters"] for r in oracle_qp_backend]
+        assert [a["status"] for a in gold] == [r["status"] for r in oracle_qp_backend]
+        assert ok == bool(g[prefix + "success"])
+        assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 1e-9
