@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <type_traits>
 
 // Diagnostic builds only (scripts/build_ablate.py): -DRL_ABLATE=<mask> removes one piece of the iteration so that its
 // cost can be read off the per-iteration time (results are wrong; never compiled into the product).
@@ -38,7 +39,9 @@
 #endif
 // experiment switches of diagnostic builds (scripts/build_ablate.py --variant): 1 static priority for wavefronts 4-7,
 // 2 register pin on the packed offsets (the r01 form), 4 unpadded right-hand side, 8 eight iterations per loop trip,
-// 16 no termination test (the loop structure around it stays), 32 the checked iteration writes no test scratch
+// 16 no termination test (the loop structure around it stays), 32 the checked iteration writes no test scratch,
+// 64 wave-uniform row-slot masks in phase (Y) (r03: slower, 0.955 against 0.933 us), 128 values of the gather-dots read
+// before the barrier in front of their phase
 #ifndef RL_VARIANT
 #define RL_VARIANT 0
 #endif
@@ -54,7 +57,14 @@
 #define LNS_MAX 3
 #define LRW 8           // value slots of a row's core entries (4 aligned pairs); the wide instantiation (CW = 16) takes 10
 #define LRW_MAX 10
-#define RL_ROLES 25
+#define RL_ROLES 29
+// aligned closed assignment: core index of the thread's W tile rows (3) and of the mat-vec total it stores (-1: none)
+#define ROLE_WROW(rr) (25 + (rr))
+#define ROLE_XOUT 28
+// tile of the aligned layout: 8 column groups (lane bits 0, 4, 5) x 8 row groups per wavefront (lane bits 1-3)
+#define AL_TR 3
+#define AL_TC 18
+#define AL_ROWS (8 * AL_TR)       // W rows (core columns) a wavefront can own
 // role-table rows of row slot q (slots 0, 1 keep their r01 places; slot 2 follows)
 #define ROLE_ROW(q) ((q) < 2 ? 4 + (q) : 20)
 #define ROLE_EPOS(q) ((q) < 2 ? 6 + (q) : 21)
@@ -93,8 +103,11 @@ static void build_sell2(int nitems, const std::vector<int> &ptr, const std::vect
 // wavefront, phase (1) follows phase (Y) without a workgroup barrier, and all eight wavefronts share the column
 // work (in a trajectory QP a component is a timestep).  False if a component needs more than 64 threads or the
 // components do not pack: the caller keeps the barrier then.
+// cols_cap > 0 (aligned form): a wavefront also owns the W rows of its core columns, at most cols_cap of them; the core
+// columns of wavefront w, in tile-row order, come back in wave_cols[w].
 static bool rl_assign_closed(const QpPlan &pl, const std::vector<int> &row_elim, const std::vector<std::vector<int>> &erows,
-                             std::vector<int> &slot_row, std::vector<int> &thr_core, std::vector<int> &thr_elim) {
+                             std::vector<int> &slot_row, std::vector<int> &thr_core, std::vector<int> &thr_elim,
+                             const int cols_cap = 0, std::vector<std::vector<int>> *wave_cols = nullptr) {
   const int m = pl.m, nc = pl.n_c, ne = pl.n_e;
   std::vector<int> uf(m + nc + ne);
   for (size_t i = 0; i < uf.size(); i++) uf[i] = (int)i;
@@ -122,20 +135,27 @@ static bool rl_assign_closed(const QpPlan &pl, const std::vector<int> &row_elim,
     for (int e : k.elims) spare += 2 - (int)erows[e].size();
     const int extra = std::max(0, (int)k.free_rows.size() - spare);
     k.need = std::max((int)k.elims.size() + (extra + 1) / 2, (int)k.cols.size());
+    if (getenv("SCO_DEBUG_PLAN")) fprintf(stderr, "comp: cols %zu elims %zu free %zu need %d\n", k.cols.size(), k.elims.size(), k.free_rows.size(), k.need);
     if (k.need > 64) return false;
     if (k.need == 0) k.need = 1;
   }
   std::vector<int> order(comps.size());
   for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return comps[a].need > comps[b].need; });
-  int load[LWV] = {0};
+  int load[LWV] = {0}, ncols[LWV] = {0};
   std::vector<std::vector<int>> bin(LWV);
   for (int k : order) {
     int best = -1;
     for (int w = 0; w < LWV; w++)
-      if (load[w] + comps[k].need <= 64 && (best < 0 || load[w] < load[best])) best = w;
+      if (load[w] + comps[k].need <= 64 && (cols_cap <= 0 || ncols[w] + (int)comps[k].cols.size() <= cols_cap) &&
+          (best < 0 || load[w] < load[best])) best = w;
     if (best < 0) return false;
-    load[best] += comps[k].need; bin[best].push_back(k);
+    load[best] += comps[k].need; ncols[best] += (int)comps[k].cols.size(); bin[best].push_back(k);
+  }
+  if (wave_cols) {
+    wave_cols->assign(LWV, std::vector<int>());
+    for (int w = 0; w < LWV; w++)
+      for (int k : bin[w]) for (int c : comps[k].cols) (*wave_cols)[w].push_back(c);
   }
   slot_row.assign(2 * LT, -1); thr_core.assign(LT, -1); thr_elim.assign(LT, -1);
   for (int w = 0; w < LWV; w++) {
@@ -162,7 +182,7 @@ static bool rl_assign_closed(const QpPlan &pl, const std::vector<int> &row_elim,
   return true;
 }
 
-static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min) {
+static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, const bool allow_aligned = false) {
   if (pl.n_c + 4 > LCAP_NC || pl.m >= LNS_MAX * LT || pl.n_e > LT || pl.n_c > LT || pl.nnzA >= 65536 || pl.n > 2 * LT) return false;
   const int m = pl.m;
   // rows of every eliminated variable; every row's eliminated variable
@@ -183,7 +203,22 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min) {
   // column code, 957 against 871 ms per bench step), so it is opt-in: SCO_QP_RL_CLOSED=1.
   const char *closed = getenv("SCO_QP_RL_CLOSED");
   rh.NS = 2;
-  rh.merged = ns_min == 2 && closed && closed[0] == '1' && rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim);
+  // The ALIGNED closed assignment (r03; opt-in with SCO_QP_RL_ALIGNED=1, measured slower, see below): the wavefront
+  // that holds a connected component's rows and columns also holds the W rows of those columns, so the mat-vec totals a
+  // row needs are produced by its own wavefront: (3) -> (Y) -> (1) run without a workgroup barrier, ONE barrier per
+  // iteration is left (before (3): the whole right-hand side), and the two wavefronts of a SIMD drift apart: the
+  // latency-bound phases of one overlap the multiply-adds of the other.  For cores of 129 .. 144 variables (the tile
+  // of that layout is 3 x 18 with 8 column groups); a pattern whose components do not pack keeps the open assignment.
+  // Measured (profiles/r03_ab.txt): 1.057 against 0.932 us per iteration.  Every wavefront then runs every kind of work
+  // at a third of its lanes (21 columns, ~45 row threads per wavefront): 176 instead of ~140 VALU and 39 instead of ~20
+  // LDS instructions per wavefront and iteration, and an iteration costs what its instructions cost, not what its
+  // barriers cost.
+  const char *al = getenv("SCO_QP_RL_ALIGNED");
+  std::vector<std::vector<int>> wave_cols;
+  rh.aligned = allow_aligned && ns_min == 2 && al && al[0] == '1' && pl.n_c > 128 && pl.n_c <= 8 * AL_TC &&
+               rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim, AL_ROWS, &wave_cols);
+  rh.merged = rh.aligned ||
+              (ns_min == 2 && closed && closed[0] == '1' && rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim));
   if (!rh.merged) {
     // two row slots per thread; a pattern with more rows than that (velocity + joint limits at 7-DOF x 20: 1100) takes
     // the three-slot instantiation.  The rows of an eliminated variable (<= 2) always sit in slots 0 and 1 of its thread.
@@ -301,17 +336,40 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min) {
   if (maxc > LCW / 2 || maxr > LRW / 2) rh.CW = LCW_MAX;      // the wide instantiation: 8 pairs per column, 5 per row
   if (NSv > 2) rh.CW = LCW_MAX3;                              // three row slots: 10 pairs per column, 5 per row
   // ---- sliced-ELL images in thread order: two value slots per pair
-  auto image = [&](const std::vector<std::vector<Pair>> &items, SellHost &out) {
-    std::vector<int> ptr(LT + 1, 0), src;
+  // Open assignment: item = thread.  Closed assignments spread every kind of work over all wavefronts (a wavefront holds
+  // ~21 of the 140 columns), so an image with one item per THREAD would be 8 full slices per operator and overflow LDS:
+  // there the items are the threads that have entries, in thread order (`ipos[t]`: image position of thread t's first
+  // value, -1 = none: such a thread reads the zero block behind the images), and a wavefront's trip count is the
+  // widest of its own threads (`iwid`).  Its active lanes still read consecutive 16-byte pieces: conflict-free.
+  const bool compact = rh.merged;
+  auto image = [&](const std::vector<std::vector<Pair>> &items, SellHost &out, std::vector<int> &ipos, std::vector<int> &iwid) {
+    std::vector<int> ptr(1, 0), src, item_of(LT, -1);
+    int nit = 0;
     for (int t = 0; t < LT; t++) {
+      if (compact && items[t].empty()) continue;
       for (const Pair &pr : items[t]) { src.push_back(pr.s0); src.push_back(pr.s1); }
-      ptr[t + 1] = (int)src.size();
+      ptr.push_back((int)src.size());
+      item_of[t] = nit++;
     }
-    build_sell2(LT, ptr, src, out);
+    if (nit == 0) { ptr.push_back(0); nit = 1; }
+    build_sell2(nit, ptr, src, out);
+    ipos.assign(LT, -1); iwid.assign(LT, 0);
+    for (int t = 0; t < LT; t++) {
+      if (item_of[t] >= 0) ipos[t] = out.base[item_of[t] / 64] + 2 * (item_of[t] % 64);
+      if (!compact) iwid[t] = out.width[t / 64];
+    }
+    if (compact)
+      for (int w = 0; w < LWV; w++) {
+        int mx = 0;
+        for (int t = 64 * w; t < 64 * w + 64; t++) mx = std::max(mx, 2 * (int)items[t].size());
+        for (int t = 64 * w; t < 64 * w + 64; t++) iwid[t] = mx;
+      }
   };
-  image(colp, rh.Ac);
+  std::vector<int> cpos, cwid, rpos[LNS_MAX], rwid[LNS_MAX];
+  image(colp, rh.Ac, cpos, cwid);
   size_t rtot = 0;
-  for (int q = 0; q < NSv; q++) { image(rowp[q], rh.Ar[q]); rtot += rh.Ar[q].total; }
+  for (int q = 0; q < NSv; q++) { image(rowp[q], rh.Ar[q], rpos[q], rwid[q]); rtot += rh.Ar[q].total; }
+  const int zblock = rh.Ac.total + (int)rtot;          // 64 x 16 zeros behind the images (kernel prologue)
   rh.lds_bytes = 8 * ((size_t)rh.Ac.total + rtot + 64 * 16 + (2 * NSv + 5) * LT) + 12 * 4 * LCAP_NC;   // + check constants
   // ---- per-thread tables: packed pair offsets (bytes) and roles
   const int CPv = rh.CW / 2;
@@ -326,12 +384,12 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min) {
     //             6/7 CSC position of the row's eliminated coefficient, 8 col base, 9/10 row bases,
     //             11/12 position of P_jj for the core / eliminated variable, 13-15 trip counts,
     //             16/17 LDS position of the row of slot 0/1
-    rh.role[(size_t)8 * LT + t] = rh.Ac.base[t / 64] + 2 * (t % 64);
+    rh.role[(size_t)8 * LT + t] = cpos[t] >= 0 ? cpos[t] : zblock + 2 * (t % 64);
     for (int q = 0, acc = rh.Ac.total; q < NSv; acc += rh.Ar[q].total, q++) {
-      rh.role[(size_t)ROLE_RBASE(q) * LT + t] = acc + rh.Ar[q].base[t / 64] + 2 * (t % 64);
-      rh.role[(size_t)ROLE_RWID(q) * LT + t] = rh.Ar[q].width[t / 64];
+      rh.role[(size_t)ROLE_RBASE(q) * LT + t] = rpos[q][t] >= 0 ? acc + rpos[q][t] : zblock + 2 * (t % 64);
+      rh.role[(size_t)ROLE_RWID(q) * LT + t] = rwid[q][t];
     }
-    rh.role[(size_t)13 * LT + t] = rh.Ac.width[t / 64];      // wave-uniform trip counts (value slots = 2 x pairs)
+    rh.role[(size_t)13 * LT + t] = cwid[t];                  // wave-uniform trip counts (value slots = 2 x pairs)
     const int c = thr_core[t];
     if (c >= 0) {
       const int j = pl.core_var[c];
@@ -342,6 +400,16 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min) {
     if (e >= 0) {
       rh.role[(size_t)2 * LT + t] = e; rh.role[(size_t)3 * LT + t] = pl.elim_var[e];
       rh.role[(size_t)12 * LT + t] = pl.Pdiag[pl.elim_var[e]];
+    }
+    if (rh.aligned) {
+      const int wv = t / 64, lane = t % 64, g = (lane >> 1) & 7, h = (lane >> 4) & 3;
+      for (int rr = 0; rr < AL_TR; rr++) {
+        const int lr = g * AL_TR + rr;
+        rh.role[(size_t)ROLE_WROW(rr) * LT + t] = lr < (int)wave_cols[wv].size() ? wave_cols[wv][lr] : -1;
+      }
+      // after the folds (rl_reduce_al) the total of tile row 0 / 1 / 2 sits in the lanes with (bit 5, bit 4) = 00 / 10 / 01
+      const int rr_out = h == 0 ? 0 : h == 2 ? 1 : h == 1 ? 2 : -1;
+      if ((lane & 1) == 0 && rr_out >= 0) rh.role[(size_t)ROLE_XOUT * LT + t] = rh.role[(size_t)ROLE_WROW(rr_out) * LT + t];
     }
     for (int q = 0; q < NSv; q++) {
       const int i = slot_row[q * LT + t];
@@ -373,12 +441,17 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min) {
   rh.TC = 2 * rh.TR;
   if (rh.TR == 5 && pl.n_c <= LGJ * 9) rh.TC = 9;
   if (rh.CW > LCW && rh.TR != 5) return false;        // the wide variants exist for the 5-row tiles only
+  if (rh.aligned) { rh.TR = AL_TR; rh.TC = AL_TC; }
   return rh.lds_bytes + 40 * 1024 <= 160 * 1024;   // + 37.5 KB of static LDS
 }
 
 // Two row slots per thread where the pattern allows it; otherwise (more than 1024 rows, or more than 8 operand pairs in
 // a column) the three-slot instantiation with ten pairs per column.
 bool rl_plan_build(const QpPlan &pl, RlHost &rh) {
+  {
+    RlHost al;
+    if (rl_plan_build_ns(pl, al, 2, true) && al.aligned) { rh = al; return true; }
+  }
   {
     RlHost two;
     if (rl_plan_build_ns(pl, two, 2)) { rh = two; return true; }
@@ -599,6 +672,48 @@ __device__ __forceinline__ double rl_dot_row_w(int w, const double *V, unsigned 
   return rl_dot<RW>(V, o, vec);
 }
 
+// The same gather-dots in two halves (RL_VARIANT & 128): the VALUES of a thread's entries never change during a solve,
+// so they can be read before the barrier that precedes the phase; only the gathered operands have to wait for it.
+template <int NP, bool COL>
+__device__ __forceinline__ void rl_vals(int w, const double *V, dbl2 (&val)[NP]) {
+  // pairs the dispatch below will multiply for this (wave-uniform) trip count
+  const int need = w <= 0 ? 0 : COL ? (w <= 4 ? 2 : w <= 8 ? 4 : w <= 12 ? 6 : w <= 16 ? 8 : NP) : (w <= 2 ? 1 : w <= 4 ? 2 : w <= 8 ? 4 : NP);
+#pragma unroll
+  for (int h = 0; h < NP; h++)
+    if (h < need) val[h] = *(const dbl2 *)(V + 128 * h);
+}
+template <int N, int NPMAX>
+__device__ __forceinline__ double rl_dot_pre(const dbl2 (&val)[NPMAX], unsigned int *o, const double *vec) {
+  constexpr int NP = N / 2;
+  dbl2 g[NP];
+#pragma unroll
+  for (int h = 0; h < NP; h++) {
+    const unsigned int off = (h & 1) ? (o[h / 2] >> 16) : (o[h / 2] & 0xffffu);
+    g[h] = *(const dbl2 *)((const char *)vec + off);
+  }
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int h = 0; h < NP; h++) { a0 += val[h].x * g[h].x; a1 += val[h].y * g[h].y; }
+  return a0 + a1;
+}
+template <int CW>
+__device__ __forceinline__ double rl_dot_col_pre(int w, const dbl2 (&val)[CW / 2], unsigned int *o, const double *vec) {
+  if (w <= 0) return 0.0;
+  if (w <= 4) return rl_dot_pre<4>(val, o, vec);
+  if (w <= 8) return rl_dot_pre<8>(val, o, vec);
+  if constexpr (CW > 12) { if (w <= 12) return rl_dot_pre<12>(val, o, vec); }
+  if constexpr (CW > 16) { if (w <= 16) return rl_dot_pre<16>(val, o, vec); }
+  return rl_dot_pre<CW>(val, o, vec);
+}
+template <int RW>
+__device__ __forceinline__ double rl_dot_row_pre(int w, const dbl2 (&val)[RW / 2], unsigned int *o, const double *vec) {
+  if (w <= 0) return 0.0;
+  if (w <= 2) return rl_dot_pre<2>(val, o, vec);
+  if (w <= 4) return rl_dot_pre<4>(val, o, vec);
+  if constexpr (RW > LRW) { if (w <= LRW) return rl_dot_pre<LRW>(val, o, vec); }
+  return rl_dot_pre<RW>(val, o, vec);
+}
+
 // ---- phase (3) reduction --------------------------------------------------------------
 // The 16 partial sums of a row of the W mat-vec sit in the lanes with the same (lane >> 2) & 3:
 // 4 DPP rows (lane >> 4) x 4 lanes of a quad (lane & 3).  Two rows' partial sums are folded per
@@ -640,9 +755,24 @@ __device__ __forceinline__ void rl_reduce_rows(const double (&acc)[TR], double (
   for (int n = 0; n < RL_NT(TR); n++) t[n] = rl_quad_sum(rl_fold16(u[2 * n], 2 * n + 1 < NU ? u[2 * n + 1] : 0.0));
 }
 __device__ __forceinline__ int rl_tile_row(int n, int h) { return 4 * n + 2 * (h & 1) + (h >> 1); }
+// Aligned layout: 8 column groups = lane bits 5, 4, 0.  Three tile rows: the swap folds over bits 5 and 4 leave the
+// total (over those bits) of row 0 / 1 / 2 in the lanes with (bit 5, bit 4) = 00 / 10 / 01, one quad_perm step adds the
+// lane pair: 12 VALU instructions for 3 rows.  Fixed association order.
+__device__ __forceinline__ double rl_reduce_al(const double (&acc)[AL_TR]) {
+  double v = rl_fold16(rl_fold32(acc[0], acc[1]), rl_fold32(acc[2], 0.0));
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xb1, 0xf, 0xf, true),     // quad_perm [1,0,3,2]
+                        __builtin_amdgcn_update_dpp(0, lo, 0xb1, 0xf, 0xf, true));
+  return v;
+}
+// wavefront-local hand-over through LDS (aligned / closed assignment): the LDS operations of one wavefront complete
+// in order, so no s_barrier is needed; this only keeps the compiler from moving accesses across the hand-over
+#define RL_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
-template <int TR, int TC, int CW, bool ADAPT, int NS = 2>
+template <int TR, int TC, int CW, bool ADAPT, int NS = 2, bool AL = false>
 __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
+  static_assert(!AL || (TR == AL_TR && TC == AL_TC && NS == 2), "aligned layout: 3 x 18 tiles, two row slots");
   const int b = a.list ? a.list[blockIdx.x + a.b0] : (int)blockIdx.x + a.b0, tid = threadIdx.x;
   if (b < 0 || (a.active && !a.active[b])) return;
   const int n = a.n, m = a.m, n_e = a.n_e, n_c = a.n_c;
@@ -653,8 +783,11 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   // core right-hand side: the TC entries of column group gj start at gj * TCP (TCP = TC rounded up to even), so a
   // thread reads its tile's entries with 16-byte LDS reads (half the LDS cycles of 8-byte pairs)
   constexpr int TCP = (RL_VARIANT & 4) ? TC : ((TC + 1) & ~1);
-  static_assert(LGJ * TCP <= LCAP_NC + 16, "padded right-hand side");
-  __shared__ __attribute__((aligned(16))) double s_rv[LCAP_NC + 16];
+  static_assert((AL ? 8 : LGJ) * TCP <= LCAP_NC + 16, "padded right-hand side");
+  // aligned form: two buffers used in turn (one barrier per iteration: a fast wavefront writes the next right-hand side
+  // while a slow one still reads the current one)
+  constexpr int RVS = AL ? LCAP_NC + 16 : 0;
+  __shared__ __attribute__((aligned(16))) double s_rv[(AL ? 2 : 1) * (LCAP_NC + 16)];
   __shared__ __attribute__((aligned(16))) double s_xc[LCAP_NC];                // x~_C
   __shared__ __attribute__((aligned(16))) double s_chk[2 * LCAP_M + 2 * LCAP_NC];   // check scratch: w*y, dy (rows), x_C, dx_C
   __shared__ double s_red[LWV * 8];
@@ -697,7 +830,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   const int wcol = __builtin_amdgcn_readfirstlane(a.role[(size_t)13 * LT + tid]);
   // W tile of this thread: row group gi (4 per wavefront: bits 2-3 of the lane), column group gj (bits 0-1 and
   // 4-5 of the lane: the 16 lanes whose partial sums rl_reduce_rows adds)
-  const int gi = (tid >> 6) * 4 + ((tid >> 2) & 3), gj = (tid & 3) + 4 * ((tid >> 4) & 3);
+  // (aligned layout: 8 column groups = lane bits 0, 4, 5; the tile rows come from the role table)
+  const int gi = (tid >> 6) * 4 + ((tid >> 2) & 3), gj = AL ? (tid & 1) + 2 * ((tid >> 4) & 3) : (tid & 3) + 4 * ((tid >> 4) & 3);
   const int wrow_h = (tid >> 4) & 3;                 // DPP row of the lane: which tile rows' totals it receives
   double wreg[TR][TC];
   {
@@ -706,14 +840,17 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     for (int rr = 0; rr < TR; rr++)
 #pragma unroll
       for (int cc = 0; cc < TC; cc++) {
-        const int row = gi * TR + rr, col = gj * TC + cc;
-        wreg[rr][cc] = (row < n_c && col < n_c) ? W[(size_t)row * n_c + col] : 0.0;
+        const int row = AL ? a.role[(size_t)ROLE_WROW(rr) * LT + tid] : gi * TR + rr, col = gj * TC + cc;
+        wreg[rr][cc] = (row >= 0 && row < n_c && col < n_c) ? W[(size_t)row * n_c + col] : 0.0;
       }
   }
+  const int xout = AL ? a.role[(size_t)ROLE_XOUT * LT + tid] : -1;     // aligned: core index of the total this lane stores
   // core-variable state
   const int cown = a.role[tid];
   const int cvar = cown >= 0 ? a.role[(size_t)LT + tid] : 0;
   const int rvpos = cown >= 0 ? (cown / TC) * TCP + cown % TC : 0;     // slot of r_c in the padded right-hand side
+  double *const rvw = s_rv + rvpos;                     // aligned form: an odd step uses the second buffer, RVS further on
+  const dbl2 *const rvr = (const dbl2 *)(s_rv + gj * TCP);
   double xcv = 0.0, qc = 0.0;
   if (cown >= 0) qc = a.qs[(size_t)b * n + cvar];
   // eliminated-variable state
@@ -736,6 +873,15 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       const int ep = a.role[(size_t)ROLE_EPOS(q) * LT + tid];
       if (ep >= 0) r_ae[q] = gAs[ep];
     }
+  }
+  // which row slots this wavefront uses at all, and whether it owns an eliminated variable (wave-uniform)
+  int rmask = 0;
+  {
+    bool any_row = __any(eown >= 0) != 0, upper = false;
+#pragma unroll
+    for (int q = 0; q < NS; q++) { const bool h = __any(r_p[q] >= 0) != 0; any_row |= h; if (q > 0) upper |= h; }
+    // two slots: 0 = no rows, 1 = slot 0 only, 3 = both; three slots: 0 or all
+    rmask = __builtin_amdgcn_readfirstlane(!any_row ? 0 : (NS == 2 && !upper) ? 1 : (1 << NS) - 1);
   }
   // per-thread constants of the termination test, parked in LDS (slot k of thread t at [k * LT + t]): the scalings
   // E of its two rows, D of its core / eliminated variable, the eliminated variable's P_ee.  Read back by the
@@ -776,7 +922,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   if (tid < 4) { s_pcv[tid * LCAP_NC + n_c] = 0.0; s_pci[tid * LCAP_NC + n_c] = n_c; }     // the zero column: threads without a core variable
   for (int i = tid; i < LCAP_M; i += LT) s_tv[i] = 0.0;
   for (int i = tid; i < LCAP_NC; i += LT) s_xc[i] = 0.0;
-  for (int i = tid; i < LCAP_NC + 16; i += LT) s_rv[i] = 0.0;
+  for (int i = tid; i < (AL ? 2 : 1) * (LCAP_NC + 16); i += LT) s_rv[i] = 0.0;
   for (int i = tid; i < 2 * LCAP_M + 2 * LCAP_NC; i += LT) s_chk[i] = 0.0;
   __syncthreads();
   const double cscale = a.cscale[b];
@@ -784,7 +930,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   const double cinv_v = 1.0 / cscale;
   const double cinv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(cinv_v)), __builtin_amdgcn_readfirstlane(__double2loint(cinv_v)));
   const double alpha = a.alpha, sigma = a.sigma;
-  const bool merged = a.merged != 0;
+  const bool merged = AL || a.merged != 0;
   const int it0 = a.slice > 0 ? a.prog[b] : 0;
   if (it0 > 0) {
     // resume an unfinished solve: every loop-carried value comes back from memory
@@ -863,12 +1009,14 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   // far jump over the termination test cost ~900 cycles per iteration,
   // profiles/r01_v5_stamps.txt), the checked copy runs every `check`-th iteration.
   double dxe = 0.0, dxc = 0.0;
-  auto step = [&](const bool chk) __attribute__((always_inline)) {
+  // `k` (0 / 1, a constant at every call site): which right-hand-side buffer the step uses (aligned form)
+  dbl2 pcol[CW / 2];          // RL_VARIANT & 128: the column values of the next phase (1), read ahead of its barrier
+  auto step = [&](const bool chk, const int k) __attribute__((always_inline)) {
     STAMP(6)
     // (1) core right-hand side
     {
-      const double dv = (RL_ABLATE & 1) ? 0.0 : rl_dot_col<CW>(wcol, vcol, co, s_tv);
-      if (cown >= 0) s_rv[rvpos] = (sigma * xcv - qc) + dv;
+      const double dv = (RL_ABLATE & 1) ? 0.0 : (RL_VARIANT & 128) ? rl_dot_col_pre<CW>(wcol, pcol, co, s_tv) : rl_dot_col<CW>(wcol, vcol, co, s_tv);
+      if (cown >= 0) rvw[k * RVS] = (sigma * xcv - qc) + dv;
     }
     STAMP(0)
     if (!(RL_ABLATE & 16)) __syncthreads();
@@ -877,14 +1025,24 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     //     DPP row and are added with row shifts (no LDS round trip, no extra barrier)
     {
       double rr_[TC], acc[TR], tot[RL_NT(TR)];
+      if constexpr (AL) {
 #pragma unroll
-      for (int cc = 0; cc < TC; cc++) rr_[cc] = s_rv[gj * TCP + cc];
+        for (int cc = 0; cc < TC; cc += 2) { const dbl2 v2 = rvr[(k * RVS + cc) / 2]; rr_[cc] = v2.x; rr_[cc + 1] = v2.y; }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < TC; cc++) rr_[cc] = s_rv[gj * TCP + cc];
+      }
 #pragma unroll
       for (int rr = 0; rr < TR; rr++) {
         acc[rr] = 0.0;
 #pragma unroll
         for (int cc = 0; cc < ((RL_ABLATE & 4) ? 1 : TC); cc++) acc[rr] += wreg[rr][cc] * rr_[cc];
       }
+      if constexpr (AL) {
+        const double t = (RL_ABLATE & 8) ? acc[0] : rl_reduce_al(acc);
+        if (xout >= 0) s_xc[xout] = t;
+        (void)tot;
+      } else {
       if (RL_ABLATE & 8) {
 #pragma unroll
         for (int nn = 0; nn < RL_NT(TR); nn++) tot[nn] = acc[nn];
@@ -897,50 +1055,73 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           if (rr < TR && gi * TR + rr < n_c) s_xc[gi * TR + rr] = tot[nn];
         }
       }
+      }
+    }
+    dbl2 prow[NS][RW / 2];
+    if (RL_VARIANT & 128) {
+#pragma unroll
+      for (int q = 0; q < NS; q++) rl_vals<RW / 2, false>(wr[q], vr[q], prow[q]);
     }
     STAMP(2)
-    if (!(RL_ABLATE & 16)) __syncthreads();
+    // aligned form: the totals a row gathers were stored by its own wavefront
+    if constexpr (AL) RL_WAVE_SYNC() else if (!(RL_ABLATE & 16)) __syncthreads();
     STAMP(3)
     // (Y) rows, eliminated variable, updates, next t'
     {
-      double zc[NS];
+      // `M`: the row slots this WAVEFRONT uses at all (wave-uniform; r03): a wavefront that only holds columns skips
+      // the whole update chain, one whose rows all sit in slot 0 the second slot's half of it.  A skipped slot holds no
+      // row in any lane: a_e = z = y = 0 there, so its terms are exact zeros and its state never changes.
+      auto rows = [&](auto M) __attribute__((always_inline)) {
+        constexpr int msk = decltype(M)::value;
+        double zc[NS];
 #pragma unroll
-      for (int q = 0; q < NS; q++) zc[q] = (RL_ABLATE & 2) ? s_xc[q] : rl_dot_row(wr[q], vr[q], ro[q], s_xc);
-      // x~_e = g_e - (1/K_ee) sum_i rw_i a_ie (A_iC x~_C)
-      const double xte = ge - kinv * ((r_w[0] * r_rho[0]) * r_ae[0] * zc[0] + (r_w[1] * r_rho[1]) * r_ae[1] * zc[1]);
-      double tq[NS], dyq[NS];
+        for (int q = 0; q < NS; q++) zc[q] = !((msk >> q) & 1) ? 0.0 : (RL_ABLATE & 2) ? s_xc[q] : (RL_VARIANT & 128) ? rl_dot_row_pre<RW>(wr[q], prow[q], ro[q], s_xc) : rl_dot_row(wr[q], vr[q], ro[q], s_xc);
+        // x~_e = g_e - (1/K_ee) sum_i rw_i a_ie (A_iC x~_C)
+        const double xte = (msk & 2) ? ge - kinv * ((r_w[0] * r_rho[0]) * r_ae[0] * zc[0] + (r_w[1] * r_rho[1]) * r_ae[1] * zc[1])
+                                     : ge - kinv * ((r_w[0] * r_rho[0]) * r_ae[0] * zc[0]);
+        double tq[NS], dyq[NS];
 #pragma unroll
-      for (int q = 0; q < NS; q++) {
-        const double zt = zc[q] + r_ae[q] * xte;
-        const double zr = alpha * zt + (1.0 - alpha) * r_z[q];
-        double zn = zr + r_rinv[q] * r_y[q];
-        zn = fmin(fmax(zn, r_ls[q]), r_us[q]);
-        dyq[q] = r_rho[q] * (zr - zn);
-        r_y[q] += dyq[q]; r_z[q] = zn;
-        tq[q] = r_w[q] * (r_rho[q] * zn - r_y[q]);
-      }
-      if (eown >= 0) {
-        const double xn = alpha * xte + (1.0 - alpha) * xe;
-        dxe = xn - xe; xe = xn;
-        const double rhs_e = (sigma * xe - qe) + r_ae[0] * tq[0] + r_ae[1] * tq[1];
-        ge = rhs_e * kinv;
-      }
-#pragma unroll
-      for (int q = 0; q < NS; q++)
-        if (r_p[q] >= 0) {
-          s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
-          if (chk) { swy[r_p[q]] = r_w[q] * r_y[q]; sdy[r_p[q]] = dyq[q]; }
+        for (int q = 0; q < NS; q++) {
+          tq[q] = dyq[q] = 0.0;
+          if (!((msk >> q) & 1)) continue;
+          const double zt = zc[q] + r_ae[q] * xte;
+          const double zr = alpha * zt + (1.0 - alpha) * r_z[q];
+          double zn = zr + r_rinv[q] * r_y[q];
+          zn = fmin(fmax(zn, r_ls[q]), r_us[q]);
+          dyq[q] = r_rho[q] * (zr - zn);
+          r_y[q] += dyq[q]; r_z[q] = zn;
+          tq[q] = r_w[q] * (r_rho[q] * zn - r_y[q]);
         }
+        if (eown >= 0) {
+          const double xn = alpha * xte + (1.0 - alpha) * xe;
+          if (chk) dxe = xn - xe;           // only the termination test reads the steps
+          xe = xn;
+          const double rhs_e = (msk & 2) ? (sigma * xe - qe) + r_ae[0] * tq[0] + r_ae[1] * tq[1] : (sigma * xe - qe) + r_ae[0] * tq[0];
+          ge = rhs_e * kinv;
+        }
+#pragma unroll
+        for (int q = 0; q < NS; q++)
+          if (((msk >> q) & 1) && r_p[q] >= 0) {
+            s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
+            if (chk) { swy[r_p[q]] = r_w[q] * r_y[q]; sdy[r_p[q]] = dyq[q]; }
+          }
+      };
+      if (!(RL_VARIANT & 64)) rows(std::integral_constant<int, (1 << NS) - 1>());
+      else if (NS == 2 && rmask == 1) rows(std::integral_constant<int, 1>());
+      else if (rmask != 0) rows(std::integral_constant<int, (1 << NS) - 1>());
       if (cown >= 0) {
         const double xn = alpha * s_xc[cown] + (1.0 - alpha) * xcv;
-        dxc = xn - xcv; xcv = xn;
+        if (chk) dxc = xn - xcv;
+        xcv = xn;
         if (chk) { sxc[cown] = xn; sdxc[cown] = dxc; }
       }
+      if ((RL_VARIANT & 128) && !chk) rl_vals<CW / 2, true>(wcol, vcol, pcol);      // for the next step's phase (1)
       STAMP(4)
       // closed assignment: the next phase (1) reads only t' written by its own wavefront (LDS operations of one
       // wavefront complete in order), every other hazard is covered by the two remaining barriers; the
       // termination test after a checked step reads what all wavefronts have just written
       if ((chk || !merged) && (chk || !(RL_ABLATE & 16))) __syncthreads();
+      else RL_WAVE_SYNC()
       STAMP(5)
     }
   };
@@ -950,15 +1131,18 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   while (!status && iter < stop && !(ADAPT && rho_new > 0.0)) {
     int next = stop;
     if (a.check > 0) { next = (iter / a.check + 1) * a.check; if (next > stop) next = stop; }
+    if (RL_VARIANT & 128) rl_vals<CW / 2, true>(wcol, vcol, pcol);
     // twelve iterations per trip (two trips between termination tests at the default cadence of 25): a loop trip
     // costs several hundred cycles of instruction refetch (profiles/r01_v6_stamps.txt); 24 copies overflow the
     // instruction cache and are slower (1.33 against 1.26 us per iteration)
     if (!(RL_VARIANT & 8))
-    while (iter + 12 < next) { iter += 12; step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); }
-    while (iter + 8 < next) { iter += 8; step(false); step(false); step(false); step(false); step(false); step(false); step(false); step(false); }
-    while (iter + 4 < next) { iter += 4; step(false); step(false); step(false); step(false); }
-    while (iter + 1 < next) { iter++; step(false); }
-    iter++; if (RL_VARIANT & 32) step(false); else step(true);
+    while (iter + 12 < next) { iter += 12; step(false, 0); step(false, 1); step(false, 0); step(false, 1); step(false, 0); step(false, 1); step(false, 0); step(false, 1); step(false, 0); step(false, 1); step(false, 0); step(false, 1); }
+    while (iter + 8 < next) { iter += 8; step(false, 0); step(false, 1); step(false, 0); step(false, 1); step(false, 0); step(false, 1); step(false, 0); step(false, 1); }
+    while (iter + 4 < next) { iter += 4; step(false, 0); step(false, 1); step(false, 0); step(false, 1); }
+    // the steps come in pairs (first buffer, second buffer); a single step is followed by a barrier, so that the first
+    // buffer can be written again at once (the checked step ends with one anyway)
+    while (iter + 1 < next) { iter++; step(false, 0); if constexpr (AL) __syncthreads(); }
+    iter++; if (RL_VARIANT & 32) { step(false, 0); if constexpr (AL) __syncthreads(); } else step(true, 0);
     {
       // ---- termination test (formulas of admm_check in sco_qp.hip) ---------------------
       CSTAMP0
@@ -1189,7 +1373,7 @@ int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd) {
   return SCO_OK;
 }
 
-template <int TR, int TC, int CW, bool ADAPT, int NS = 2>
+template <int TR, int TC, int CW, bool ADAPT, int NS = 2, bool AL = false>
 static int rl_launch_k(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
   // hipFuncSetAttribute applies to the current device only
   static bool attr_done[64] = {};
@@ -1197,18 +1381,18 @@ static int rl_launch_k(const RlArgs &ra, int batch, size_t lds, hipStream_t st) 
   (void)hipGetDevice(&dev_);
   dev_ &= 63;
   if (!attr_done[dev_]) {
-    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS, AL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 108 * 1024));
     attr_done[dev_] = true;
   }
-  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS>), dim3(batch), dim3(LT), lds, st, ra);
+  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS, AL>), dim3(batch), dim3(LT), lds, st, ra);
   SCO_HIP(hipGetLastError());
   return SCO_OK;
 }
-template <int TR, int TC, int CW = LCW, int NS = 2>
+template <int TR, int TC, int CW = LCW, int NS = 2, bool AL = false>
 static int rl_launch_one(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
   // the adaptive-rho variant is a separate instantiation: the default kernel's code is untouched by it
-  return ra.ad_interval > 0 ? rl_launch_k<TR, TC, CW, true, NS>(ra, batch, lds, st) : rl_launch_k<TR, TC, CW, false, NS>(ra, batch, lds, st);
+  return ra.ad_interval > 0 ? rl_launch_k<TR, TC, CW, true, NS, AL>(ra, batch, lds, st) : rl_launch_k<TR, TC, CW, false, NS, AL>(ra, batch, lds, st);
 }
 
 int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t st) {
@@ -1239,6 +1423,11 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
     extern double *sco_debug_stamp_ptr; sco_debug_stamp_ptr = g_stamp;
   }
 #endif
+  if (rh.aligned) {
+    // aligned closed assignment: 3 x 18 tiles, one barrier per iteration
+    if (rh.CW > LCW) return rl_launch_one<AL_TR, AL_TC, LCW_MAX, 2, true>(ra, nwg, rh.lds_bytes, st);
+    return rl_launch_one<AL_TR, AL_TC, LCW, 2, true>(ra, nwg, rh.lds_bytes, st);
+  }
   if (rh.NS == 3) {
     // three row slots per thread and ten operand pairs per column (velocity + joint limits at 7-DOF x 20: 1100 rows)
     if (rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW_MAX3, 3>(ra, nwg, rh.lds_bytes, st);

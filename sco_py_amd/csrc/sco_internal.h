@@ -127,6 +127,8 @@ struct RlHost {
   int pcw = 0;                     // most P entries in a core variable's column (<= 4: cached in LDS for the termination test)
   int zpos = 0;                    // LDS position of the always-zero pair of the row vectors
   bool merged = false;             // closed thread assignment: phases (Y) and (1) share a wavefront, one barrier less per iteration
+  bool aligned = false;            // closed assignment + the W rows of a wavefront's core columns in that wavefront: phases
+                                   // (3), (Y), (1) are wavefront-local, ONE barrier per iteration (double-buffered right-hand side)
   int NS = 2;                      // row slots per thread (3: patterns with more than 1024 rows)
   SellHost Ac, Ar[3];
   size_t lds_bytes = 0;
