@@ -217,6 +217,13 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
   std::vector<std::vector<int>> wave_cols;
   rh.aligned = allow_aligned && ns_min == 2 && al && al[0] == '1' && pl.n_c > 128 && pl.n_c <= 8 * AL_TC &&
                rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim, AL_ROWS, &wave_cols);
+  // The 8-column-group W layout with the OPEN assignment (r03): the W phase costs 3 swap folds + one quad step per
+  // wavefront instead of 5 + 4 (a lane-swap instruction costs ~12 cycles, a multiply-add 4.5: scripts/microbench/inst_cost.hip),
+  // six wavefronts carry W rows instead of eight.  Measured neutral without and slower with the termination test
+  // (0.929 / 1.048 against 0.932 / 1.009 us per iteration, profiles/r03_ab.txt): 54 instead of 45 multiply-adds and 9
+  // instead of 5 reads of the right-hand side eat what the reduction saves.  Opt-in: SCO_QP_RL_LAY8=1.
+  const char *l8 = getenv("SCO_QP_RL_LAY8");
+  rh.lay8 = !rh.aligned && ns_min == 2 && l8 && l8[0] == '1' && pl.n_c > 128 && pl.n_c <= 8 * AL_TC;
   rh.merged = rh.aligned ||
               (ns_min == 2 && closed && closed[0] == '1' && rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim));
   if (!rh.merged) {
@@ -245,6 +252,7 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
       if (ns == LNS_MAX) return false;
     }
   }
+  if (rh.NS != 2) rh.lay8 = false;
   // ---- LDS positions of the row vectors (t', and w y / dy of the termination test).  A gather-dot reads its
   // operands two at a time (one ds_read_b128 per aligned PAIR of positions), so rows that one column reads together
   // should sit next to each other: rows with several core entries grouped by their set of columns (the rows of one
@@ -401,11 +409,13 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
       rh.role[(size_t)2 * LT + t] = e; rh.role[(size_t)3 * LT + t] = pl.elim_var[e];
       rh.role[(size_t)12 * LT + t] = pl.Pdiag[pl.elim_var[e]];
     }
-    if (rh.aligned) {
+    if (rh.aligned || rh.lay8) {
       const int wv = t / 64, lane = t % 64, g = (lane >> 1) & 7, h = (lane >> 4) & 3;
       for (int rr = 0; rr < AL_TR; rr++) {
         const int lr = g * AL_TR + rr;
-        rh.role[(size_t)ROLE_WROW(rr) * LT + t] = lr < (int)wave_cols[wv].size() ? wave_cols[wv][lr] : -1;
+        // open assignment: wavefront w carries the W rows 24 w .. 24 w + 23 (six wavefronts at 140 core variables)
+        rh.role[(size_t)ROLE_WROW(rr) * LT + t] = rh.aligned ? (lr < (int)wave_cols[wv].size() ? wave_cols[wv][lr] : -1)
+                                                             : (wv * AL_ROWS + lr < pl.n_c ? wv * AL_ROWS + lr : -1);
       }
       // after the folds (rl_reduce_al) the total of tile row 0 / 1 / 2 sits in the lanes with (bit 5, bit 4) = 00 / 10 / 01
       const int rr_out = h == 0 ? 0 : h == 2 ? 1 : h == 1 ? 2 : -1;
@@ -441,7 +451,8 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
   rh.TC = 2 * rh.TR;
   if (rh.TR == 5 && pl.n_c <= LGJ * 9) rh.TC = 9;
   if (rh.CW > LCW && rh.TR != 5) return false;        // the wide variants exist for the 5-row tiles only
-  if (rh.aligned) { rh.TR = AL_TR; rh.TC = AL_TC; }
+  if (rh.NS != 2) rh.lay8 = false;
+  if (rh.aligned || rh.lay8) { rh.TR = AL_TR; rh.TC = AL_TC; }
   return rh.lds_bytes + 40 * 1024 <= 160 * 1024;   // + 37.5 KB of static LDS
 }
 
@@ -770,9 +781,12 @@ __device__ __forceinline__ double rl_reduce_al(const double (&acc)[AL_TR]) {
 #define RL_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
-template <int TR, int TC, int CW, bool ADAPT, int NS = 2, bool AL = false>
+// LAY: 0 = 16 column groups of the W tile (5 x 9 at 140 core variables), 1 = 8 column groups (3 x 18, cheaper reduction, six
+// of the eight wavefronts carry W), 2 = 8 column groups with the aligned closed assignment (one barrier per iteration)
+template <int TR, int TC, int CW, bool ADAPT, int NS = 2, int LAY = 0>
 __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
-  static_assert(!AL || (TR == AL_TR && TC == AL_TC && NS == 2), "aligned layout: 3 x 18 tiles, two row slots");
+  constexpr bool L8 = LAY != 0, AL = LAY == 2;
+  static_assert(!L8 || (TR == AL_TR && TC == AL_TC && NS == 2), "8-column-group layout: 3 x 18 tiles, two row slots");
   const int b = a.list ? a.list[blockIdx.x + a.b0] : (int)blockIdx.x + a.b0, tid = threadIdx.x;
   if (b < 0 || (a.active && !a.active[b])) return;
   const int n = a.n, m = a.m, n_e = a.n_e, n_c = a.n_c;
@@ -783,7 +797,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   // core right-hand side: the TC entries of column group gj start at gj * TCP (TCP = TC rounded up to even), so a
   // thread reads its tile's entries with 16-byte LDS reads (half the LDS cycles of 8-byte pairs)
   constexpr int TCP = (RL_VARIANT & 4) ? TC : ((TC + 1) & ~1);
-  static_assert((AL ? 8 : LGJ) * TCP <= LCAP_NC + 16, "padded right-hand side");
+  static_assert((L8 ? 8 : LGJ) * TCP <= LCAP_NC + 16, "padded right-hand side");
   // aligned form: two buffers used in turn (one barrier per iteration: a fast wavefront writes the next right-hand side
   // while a slow one still reads the current one)
   constexpr int RVS = AL ? LCAP_NC + 16 : 0;
@@ -831,7 +845,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   // W tile of this thread: row group gi (4 per wavefront: bits 2-3 of the lane), column group gj (bits 0-1 and
   // 4-5 of the lane: the 16 lanes whose partial sums rl_reduce_rows adds)
   // (aligned layout: 8 column groups = lane bits 0, 4, 5; the tile rows come from the role table)
-  const int gi = (tid >> 6) * 4 + ((tid >> 2) & 3), gj = AL ? (tid & 1) + 2 * ((tid >> 4) & 3) : (tid & 3) + 4 * ((tid >> 4) & 3);
+  const int gi = (tid >> 6) * 4 + ((tid >> 2) & 3), gj = L8 ? (tid & 1) + 2 * ((tid >> 4) & 3) : (tid & 3) + 4 * ((tid >> 4) & 3);
   const int wrow_h = (tid >> 4) & 3;                 // DPP row of the lane: which tile rows' totals it receives
   double wreg[TR][TC];
   {
@@ -840,11 +854,12 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     for (int rr = 0; rr < TR; rr++)
 #pragma unroll
       for (int cc = 0; cc < TC; cc++) {
-        const int row = AL ? a.role[(size_t)ROLE_WROW(rr) * LT + tid] : gi * TR + rr, col = gj * TC + cc;
+        const int row = L8 ? a.role[(size_t)ROLE_WROW(rr) * LT + tid] : gi * TR + rr, col = gj * TC + cc;
         wreg[rr][cc] = (row >= 0 && row < n_c && col < n_c) ? W[(size_t)row * n_c + col] : 0.0;
       }
   }
-  const int xout = AL ? a.role[(size_t)ROLE_XOUT * LT + tid] : -1;     // aligned: core index of the total this lane stores
+  const int xout = L8 ? a.role[(size_t)ROLE_XOUT * LT + tid] : -1;     // 8 column groups: core index of the total this lane stores
+  const bool wwave = !L8 || __builtin_amdgcn_readfirstlane(__any(a.role[(size_t)ROLE_WROW(0) * LT + tid] >= 0) ? 1 : 0) != 0;   // this wavefront carries W rows
   // core-variable state
   const int cown = a.role[tid];
   const int cvar = cown >= 0 ? a.role[(size_t)LT + tid] : 0;
@@ -1023,9 +1038,9 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     STAMP(1)
     // (3) register-tile mat-vec; the 16 partial sums of a row sit in the 16 lanes of a
     //     DPP row and are added with row shifts (no LDS round trip, no extra barrier)
-    {
+    if (wwave) {          // (8 column groups: two of the eight wavefronts hold no W rows and go straight to the barrier)
       double rr_[TC], acc[TR], tot[RL_NT(TR)];
-      if constexpr (AL) {
+      if constexpr (L8) {
 #pragma unroll
         for (int cc = 0; cc < TC; cc += 2) { const dbl2 v2 = rvr[(k * RVS + cc) / 2]; rr_[cc] = v2.x; rr_[cc + 1] = v2.y; }
       } else {
@@ -1038,7 +1053,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
 #pragma unroll
         for (int cc = 0; cc < ((RL_ABLATE & 4) ? 1 : TC); cc++) acc[rr] += wreg[rr][cc] * rr_[cc];
       }
-      if constexpr (AL) {
+      if constexpr (L8) {
         const double t = (RL_ABLATE & 8) ? acc[0] : rl_reduce_al(acc);
         if (xout >= 0) s_xc[xout] = t;
         (void)tot;
@@ -1373,7 +1388,7 @@ int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd) {
   return SCO_OK;
 }
 
-template <int TR, int TC, int CW, bool ADAPT, int NS = 2, bool AL = false>
+template <int TR, int TC, int CW, bool ADAPT, int NS = 2, int LAY = 0>
 static int rl_launch_k(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
   // hipFuncSetAttribute applies to the current device only
   static bool attr_done[64] = {};
@@ -1381,18 +1396,18 @@ static int rl_launch_k(const RlArgs &ra, int batch, size_t lds, hipStream_t st) 
   (void)hipGetDevice(&dev_);
   dev_ &= 63;
   if (!attr_done[dev_]) {
-    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS, AL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SCO_HIP(hipFuncSetAttribute((const void *)qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS, LAY>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 108 * 1024));
     attr_done[dev_] = true;
   }
-  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS, AL>), dim3(batch), dim3(LT), lds, st, ra);
+  hipLaunchKernelGGL((qp_admm_rl_kernel<TR, TC, CW, ADAPT, NS, LAY>), dim3(batch), dim3(LT), lds, st, ra);
   SCO_HIP(hipGetLastError());
   return SCO_OK;
 }
-template <int TR, int TC, int CW = LCW, int NS = 2, bool AL = false>
+template <int TR, int TC, int CW = LCW, int NS = 2, int LAY = 0>
 static int rl_launch_one(const RlArgs &ra, int batch, size_t lds, hipStream_t st) {
   // the adaptive-rho variant is a separate instantiation: the default kernel's code is untouched by it
-  return ra.ad_interval > 0 ? rl_launch_k<TR, TC, CW, true, NS, AL>(ra, batch, lds, st) : rl_launch_k<TR, TC, CW, false, NS, AL>(ra, batch, lds, st);
+  return ra.ad_interval > 0 ? rl_launch_k<TR, TC, CW, true, NS, LAY>(ra, batch, lds, st) : rl_launch_k<TR, TC, CW, false, NS, LAY>(ra, batch, lds, st);
 }
 
 int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t st) {
@@ -1425,8 +1440,13 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
 #endif
   if (rh.aligned) {
     // aligned closed assignment: 3 x 18 tiles, one barrier per iteration
-    if (rh.CW > LCW) return rl_launch_one<AL_TR, AL_TC, LCW_MAX, 2, true>(ra, nwg, rh.lds_bytes, st);
-    return rl_launch_one<AL_TR, AL_TC, LCW, 2, true>(ra, nwg, rh.lds_bytes, st);
+    if (rh.CW > LCW) return rl_launch_one<AL_TR, AL_TC, LCW_MAX, 2, 2>(ra, nwg, rh.lds_bytes, st);
+    return rl_launch_one<AL_TR, AL_TC, LCW, 2, 2>(ra, nwg, rh.lds_bytes, st);
+  }
+  if (rh.lay8) {
+    // 8 column groups, open assignment (three barriers)
+    if (rh.CW > LCW) return rl_launch_one<AL_TR, AL_TC, LCW_MAX, 2, 1>(ra, nwg, rh.lds_bytes, st);
+    return rl_launch_one<AL_TR, AL_TC, LCW, 2, 1>(ra, nwg, rh.lds_bytes, st);
   }
   if (rh.NS == 3) {
     // three row slots per thread and ten operand pairs per column (velocity + joint limits at 7-DOF x 20: 1100 rows)

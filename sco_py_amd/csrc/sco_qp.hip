@@ -1227,11 +1227,12 @@ extern "C" int sco_debug_plan_build(int n, int m, const int *Pp, const int *Pi, 
 }
 // Host-only: would the pattern last given to sco_debug_plan_build land on the row-local tier, and with what shape?
 // info[0] fits, [1] CW (value slots per column = 2 x operand pairs), [2] TR, [3] TC, [4] dynamic LDS bytes, [5] closed plan,
-// [6] aligned closed plan (one barrier per iteration), [7] row slots per thread
+// [6] 1 = aligned closed plan (one barrier per iteration), 2 = 8 column groups of the W tile with the open assignment,
+// [7] row slots per thread
 extern "C" int sco_debug_rl_plan(int *info) {
   RlHost rh;
   const bool ok = rl_plan_build(g_dbg_plan, rh);
-  info[0] = ok ? 1 : 0; info[1] = rh.CW; info[2] = rh.TR; info[3] = rh.TC; info[4] = (int)rh.lds_bytes; info[5] = rh.merged ? 1 : 0; info[6] = rh.aligned ? 1 : 0; info[7] = rh.NS;
+  info[0] = ok ? 1 : 0; info[1] = rh.CW; info[2] = rh.TR; info[3] = rh.TC; info[4] = (int)rh.lds_bytes; info[5] = rh.merged ? 1 : 0; info[6] = rh.aligned ? 1 : rh.lay8 ? 2 : 0; info[7] = rh.NS;
   return SCO_OK;
 }
 extern "C" int sco_debug_plan_get(const char *name, int *out, int cap) {

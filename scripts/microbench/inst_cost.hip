@@ -1,0 +1,122 @@
+// Instruction-cost micro-benchmark for the row-local ADMM kernel's building blocks (diagnostic only): what one
+// wavefront-instruction of each kind costs when 1 or 2 wavefronts share a SIMD, and what a barrier hand-over through LDS
+// costs.  One workgroup on one CU; cycles from s_memtime around REPS repetitions of an unrolled body.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/inst_cost scripts/microbench/inst_cost.hip && /tmp/inst_cost
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REPS 2000
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double fold32(double a, double b) {
+  const u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double fold16(double a, double b) {
+  const u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double quad1(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return v + __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xb1, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, 0xb1, 0xf, 0xf, true));
+}
+
+// mode: 0 independent fma (10 chains x 10), 1 dependent fma chain (100), 2 fold32 x 20 (dependent pairs), 3 fold16 x 20,
+//       4 quad step x 20 (dependent), 5 barrier x 10, 6 LDS write -> barrier -> read (b64) x 10, 7 ds_read_b128 x 16 + wait,
+//       8 the r02 5-row reduction (fold32 x3, fold16 x2, quad x4), 9 dependent ds_read_b64 chain (pointer chase) x 20
+template <int MODE>
+__global__ __launch_bounds__(512) void k(double *out, long long *cyc, int reps) {
+  __shared__ __attribute__((aligned(16))) double lds[4096];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 4096; i += blockDim.x) lds[i] = (double)((i * 7 + 3) % 4096) * 8.0;   // also a pointer-chase table (byte offsets)
+  __syncthreads();
+  double a[10];
+  for (int i = 0; i < 10; i++) a[i] = 1.0 + tid * 1e-3 + i;
+  double x = 1.0000001, y = 1e-9;
+  unsigned int p = (tid * 8) & 32767;
+  const long long t0 = __builtin_readcyclecounter();
+  for (int r = 0; r < reps; r++) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 10; j++)
+#pragma unroll
+        for (int i = 0; i < 10; i++) a[i] = __builtin_fma(a[i], x, y);
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < 100; j++) a[0] = __builtin_fma(a[0], x, y);
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int j = 0; j < 20; j++) a[0] = fold32(a[0], a[1]);
+    } else if (MODE == 3) {
+#pragma unroll
+      for (int j = 0; j < 20; j++) a[0] = fold16(a[0], a[1]);
+    } else if (MODE == 4) {
+#pragma unroll
+      for (int j = 0; j < 20; j++) a[0] = quad1(a[0]);
+    } else if (MODE == 5) {
+#pragma unroll
+      for (int j = 0; j < 10; j++) __syncthreads();
+    } else if (MODE == 6) {
+#pragma unroll
+      for (int j = 0; j < 10; j++) {
+        lds[(tid + j) & 4095] = a[0];
+        __syncthreads();
+        a[0] += lds[(tid * 5 + 17 * j) & 4095];
+        __syncthreads();
+      }
+    } else if (MODE == 7) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      d2 v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = *(const d2 *)(lds + ((2 * tid + 128 * j) & 4094));
+#pragma unroll
+      for (int j = 0; j < 16; j++) a[j % 10] += v[j].x + v[j].y;
+    } else if (MODE == 8) {
+      const double u0 = fold32(a[0], a[1]), u1 = fold32(a[2], a[3]), u2_ = fold32(a[4], 0.0);
+      double t0_ = fold16(u0, u1), t1_ = fold16(u2_, 0.0);
+      t0_ = quad1(t0_); t1_ = quad1(t1_);
+      const int lo = __double2loint(t0_), hi = __double2hiint(t0_), lo1 = __double2loint(t1_), hi1 = __double2hiint(t1_);
+      t0_ += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4e, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, 0x4e, 0xf, 0xf, true));
+      t1_ += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi1, 0x4e, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo1, 0x4e, 0xf, 0xf, true));
+      a[0] = t0_; a[1] = t1_; a[2] += t0_; a[3] += t1_; a[4] += t0_;
+    } else if (MODE == 9) {
+#pragma unroll
+      for (int j = 0; j < 20; j++) p = (unsigned int)*(const double *)((const char *)lds + p);
+    }
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  double s = 0;
+  for (int i = 0; i < 10; i++) s += a[i];
+  out[blockIdx.x * blockDim.x + tid] = s + p;
+  if ((tid & 63) == 0) cyc[tid >> 6] = t1 - t0;
+}
+
+template <int MODE>
+static void run(const char *name, int per_rep, int threads) {
+  double *out; long long *cyc;
+  hipMalloc(&out, 512 * 8); hipMalloc(&cyc, 8 * 8);
+  k<MODE><<<1, threads>>>(out, cyc, 10); hipDeviceSynchronize();
+  k<MODE><<<1, threads>>>(out, cyc, REPS); hipDeviceSynchronize();
+  std::vector<long long> h(8); hipMemcpy(h.data(), cyc, 64, hipMemcpyDeviceToHost);
+  long long mx = 0; for (int w = 0; w < threads / 64; w++) mx = std::max(mx, h[w]);
+  printf("%-44s %4d threads: %8.1f cycles per repetition = %6.2f per item (%d items)\n", name, threads, (double)mx / REPS, (double)mx / REPS / per_rep, per_rep);
+  hipFree(out); hipFree(cyc);
+}
+int main() {
+  for (int threads : {64, 256, 512}) {
+    run<0>("v_fma_f64 independent", 100, threads);
+    run<1>("v_fma_f64 dependent chain", 100, threads);
+    run<2>("fold32 (2 permlane32_swap + add), dependent", 20, threads);
+    run<3>("fold16 (2 permlane16_swap + add), dependent", 20, threads);
+    run<4>("quad step (2 mov_dpp + add), dependent", 20, threads);
+    run<5>("s_barrier", 10, threads);
+    run<6>("LDS write -> barrier -> read -> barrier", 10, threads);
+    run<7>("16 ds_read_b128 + 16 adds", 16, threads);
+    run<8>("5-row reduction of the W phase", 1, threads);
+    run<9>("dependent ds_read_b64 (pointer chase)", 20, threads);
+  }
+  return 0;
+}

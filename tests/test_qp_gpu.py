@@ -527,3 +527,30 @@ def test_closed_thread_assignment_gives_the_same_answer(gpu, monkeypatch):
     closed = _check(probs)
     assert np.array_equal(base[2], closed[2]) and np.array_equal(base[3], closed[3])
     assert np.abs(base[1] - closed[1]).max() < 1e-10
+
+
+@pytest.mark.parametrize("switch", ["SCO_QP_RL_ALIGNED", "SCO_QP_RL_LAY8"])
+def test_opt_in_layouts_of_the_row_local_kernel_give_the_same_answer(gpu, monkeypatch, switch):
+    """r03 experiments kept as opt-ins (both measured not faster, profiles/r03_ab.txt): SCO_QP_RL_ALIGNED=1 -- every
+    wavefront owns whole timesteps (rows, columns and the W rows of those columns), one barrier per iteration, double-
+    buffered right-hand side; SCO_QP_RL_LAY8=1 -- 3 x 18 W tiles with 8 column groups under the open assignment.  Same
+    status and iteration count as the default plan and as the oracle, solutions to 1e-10 (the W mat-vec sums in a different
+    order).  Parked / resumed solves of these layouts: test_sqp_gpu.py::test_opt_in_layouts_through_the_sliced_sqp_loop."""
+    rng = np.random.default_rng(23)
+    probs = [penalty_qp(rng, 20, 7, 10) for _ in range(3)]
+    base = _check(probs)
+    monkeypatch.setenv(switch, "1")
+    alt = _check(probs)
+    assert np.array_equal(base[2], alt[2]) and np.array_equal(base[3], alt[3])
+    assert np.abs(base[1] - alt[1]).max() < 1e-10
+    # the plan really is the opt-in one
+    import ctypes as C
+    n, m, Pp, Pi, Ap, Ai = _stack(probs[:1])[:6]
+    lib = _lib.load()
+    ip = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int))
+    sizes = np.zeros(16, dtype=np.int32); info = np.zeros(8, dtype=np.int32)
+    lib.sco_debug_plan_build.argtypes = [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4 + [C.c_int, C.POINTER(C.c_int)]
+    lib.sco_debug_rl_plan.argtypes = [C.POINTER(C.c_int)]
+    assert lib.sco_debug_plan_build(n, m, ip(Pp), ip(Pi), ip(Ap), ip(Ai), 1, ip(sizes)) == 0
+    assert lib.sco_debug_rl_plan(ip(info)) == 0
+    assert info[0] == 1 and info[6] == (1 if switch.endswith("ALIGNED") else 2) and info[2] == 3 and info[3] == 18

@@ -955,3 +955,22 @@ def test_objective_family_call_order_and_limits(gpu):
                     arrays["point_frac"], arrays["obstacles"], cost_weight=-1.0, cost_target=arrays["cost_target"])
     with pytest.raises(_lib.ScoHipError):
         sb.TrajOptBatch(1, 17, 4, 1, 1, ee_cost=True)          # the block Hessian is handled per thread: dof <= 16
+
+
+@pytest.mark.parametrize("switch", ["SCO_QP_RL_ALIGNED", "SCO_QP_RL_LAY8"])
+def test_opt_in_layouts_through_the_sliced_sqp_loop(gpu, monkeypatch, switch):
+    """The opt-in layouts of the row-local ADMM kernel (r03, csrc/sco_admm_rl.hip: aligned closed assignment with one
+    barrier per iteration; 3 x 18 W tiles) under the device loop: parked / resumed solves (time slices of 1000 iterations),
+    cold and slice-free runs agree bit for bit with each other, and with the oracle decision for decision."""
+    monkeypatch.setenv(switch, "1")
+    arrays, probs = af.make_batch(6)
+    outs = []
+    with sb.TrajOptBatch(6, 7, 20, 5, 2) as tb:
+        tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                arrays["point_frac"], arrays["obstacles"])
+        for sl in (-1, 1000):
+            tb.solve(_lib.default_sqp_params(admm_slice=sl))
+            r = tb.fetch(); r.trace = tb.trace()
+            outs.append(r)
+    assert np.array_equal(outs[0].x, outs[1].x) and np.array_equal(outs[0].admm_iters, outs[1].admm_iters)
+    _compare(outs[1], probs, range(2))
