@@ -240,14 +240,18 @@ def main():
         cpu_all = cpu_baseline_all_cores(dict(d=7, T=20, K=5, O=2))
     import torch
     import torch.distributed as dist
-    # rehearsal on a 1-GPU box: SCO_BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo
-    # (RCCL refuses two ranks on one device); the driver's real multi-GPU run never sets it
-    rehearse = os.environ.get("SCO_BENCH_REHEARSE", "0") == "1"
+    # rehearsal on a 1-GPU box: SCO_BENCH_REHEARSE=1 (or "gloo") puts every rank on device 0 and uses gloo;
+    # SCO_BENCH_REHEARSE=nccl keeps the RCCL branch (init with device_id, all-gather and max-reduce on device tensors) with
+    # every rank on device 0 -- RCCL may refuse two ranks on one device, then the run fails at init and says so.
+    # The driver's real multi-GPU run never sets the variable.
+    rehearse_mode = os.environ.get("SCO_BENCH_REHEARSE", "0")
+    rehearse = rehearse_mode in ("1", "gloo", "nccl")
+    use_gloo = rehearse_mode in ("1", "gloo")
     if rehearse:
         local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        if rehearse:
+        if use_gloo:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -286,7 +290,7 @@ def main():
         for _ in range(warmup):
             sd.solve_sharded(tb, total, params, qs)
         # the interpreter's cyclic collector walks every object torch has imported (a full pass took 40-75 ms in the
-        # middle of a step, scripts/experiments/host_overhead.py): park what exists now in the permanent generation
+        # middle of a step): park what exists now in the permanent generation
         import gc
         gc.collect(); gc.freeze()
         sync()
@@ -311,7 +315,7 @@ def main():
         qp_solves = steps * int(res.qp_solves.sum())
         tb.close()
         if world > 1:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if use_gloo else "cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         return dict(dims=dims, B=B, total=total, steps=steps, elapsed=elapsed, sco_iters=sco_iters, admm_ms=admm_ms,
@@ -332,7 +336,11 @@ def main():
                   "ratio_to_8TBps": alg_bytes / secs / HBM_PEAK if secs > 0 else 0.0,
                   "algorithmic_bytes_per_launch": alg_bytes / launches}
         if big:
-            tj, src = measured_traffic("r02_traffic_12x50.json")
+            tj, src = measured_traffic("r03_traffic_12x50.json")
+            # a PMC record is quoted for the batch it was taken at only (the working set, and with it the share of the
+            # Infinity Cache, follows the batch)
+            if tj and tj.get("batch") != r["B"]:
+                tj, src = None, "PMC record taken at batch %s, this run has %d" % (tj.get("batch"), r["B"])
             traffic = tj["hbm_bytes_per_problem_iteration"] * (r["it_proj"] + r["it_pen"]) / launches if tj else None
             return {"bound": "hbm", "kernel": "qp_admm_bt_kernel", "achieved": hbm_eq["achieved_GBps"], "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": hbm_eq["ratio_to_8TBps"], "traffic": traffic, "traffic_source": src,
@@ -344,19 +352,19 @@ def main():
         f_pro, l_pro = onchip_model(d["d"], d["T"], d["K"], d["O"], projection=True)
         flops = r["it_pen"] * f_pen + r["it_proj"] * f_pro
         lds = r["it_pen"] * l_pen + r["it_proj"] * l_pro
-        tj, src = measured_traffic("r02_traffic.json")
+        tj, src = measured_traffic("r03_traffic.json")
         traffic = tj["hbm_bytes_per_step"] * r["steps"] / launches if tj and r["B"] == tj.get("batch") else None
-        return {"bound": "mfma", "kernel": "qp_admm_rl_kernel", "achieved": flops / secs / 1e12 if secs > 0 else 0.0,
+        return {"bound": "valu_f64", "kernel": "qp_admm_rl_kernel", "achieved": flops / secs / 1e12 if secs > 0 else 0.0,
                 "peak": F64_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / secs / F64_PEAK if secs > 0 else 0.0,
                 "traffic": traffic, "traffic_source": src,
                 "onchip": {"valu_frac": flops / secs / F64_PEAK if secs > 0 else 0.0,
                            "lds_frac": lds / secs / LDS_PEAK if secs > 0 else 0.0,
                            "flops_per_problem_iteration": f_pen, "lds_bytes_per_problem_iteration": l_pen,
-                           "clock_ghz_assumed": CLOCK_HZ / 1e9, "cus": N_CU},
+                           "clock_ghz_assumed": CLOCK_HZ / 1e9, "clock_ghz_measured": (tj or {}).get("clock_ghz_measured"), "cus": N_CU},
                 "hbm_measured": {"bytes_per_launch": traffic,
                                  "frac_of_8TBps": traffic * launches / secs / HBM_PEAK if traffic and secs > 0 else None},
                 "hbm_equivalent": hbm_eq,
-                "note": "f64 peak of MI355X: 64 FMA/clk/CU on the vector ALU = its dense f64 MFMA rate (78.6 TFLOP/s at 2.4 GHz); "
+                "note": "bound = the f64 VECTOR ALU (the kernel holds no MFMA instruction).  f64 peak of MI355X: 64 FMA/clk/CU on the vector ALU = its dense f64 MFMA rate (78.6 TFLOP/s at 2.4 GHz); "
                         "the kernel has no GEMM-shaped work (one dense 140 x 140 mat-vec per problem-iteration with a different "
                         "matrix per problem), so its flops issue on the vector ALU and are priced against that peak.  Iterates live "
                         "in LDS / registers for a whole solve: HBM sees the problem once per launch (hbm_measured, PMC)"}
@@ -419,6 +427,8 @@ def main():
                     "stage_ms_per_step": dict(zip(["convexify", "qp_setup", "admm", "decide", "total"],
                                                   r["stage_ms"].round(3).tolist())),
                     "success_fraction": r["success"],
+                    "sco_iters_per_step": r["sco_iters"] / args.steps,          # over ALL ranks (from the gathered records)
+                    "backend": (dist.get_backend() if world > 1 else None),
                     "admm_launches_per_step": r["qp_launches"] / args.steps,
                     "stream_groups": r["groups"],
                     "kernel_src_sha": kernel_src_sha()},

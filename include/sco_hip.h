@@ -320,9 +320,10 @@ int sco_sqp_fetch(sco_sqp *h, double *x, int *success, int *sqp_iters, int *qp_s
 #define SCO_SQP_FLAG_TRACE_FULL 4  /* more decisions than sco_sqp_trace keeps (64)                              */
 int sco_sqp_fetch_flags(sco_sqp *h, int *flags);
 /* Number of device rounds (pre -> QP setup -> ADMM launch -> post) of the last solve, the projection round
- * included; with time slicing one QP spans several rounds.  A large batch is cut into stream groups whose rounds
- * run side by side (scheduling only, results unchanged; SCO_SQP_GROUPS=1 in the environment keeps one group):
- * `rounds` counts the group that needed most. */
+ * included; with time slicing one QP spans several rounds.  Default schedule: ONE group with round selection (a
+ * batch larger than the CU count runs whole passes of the problems with most work in front of them); SCO_SQP_GROUPS=2..4
+ * in the environment cuts the batch into stream groups whose rounds run side by side instead (no selection then).
+ * Scheduling only, results unchanged.  `rounds` counts the group that needed most. */
 int sco_sqp_last_rounds(const sco_sqp *h, int *rounds);
 /* Round launches of the last solve summed over its stream groups (projection round excluded), and the number of
  * groups it used (either pointer may be null). */

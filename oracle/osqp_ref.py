@@ -38,7 +38,15 @@ class Info(C.Structure):
 
 
 def build(force=False):
-    """Compile the C restatement (gcc, host only)."""
+    """Compile the C restatement (gcc, host only).  SCO_ORACLE_SANITIZE=1 (scripts/cpu_sanitize.sh, CPU only) builds
+    and loads an AddressSanitizer + UndefinedBehaviorSanitizer variant next to it instead."""
+    global _SO
+    if os.environ.get("SCO_ORACLE_SANITIZE", "0") == "1":
+        _SO = os.path.join(_HERE, "_osqp_ref_asan.so")
+        if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+            subprocess.check_call(["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                                   "-fno-sanitize-recover=undefined", "-shared", "-fPIC", "-o", _SO, _SRC, "-lm"])
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
         subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", _SO, _SRC, "-lm"])
     return _SO

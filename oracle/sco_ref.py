@@ -101,7 +101,8 @@ def min_eig_jacobi(H, sweeps=12):
                 if abs(A[p, q]) < 1e-300:
                     continue
                 theta = (A[q, q] - A[p, p]) / (2.0 * A[p, q])
-                t = (1.0 if theta >= 0 else -1.0) / (abs(theta) + np.sqrt(theta * theta + 1.0))
+                # |theta| beyond 1e150 would overflow theta^2: there sqrt(theta^2 + 1) = |theta| to the last bit
+                t = (1.0 if theta >= 0 else -1.0) / (abs(theta) + (abs(theta) if abs(theta) > 1e150 else np.sqrt(theta * theta + 1.0)))
                 c = 1.0 / np.sqrt(t * t + 1.0); s_ = t * c
                 Rp, Rq = A[:, p].copy(), A[:, q].copy()
                 A[:, p] = c * Rp - s_ * Rq; A[:, q] = s_ * Rp + c * Rq

@@ -46,7 +46,10 @@ def build(force=False, verbose=False, defines=(), lib=None, obj_dir=None):
 
     `defines` / `lib` / `obj_dir` build a diagnostic variant (e.g. -DSCO_STAMP) next to the product."""
     lib = lib or LIB
-    obj_dir = obj_dir or OBJ
+    if obj_dir is None:
+        # a variant with its own defines gets its own objects: it must neither reuse the product's (compiled without
+        # the defines) nor overwrite them
+        obj_dir = OBJ if not defines else os.path.join(CSRC, "build_" + "_".join(sorted(d.replace("=", "-") for d in defines)))
     if not force and lib == LIB and not needs_build():
         return LIB
     os.makedirs(obj_dir, exist_ok=True)

@@ -1348,7 +1348,7 @@ static hipEvent_t next_event(sco_sqp *h, size_t &cursor) {
 // Which problems take part in the next round.  A workgroup of the ADMM kernels fills a CU and the hardware deals the
 // workgroups of a launch to XCDs and shader engines in a fixed rotation, waiting for the engine whose turn it is: a
 // workgroup that finds its problem inactive and exits at once still takes its turn, so a launch of 1024 workgroups of
-// which 768 have work costs four passes of the chip, not three (measured, scripts/experiments/trace_rounds.py), and
+// which 768 have work costs four passes of the chip, not three (measured, profiles/r02_rounds.txt), and
 // once problems start to finish the last pass of every lock-step round is partly empty.  With more active problems
 // than CUs a round therefore runs P = floor(active / CUs) whole passes as a COMPACT launch: this kernel lists the
 // P x CUs problems with most in front of them as far as the device can tell -- the slices their current QP has left if
@@ -1357,7 +1357,7 @@ static hipEvent_t next_event(sco_sqp *h, size_t &cursor) {
 // launch from the active count it read back SQP_DEPTH rounds earlier (`cap`, never too small: the count only falls);
 // surplus workgroups find -1 and exit.  The others are not visited: per problem the sequence of kernels and every
 // result is unchanged, only the round it happens in moves (model on the measured chains, 1024 problems at 7x20:
-// 667 -> 636 ms per step; choosing by the true remaining work would give 629, scripts/experiments/select_sim.py).
+// 667 -> 636 ms per step; choosing by the true remaining work would give 629, profiles/r02_slice_model.txt).
 // n_active starts the round at the number of live problems left out (sqp_post_kernel adds those that ran and go on).
 #define SEL_T 1024
 #define SEL_BUCKETS 1024
@@ -1601,8 +1601,17 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     r.issued++;
     return SCO_OK;
   };
-  const int depth = SQP_DEPTH;
+  // Rounds kept enqueued ahead of the host: SQP_DEPTH where a round's read-back would otherwise leave the device idle
+  // (selection, stream groups, time slices); ONE for the plain unsliced loop over a batch that fits the CUs (the B = 1
+  // latency case): there a second round in flight would only be a trailing all-inactive launch sequence per solve.
+  const int depth = (!select && G == 1 && slice_req == 0) ? 1 : SQP_DEPTH;
   bool capped = false;
+  if (G > 1) {
+    // the other groups' streams start behind the memsets queued on the main stream above (prog reset, warm-start zeroing)
+    hipEvent_t ready = next_event(h, ec); stage.push_back(-2);
+    SCO_HIP(hipEventRecord(ready, h->stream));
+    for (int g = 1; g < G; g++) SCO_HIP(hipStreamWaitEvent(grp[g].st, ready, 0));
+  }
   if (n_active > 0) {
     for (int k = 0; k < depth; k++)
       for (int g = 0; g < G; g++)

@@ -7,8 +7,9 @@ installed here; its exact step sequence is *parity unpinned*.  What the
 reference's tests pin is the derivative itself (rtol 1e-5 / atol 1e-8 against the
 analytic value, tests/sco_osqp/test_expr.py:71-78, 151-211).
 
-The scheme below is the one the device kernel ``fd_jacobian_kernel`` in
-csrc/sco_hip.hip implements, so host and device agree to rounding:
+The scheme below is the one ``sqp_pre_kernel`` in csrc/sco_sqp.hip implements
+(its FD_BASE / FD_LEVELS ladder and ``richardson``), and ``oracle/sco_ref.py``'s
+``fd_jacobian`` / ``fd_hessian``, so host, oracle and device agree to rounding:
 
   central differences  D(h) = (f(x + h e_j) - f(x - h e_j)) / (2h)
   on the step ladder   h_k = h0 / 2^k,  k = 0..LEVELS-1,  h0 = BASE * max(1, |x_j|)

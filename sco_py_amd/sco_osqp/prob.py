@@ -318,8 +318,6 @@ class Prob(object):
             self._osqp_vars.add(t)
             arr[pos] = t
         return arr
-
-    # @profile
     def _update_nonlin_cnt_and_add_to_qp(self, bexpr, ind):
         """Write the new affine model (A, b) of penalty block ``ind`` into its
         existing rows, then append those rows to the QP once more
@@ -348,8 +346,6 @@ class Prob(object):
     def add_trust_region(self, trust_region_size):
         for var in self._vars:
             var.add_trust_region(trust_region_size)
-
-    # @profile
     def convexify(self):
         """Quadratic models of the non-quadratic objectives and l1-penalty models
         of the non-linear constraints at the current point, plus the per-group
@@ -363,7 +359,6 @@ class Prob(object):
             self._penalty_groups.append([be.convexify(degree=1) for be in self._cnt_groups[gid]])
 
     # ------------------------------------------------------------------ merit
-    # @profile
     def get_value(self, penalty_coeff, vectorize=False):
         """Exact penalty objective at the current point, or (vectorize) the
         per-group sums of constraint violation (prob.py:547-579)."""
@@ -380,8 +375,6 @@ class Prob(object):
         for be in self._nonlin_cnt_exprs:
             total += penalty_coeff * np.sum(self._compute_cnt_violation(be))
         return total
-
-    # @profile
     def _compute_cnt_violation(self, bexpr):
         comp = bexpr.expr
         at = bexpr.var.get_value()

@@ -35,7 +35,7 @@ Trial = namedtuple("Trial", "merit model_merit new_merit merit_vec model_vec")
 Verdict = namedtuple("Verdict", "code approx_improve exact_improve ratio stalled reported")
 
 
-def classify_trial(trial, thr, group_index, group_overlap, group_order):
+def classify_trial(trial, thr, group_index, group_overlap, group_order, predicates=None):
     """Decision for one trust-region trial; a pure function of the trial's numbers.
 
     ``group_index``: gid -> position in the merit vectors (``prob.gid2ind``); ``group_overlap``: gid -> gids
@@ -44,7 +44,10 @@ def classify_trial(trial, thr, group_index, group_overlap, group_order):
     none of whose overlapping groups progresses (they end the run); ``reported`` = what the reference leaves in
     ``prob.nonconverged_groups`` then (the stalled ones followed by every violated group under the y threshold,
     solver.py:232-234).  STEP_SHRINK here never means x-converged: that depends on the trust size and is the
-    caller's test.
+    caller's test.  ``predicates`` = (bad_model, y_converged, shrink_trust_region) callables: ``Solver`` hands in its
+    own ``_bad_model`` / ``_y_converged`` / ``_shrink_trust_region`` (the reference's overridable predicate methods,
+    solver.py:255-283), so a subclass that overrides them decides here exactly as it does in the reference; without
+    them the thresholds of ``thr`` are used (the same tests).
     """
     approx = trial.merit - trial.model_merit
     if not approx:
@@ -55,9 +58,12 @@ def classify_trial(trial, thr, group_index, group_overlap, group_order):
     def verdict(code, stalled=(), reported=()):
         return Verdict(code, approx, exact, ratio, list(stalled), list(reported))
 
-    if approx < BAD_MODEL_THRESHOLD:
+    bad_model, y_converged, shrink = predicates or (
+        lambda a: a < BAD_MODEL_THRESHOLD, lambda a: a < thr.min_approx_improve,
+        lambda e, r: e < 0 or r < thr.improve_ratio)
+    if bad_model(approx):
         return verdict(STEP_BAD)
-    if approx < thr.min_approx_improve:
+    if y_converged(approx):
         return verdict(STEP_YCONV)
 
     per_group = np.asarray(trial.merit_vec, dtype=np.float64) - np.asarray(trial.model_vec, dtype=np.float64)
@@ -77,7 +83,7 @@ def classify_trial(trial, thr, group_index, group_overlap, group_order):
         under = [g for k, g in enumerate(group_order) if violated[k] and per_group[k] < thr.min_approx_improve]
         return verdict(STEP_GROUP, stalled, stalled + under)
 
-    if exact < 0 or ratio < thr.improve_ratio:
+    if shrink(exact, ratio):
         return verdict(STEP_SHRINK)
     return verdict(STEP_ACCEPT)
 
@@ -168,7 +174,8 @@ class Solver(object):
             prob.optimize(verbose=verbose, **qp_kw)        # a failed QP leaves the point where it was (Q6)
             trial = Trial(base_merit, prob.get_approx_value(penalty_coeff), prob.get_value(penalty_coeff),
                           base_vec, prob.get_approx_value(penalty_coeff, True))
-            v = classify_trial(trial, thr, prob.gid2ind, prob._cnt_groups_overlap, sorted(prob._cnt_groups.keys()))
+            v = classify_trial(trial, thr, prob.gid2ind, prob._cnt_groups_overlap, sorted(prob._cnt_groups.keys()),
+                               predicates=(self._bad_model, self._y_converged, self._shrink_trust_region))
             row = (trial.merit, trial.model_merit, trial.new_merit, trust, penalty_coeff)
             say("  trust %g: model %r, new %r, improvement model %.3e / exact %.3e (ratio %.3g) -> %s"
                 % (trust, trial.model_merit, trial.new_merit, v.approx_improve, v.exact_improve, v.ratio,

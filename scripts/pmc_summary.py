@@ -46,6 +46,16 @@ for key, fname in (("qp_admm_rl_kernel", "traffic.json"), ("qp_admm_bt_kernel", 
                      ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU",
                       "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
                       "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE")}
+    try:        # shader clock held during the kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time of the same pass
+        dur = 0
+        for f in glob.glob(os.path.join(root, "pmc_sq2", "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if key in r["Kernel_Name"]:
+                    dur += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if dur > 0 and "sq" in rec and rec["sq"].get("GRBM_GUI_ACTIVE"):
+            rec["clock_ghz_measured"] = rec["sq"]["GRBM_GUI_ACTIVE"] / 8.0 / dur
+    except Exception as e:
+        print("no clock estimate:", e)
     try:        # the bench line of the FETCH_SIZE pass: ADMM problem-iterations of the profiled step
         line = [l for l in open(os.path.join(root, "pmc_FETCH_SIZE.json")) if l.startswith("{")][-1]
         bj = json.loads(line)

@@ -1,0 +1,75 @@
+"""The N > 1 path of bench.py on real hardware, in the driver-run record (r02 verdict item 2).
+
+A one-GPU box cannot give every rank its own device, so this is the REHEARSAL form: `bench.py --gpus 2` starts its own
+two rank processes (torch.distributed.run as a fresh CHILD process -- never an exec of this pytest process, which has
+touched the GPU), both on device 0: self_launch -> torchrun -> init_process_group -> shard -> solve_sharded (the real
+libsco_hip.so) -> all-gather of the 24-byte records -> max-over-ranks clock -> rank 0's JSON line.  Problems are
+independent (/root/reference/sco_py/sco_osqp/prob.py:48-86: all state hangs off one Prob), so what the gather returns
+must equal two single-rank solves of the two shards."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from sco_py_amd import _lib, batch as sb, dist as sd
+from sco_py_amd import workloads as af
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIMS = dict(d=7, T=20, K=5, O=2)
+
+
+def _single_rank_iters(total, world):
+    """sqp_iters of the shards [lo, hi) solved one after the other in this process."""
+    out = 0
+    for r in range(world):
+        lo, hi = sd.shard_range(total, r, world)
+        arrays, _ = af.make_batch(hi - lo, first=lo, **DIMS)
+        with sb.TrajOptBatch(hi - lo, DIMS["d"], DIMS["T"], DIMS["K"], DIMS["O"]) as tb:
+            tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                    arrays["point_frac"], arrays["obstacles"])
+            tb.solve()
+            out += int(tb.fetch().sqp_iters.sum())
+    return out
+
+
+def _bench_two_ranks(mode, batch):
+    env = dict(os.environ)
+    env["SCO_BENCH_REHEARSE"] = mode
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", str(batch),
+           "--cpu-problems", "0", "--aux-12x50", "0", "--aux-b4096", "0"]
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_with_two_ranks_on_one_device_gloo(gpu):
+    p = _bench_two_ranks("1", 1024)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    out = _json_line(p.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2048 and out["scaling"] == "weak"
+    assert out["aux"]["backend"] == "gloo" and out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert out["aux"]["sco_iters_per_step"] == _single_rank_iters(2048, 2)
+
+
+def test_bench_with_two_ranks_on_one_device_rccl_branch(gpu):
+    """The nccl (= RCCL) branch of bench.py / dist.py with both ranks on device 0: init with device_id, all-gather and
+    max-reduce on device tensors.  RCCL may refuse two ranks on one device ("duplicate GPU"); the branch has then at least
+    been imported, argument-checked and run up to the communicator, and the test says which."""
+    p = _bench_two_ranks("nccl", 64)
+    if p.returncode != 0:
+        err = (p.stderr or "")[-6000:]
+        low = err.lower()
+        assert "init_process_group" in err or "nccl" in low or "rccl" in low, err      # it failed in the communicator, nowhere else
+        pytest.skip("RCCL refuses two ranks on one device here: " + " | ".join(l for l in err.splitlines() if "rror" in l)[-400:])
+    out = _json_line(p.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["aux"]["backend"] == "nccl"
+    assert out["aux"]["sco_iters_per_step"] == _single_rank_iters(128, 2)

@@ -471,3 +471,28 @@ def test_classify_trial_takes_the_exits_in_the_reference_order():
     # a satisfied group (merit below cnt_tolerance) cannot stall
     v = code(3.0, 2.0, 2.1, np.array([1.0, 1.0, 1e-5]), np.array([0.5, 0.5, 1e-5]), groups)
     assert v.code == sv.STEP_ACCEPT
+
+
+def test_overridden_predicates_of_a_solver_subclass_decide_as_in_the_reference():
+    """The reference's Solver decides through its overridable predicate methods (_bad_model, _y_converged,
+    _shrink_trust_region: /root/reference/sco_py/sco_osqp/solver.py:255-283); the mirror routes classify_trial through the
+    same methods, so a subclass that overrides one changes the decisions here as it would there."""
+    from sco_py_amd.sco_osqp import solver as sv
+    thr = sv.Thresholds(0.25, 1e-8, 1e-4)
+    trial = sv.Trial(10.0, 9.0, 9.9, [], [])          # model improvement 1.0, exact 0.1: ratio 0.1 -> shrink
+    assert sv.classify_trial(trial, thr, {}, {}, []).code == sv.STEP_SHRINK
+    s = sv.Solver()
+    preds = (s._bad_model, s._y_converged, s._shrink_trust_region)
+    assert sv.classify_trial(trial, thr, {}, {}, [], predicates=preds).code == sv.STEP_SHRINK
+
+    class Lenient(sv.Solver):
+        def _shrink_trust_region(self, exact_merit_improve, merit_improve_ratio):
+            return exact_merit_improve < 0            # any improvement is accepted
+
+    class Jumpy(sv.Solver):
+        def _y_converged(self, approx_merit_improve):
+            return approx_merit_improve < 5.0
+
+    l = Lenient(); j = Jumpy()
+    assert sv.classify_trial(trial, thr, {}, {}, [], predicates=(l._bad_model, l._y_converged, l._shrink_trust_region)).code == sv.STEP_ACCEPT
+    assert sv.classify_trial(trial, thr, {}, {}, [], predicates=(j._bad_model, j._y_converged, j._shrink_trust_region)).code == sv.STEP_YCONV
