@@ -200,11 +200,19 @@ void sco_sqp_default_params(sco_sqp_params *p);
                                   (sco_sqp_load_quadratic), Q_r symmetric and of either sign -- keep-out ellipses, keep-in
                                   discs, half-planes, products of coordinates ...; dof <= 16, n_points must be 1; link_len /
                                   point_* / obstacles of sco_sqp_load are not read.  Flags as for SCO_FAM_POINT_CIRCLES */
-#define SCO_FAM_STATE_PROGRAM 5 /* closed-form rows given as small postfix programs over the state of a timestep and a
+#define SCO_FAM_STATE_PROGRAM 5 /* closed-form rows given as small postfix programs over the state of a constraint block and a
                                   per-problem parameter vector (sco_sqp_load_program) -- what the reference's Expr(f) is for
-                                  any f one can write down with + - * / sin cos sqrt exp: n_obstacles rows g[r](x, p) <= 0 per
-                                  timestep, Jacobians by the device's central differences (analytic_jac must be 0); dof <= 16,
-                                  n_points must be 1.  Flags as for SCO_FAM_POINT_CIRCLES.
+                                  any f one can write down with + - * / sin cos sqrt exp.  A block is `span` (1 or 2)
+                                  consecutive timesteps: block t binds the rows to the Variable (theta[t], .., theta[t+span-1])
+                                  (the reference binds any Expr to any Variable, expr.py:413-437, prob.py:112-144; swept-volume
+                                  and dynamics constraints live on two timesteps), state = their concatenation, span * dof <= 32,
+                                  horizon - span + 1 blocks.  n_obstacles rows per block: the first n_obstacles - n_eq_rows are
+                                  inequalities g[r](x, p) <= 0 (LEqExpr -> hinge penalty, prob.py:251-278), the last n_eq_rows
+                                  equalities g[r](x, p) = 0 (EqExpr -> abs penalty with two slacks per row, prob.py:280-315).
+                                  Jacobians by the device's central differences (analytic_jac = 0: the reference's default
+                                  for an Expr without grad) or by forward-mode differentiation of the program itself
+                                  (analytic_jac = 1: what a caller who supplies grad gets, expr.py:86-100).  n_points must be 1.
+                                  Linear-row flags as for SCO_FAM_POINT_CIRCLES; SCO_FAM_FLAG_OBJ_PROGRAM below.
                                   Program words are pairs (op, arg): */
 #define SCO_OP_END 0      /* end of a row's program: its value is the one number left on the stack */
 #define SCO_OP_X 1        /* push x[arg] (state coordinate)        */
@@ -243,17 +251,26 @@ void sco_sqp_default_params(sco_sqp_params *p);
                                   prob.py:532-534); the model goes into P and q (prob.py:348-367).  dof <= 16;
                                   weight, target via sco_sqp_load_ee_cost */
 
+#define SCO_FAM_FLAG_OBJ_PROGRAM 128  /* OR-ed into SCO_FAM_STATE_PROGRAM (span 1, dof <= 16): one more program -- row index
+                                  n_obstacles of sco_sqp_load_program -- is a NON-QUADRATIC OBJECTIVE TERM f(theta[t], p) per
+                                  timestep (Prob.add_obj_expr on a plain Expr, prob.py:88-104): convexified to degree 2 on
+                                  every SQP iteration exactly like SCO_FAM_FLAG_EE_COST (numeric Hessian, eigenvalue shift,
+                                  numeric gradient, expr.py:102-156; model into P and q, prob.py:348-367) */
+
 typedef struct sco_trajopt_desc {
   int batch;
   int dof;
   int horizon;
   int n_points;      /* link points per arm configuration   */
-  int n_obstacles;   /* circular obstacles per problem      */
+  int n_obstacles;   /* circular obstacles per problem (rows per block for the state families) */
   int family;        /* SCO_FAM_*                           */
   int analytic_jac;  /* 0: finite differences (reference default, expr.py:86-87), 1: analytic */
   int prox_count;    /* how many Variables with a value hold each atom: the projection QP of
                         find_closest_feasible_point adds one (x_i - x0_i)^2 per Variable
-                        (prob.py:381-404); 0 is read as 1 */
+                        (prob.py:381-404); 0 is read as 1.  With span > 1 this is the count of an atom that ONE
+                        block Variable covers; an atom covered by k blocks counts prox_count - 1 + k */
+  int span;          /* SCO_FAM_STATE_PROGRAM: timesteps per constraint block, 1 or 2 (0 is read as 1) */
+  int n_eq_rows;     /* SCO_FAM_STATE_PROGRAM: how many of the n_obstacles rows of a block (the last ones) are equalities */
 } sco_trajopt_desc;
 
 typedef struct sco_sqp sco_sqp;

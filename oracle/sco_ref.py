@@ -503,10 +503,24 @@ def trajopt_flat(prob, analytic_jac=False):
         lin_hi = np.concatenate([lin_hi, np.tile(prob["jhi"], T), -np.tile(prob["jlo"], T)])
     blocks = []
     R = prob["K"] * prob["O"]
-    for t in range(T):
-        if prob.get("row_program") is not None:  # SCO_FAM_STATE_PROGRAM: closed-form rows (numeric Jacobian only)
+    prog = prob.get("row_program")
+    span = prog.span if prog is not None else 1
+    if prog is not None and (span > 1 or prog.n_eq > 0):
+        # r03 program blocks: block t binds its rows to (theta[t], .., theta[t+span-1]); its inequality rows are one
+        # LEqExpr, its equality rows one EqExpr (val 0) on the same Variable (tests/trajopt_build.py)
+        for t in range(T - span + 1):
+            idx = np.arange(t * d, (t + span) * d)
+            gids = prob["groups"][t] if prob.get("groups") is not None else None
+            for kind, rows in (("leq", prog.ineq_rows), ("eq", prog.eq_rows)):
+                if not rows:
+                    continue
+                f = prog.numpy_fn(prob["row_params"], rows)
+                jac = prog.numpy_jac(prob["row_params"], rows) if analytic_jac else None
+                blocks.append(Block(kind, f, idx, np.zeros(len(rows)), jac=jac, groups=gids))
+    for t in range(T if not (prog is not None and (span > 1 or prog.n_eq > 0)) else 0):
+        if prob.get("row_program") is not None:  # SCO_FAM_STATE_PROGRAM: closed-form rows
             f = prob["row_program"].numpy_fn(prob["row_params"])
-            jac = None
+            jac = prob["row_program"].numpy_jac(prob["row_params"]) if analytic_jac else None
         elif prob.get("quad_Q") is not None:    # SCO_FAM_STATE_QUADRATIC: general quadratic rows on the state
             f = (lambda th, pr=prob: af.quad_rows(th, pr["quad_Q"], pr["quad_a"], pr["quad_c"]))
             jac = (lambda th, pr=prob: af.quad_rows_jac(th, pr["quad_Q"], pr["quad_a"], pr["quad_c"])) if analytic_jac else None
@@ -526,11 +540,16 @@ def trajopt_flat(prob, analytic_jac=False):
         blocks.append(Block("eq", f, np.arange((T - 1) * d, T * d), prob["target"], jac=jac,
                             groups=prob["groups"][T] if prob.get("groups") is not None else None))
     obj_blocks = []
+    if prog is not None and prog.objective:      # SCO_FAM_FLAG_OBJ_PROGRAM: a non-quadratic objective term per timestep
+        for t in range(T):
+            obj_blocks.append(ObjBlock(prog.objective_fn(prob["row_params"]), np.arange(t * d, (t + 1) * d)))
     if prob.get("cost_weight") is not None:
         for t in range(T):
             fc = (lambda th, pr=prob: af.ee_cost(th, pr["link_len"], pr["cost_target"], pr["cost_weight"]))
             obj_blocks.append(ObjBlock(fc, np.arange(t * d, (t + 1) * d)))
     # the object-API construction (tests/trajopt_build.py) binds every atom to two
-    # Variables: the whole trajectory and its timestep block
+    # Variables: the whole trajectory and its timestep block; with blocks of `span` timesteps an atom of timestep t sits
+    # in the trajectory and in every block Variable that covers t
+    nblk = np.array([min(t, T - span) - max(0, t - span + 1) + 1 for t in range(T)], dtype=np.float64)
     return FlatProblem(prob["x0"], Q.tocsc(), np.zeros(n_x), 0.0, lin.tocsr(), lin_lo, lin_hi, blocks,
-                       prox_count=np.full(n_x, 2.0), obj_blocks=obj_blocks)
+                       prox_count=np.repeat(1.0 + nblk, d), obj_blocks=obj_blocks)

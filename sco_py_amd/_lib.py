@@ -52,7 +52,7 @@ class TrajoptDesc(C.Structure):
     _fields_ = [
         ("batch", C.c_int), ("dof", C.c_int), ("horizon", C.c_int), ("n_points", C.c_int),
         ("n_obstacles", C.c_int), ("family", C.c_int), ("analytic_jac", C.c_int),
-        ("prox_count", C.c_int),
+        ("prox_count", C.c_int), ("span", C.c_int), ("n_eq_rows", C.c_int),
     ]
 
 

@@ -23,6 +23,7 @@ SCO_FAM_STATE_PROGRAM = 5
 SCO_FAM_FLAG_VEL_LIMITS = 16
 SCO_FAM_FLAG_JOINT_LIMITS = 32
 SCO_FAM_FLAG_EE_COST = 64
+SCO_FAM_FLAG_OBJ_PROGRAM = 128
 TRACE_W = 8
 
 
@@ -44,7 +45,10 @@ class TrajOptBatch(object):
     SCO_FAM_STATE_QUADRATIC, n_obstacles rows 1/2 x' Q_r x + a_r' x + c_r <= 0 on the state of every timestep with
     per-problem coefficients (``load(..., quad_Q=, quad_a=, quad_c=)``); ``program=True``: SCO_FAM_STATE_PROGRAM, rows
     given as closed-form expressions over the state and a per-problem parameter vector, compiled by
-    ``sco_py_amd.rowexpr.compile_rows`` (``load(..., row_program=, row_params=)``))
+    ``sco_py_amd.rowexpr.compile_rows`` (``load(..., row_program=, row_params=)``); the program says how many timesteps
+    a constraint block spans (``span`` 1 or 2: block t binds its rows to (theta[t], .., theta[t+span-1])), how many of a
+    block's rows are equalities (``n_eq``) and whether it carries a non-quadratic objective term per timestep -- pass it
+    to the constructor as ``program=prog``; ``analytic_jac=True`` differentiates program rows in forward mode)
     solved per problem exactly like ``Solver().solve(prob, method="penalty_sqp")``.
     ``prox_count`` says how many Variables hold each atom in the equivalent object-API
     construction (it scales the projection QP of find_closest_feasible_point,
@@ -69,17 +73,23 @@ class TrajOptBatch(object):
             raise ValueError("the point-robot and quadratic-row families have neither the reach equality nor the objective term")
         self.program = bool(program)       # SCO_FAM_STATE_PROGRAM: rows as closed-form programs (sco_py_amd.rowexpr)
         if sum((self.point, self.quadratic, self.program)) > 1 or (self.program and (self.reach or self.ee_cost)):
-            raise ValueError("one family per batch; the program family has neither the reach equality nor the objective term")
-        if self.program and analytic_jac:
-            raise ValueError("program rows are differentiated numerically")
+            raise ValueError("one family per batch; the program family has neither the reach equality nor the arm's objective term")
+        # the structure of the program family's blocks comes with the compiled program (program=prog); program=True keeps
+        # the r02 form: one timestep per block, inequality rows only, no objective term
+        prog = program if hasattr(program, "row_ptr") else None
+        self.span = prog.span if prog is not None else 1
+        self.n_eq = prog.n_eq if prog is not None else 0
+        self.obj_program = bool(prog is not None and prog.objective)
+        self.n_blocks = self.T - self.span + 1
         desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O,
                                 (SCO_FAM_STATE_PROGRAM if self.program else SCO_FAM_STATE_QUADRATIC if self.quadratic else
                                  SCO_FAM_POINT_CIRCLES if self.point else
                                  SCO_FAM_ARM_REACH if self.reach else SCO_FAM_ARM_CIRCLES) |
                                 (SCO_FAM_FLAG_VEL_LIMITS if self.vel_limits else 0) |
                                 (SCO_FAM_FLAG_JOINT_LIMITS if self.joint_limits else 0) |
-                                (SCO_FAM_FLAG_EE_COST if self.ee_cost else 0),
-                                1 if analytic_jac else 0, int(prox_count))
+                                (SCO_FAM_FLAG_EE_COST if self.ee_cost else 0) |
+                                (SCO_FAM_FLAG_OBJ_PROGRAM if self.obj_program else 0),
+                                1 if analytic_jac else 0, int(prox_count), self.span, self.n_eq)
         _lib.check(_lib.load().sco_sqp_create(self.device, C.byref(desc), C.byref(self._h)))
 
     def close(self):
@@ -126,9 +136,12 @@ class TrajOptBatch(object):
         if self.program:
             if row_program is None:
                 raise ValueError("the program family needs row_program (sco_py_amd.rowexpr.compile_rows) and row_params (B, n_params)")
-            if row_program.n_rows != O or row_program.n_state > d:
-                raise ValueError("the program has %d rows over %d state coordinates; the batch has %d rows per timestep and dof %d"
-                                 % (row_program.n_rows, row_program.n_state, O, d))
+            if row_program.n_rows != O or row_program.n_state > d * self.span or row_program.span != self.span or \
+                    row_program.n_eq != self.n_eq or row_program.objective != self.obj_program:
+                raise ValueError("the program has %d rows (%d equalities) over %d state coordinates, span %d, objective term %s; the "
+                                 "batch was created for %d rows per block (%d equalities), dof %d, span %d, objective term %s"
+                                 % (row_program.n_rows, row_program.n_eq, row_program.n_state, row_program.span, row_program.objective,
+                                    O, self.n_eq, d, self.span, self.obj_program))
             npar = row_program.n_params
             par = arr(row_params if row_params is not None else np.zeros((B, 0)), (B, npar)) if npar else np.zeros((B, 0))
             _lib.check(_lib.load().sco_sqp_load_program(
@@ -162,7 +175,7 @@ class TrajOptBatch(object):
         """Constraint groups (``prob.add_cnt_expr(bound_expr, group_ids)``): one list of group ids
         per constraint block (T timestep blocks, then the reach block).  Ids are sorted like the
         reference sorts them; ``fetch().nonconverged_groups`` reports them by name."""
-        nb = self.T + (1 if self.reach else 0)
+        nb = self.n_blocks + (1 if self.reach else 0)
         if len(block_groups) != nb:
             raise ValueError("expected %d blocks, got %d" % (nb, len(block_groups)))
         gids = sorted(set(g for blk in block_groups for g in blk))
@@ -227,7 +240,7 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
                       prox_count=prox_count, reach=bool(a.get("reach")), vel_limits=a.get("vmax") is not None,
                       joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
                       point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None,
-                      program=a.get("row_program") is not None) as tb:
+                      program=a.get("row_program") if a.get("row_program") is not None else False) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                 target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
                 cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),

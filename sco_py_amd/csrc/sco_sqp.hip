@@ -59,6 +59,10 @@ struct SqpDev {
   // SCO_FAM_ARM_REACH: NE = 2 equality rows (end-effector x, y) on the last timestep, block index T;
   // NB = number of constraint blocks (T or T + 1), RM = widest block (history strides)
   int NE, NB, RM;
+  // constraint blocks of the state families: block t covers the S (span) timesteps t .. t + S - 1, its state is the
+  // ds = S d numbers x[t d .. t d + ds) (consecutive timesteps are contiguous), there are NBt = T - S + 1 of them, and the
+  // last Req of a block's R rows are equalities (r03).  Arm / point families: S = 1, ds = d, NBt = T, Req = 0.
+  int S, ds, NBt, Req;
   int point;         // 1 SCO_FAM_POINT_CIRCLES: the rows are distances of the point x[0:2] itself (no arm kinematics);
                      // 2 SCO_FAM_STATE_QUADRATIC: general quadratic rows with the coefficients below
   double *qQ, *qa, *qc;   // [B][O][d*d], [B][O][d], [B][O]
@@ -70,7 +74,7 @@ struct SqpDev {
   // SCO_FAM_FLAG_EE_COST: non-quadratic objective term weight * ||ee(theta_t) - target||^2 per timestep, convexified to
   // degree 2 every SQP iteration (expr.py:143-153): oH = Hessian after the eigenvalue shift, oA, ob = the model's
   // linear and constant part; ppos = position in qp1's P values of entry (row (t, 0), column (t, j))
-  int cost;
+  int cost;          // 1 = the arm's end-effector term, 2 = an objective PROGRAM (SCO_FAM_FLAG_OBJ_PROGRAM: program index R)
   double *cw, *ctgt, *oH, *oA, *ob;   // [B], [B][2], [B][T][d*d], [B][T][d], [B][T]
   const int *ppos;                    // [n_x]
   const double *a0c, *a1c;      // constant parts of the A values of the projection / penalty QP (shared)
@@ -119,6 +123,8 @@ struct sco_sqp {
   int groups_used = 1;
   std::vector<void *> allocs;
   std::vector<hipEvent_t> events;
+  void *prog_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // sco_sqp_load_program: words, row starts, constants, parameters
+  size_t prog_bytes[4] = {0, 0, 0, 0};
   bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false, cost_loaded = false, quad_loaded = false, prog_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   int rounds = 0;          // 1 (projection) + the rounds of the group that needed most
@@ -257,6 +263,7 @@ __device__ __forceinline__ double richardson(double (&tab)[FD_LEVELS]) {
 // smallest eigenvalue of the symmetric d x d matrix H (d <= 16) by cyclic Jacobi rotations on a private copy
 // (the reference calls scipy.linalg.eigvalsh, expr.py:145; oracle/sco_ref.py:min_eig_jacobi is this sweep)
 #define OBJ_DMAX 16
+#define SCO_STATE_MAX 32      // widest state of a constraint block of the program family (span x dof)
 __device__ double min_eig_jacobi(const double *H, int d) {
   double A[OBJ_DMAX * OBJ_DMAX];
   for (int i = 0; i < d * d; i++) A[i] = H[i];
@@ -284,46 +291,80 @@ __device__ double min_eig_jacobi(const double *H, int d) {
 
 // Non-linear row e of a problem: hinge rows (timestep-major, R per timestep) first, then the NE
 // equality rows of the reach variant on the last timestep (constraint block index T).
+// `eq`: 0 hinge row, 1 equality row of the reach variant (block NBt = T on the last timestep, arm kinematics),
+// 2 equality row inside a block of the state families (the last Req rows of the block, r03)
 struct RowRef { int blk, t, r, eq; };
-__device__ __forceinline__ RowRef row_ref(int e, int T, int R) {
+struct RowLay { int T, NBt, R, Req; };
+__device__ __forceinline__ RowRef row_ref(int e, const RowLay &L) {
   RowRef q;
-  if (e < T * R) { q.blk = e / R; q.t = q.blk; q.r = e % R; q.eq = 0; }
-  else { q.blk = T; q.t = T - 1; q.r = e - T * R; q.eq = 1; }
+  if (e < L.NBt * L.R) { q.blk = e / L.R; q.t = q.blk; q.r = e % L.R; q.eq = (q.r >= L.R - L.Req) ? 2 : 0; }
+  else { q.blk = L.NBt; q.t = L.T - 1; q.r = e - L.NBt * L.R; q.eq = 1; }
   return q;
 }
 
 struct RowCtx { const double *len, *obs, *target; const int *point_link; const double *point_frac; int d, O, point;
                 const double *qQ, *qa, *qc;         // SCO_FAM_STATE_QUADRATIC: this problem's row coefficients (point == 2)
                 const int *pw, *pptr; const double *pconst, *ppar; };   // SCO_FAM_STATE_PROGRAM (point == 3): words, row starts, constants, this problem's parameters
-// f of row q at th (the raw function value: the right-hand side val is 0 for hinge rows and
-// target[r] for equality rows and is applied by the callers, in the reference's order)
-__device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, const double *th, int pert, double h) {
-  if (q.eq) return arm_ee(th, c.len, c.d, q.r, pert, h);
-  const int kp = q.r / c.O, o = q.r % c.O;
-  if (c.point == 3) {                          // SCO_FAM_STATE_PROGRAM: the row's postfix program
-    double st[SCO_PROGRAM_STACK];
-    int sp = 0;
-    for (int w = c.pptr[o];; w++) {
-      const int op = c.pw[2 * w], arg = c.pw[2 * w + 1];
-      if (op == SCO_OP_END) break;
-      switch (op) {
-        case SCO_OP_X: st[sp++] = th[arg] + (arg == pert ? h : 0.0); break;
-        case SCO_OP_P: st[sp++] = c.ppar[arg]; break;
-        case SCO_OP_C: st[sp++] = c.pconst[arg]; break;
-        case SCO_OP_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
-        case SCO_OP_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
-        case SCO_OP_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
-        case SCO_OP_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
-        case SCO_OP_NEG: st[sp - 1] = -st[sp - 1]; break;
-        case SCO_OP_SIN: st[sp - 1] = sin(st[sp - 1]); break;
-        case SCO_OP_COS: st[sp - 1] = cos(st[sp - 1]); break;
-        case SCO_OP_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
-        case SCO_OP_EXP: st[sp - 1] = exp(st[sp - 1]); break;
-        default: st[sp - 1] = st[sp - 1] * st[sp - 1]; break;       // SCO_OP_SQUARE
-      }
+// (for the state families `d` is the dimension of a BLOCK's state, span x dof)
+
+// SCO_FAM_STATE_PROGRAM: value of program `o` at th, up to two coordinates perturbed (finite differences)
+__device__ __forceinline__ double prog_eval(const RowCtx &c, int o, const double *th, int pi, double hi, int pj, double hj) {
+  double st[SCO_PROGRAM_STACK];
+  int sp = 0;
+  for (int w = c.pptr[o];; w++) {
+    const int op = c.pw[2 * w], arg = c.pw[2 * w + 1];
+    if (op == SCO_OP_END) break;
+    switch (op) {
+      case SCO_OP_X: st[sp++] = th[arg] + (arg == pi ? hi : 0.0) + (arg == pj ? hj : 0.0); break;
+      case SCO_OP_P: st[sp++] = c.ppar[arg]; break;
+      case SCO_OP_C: st[sp++] = c.pconst[arg]; break;
+      case SCO_OP_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+      case SCO_OP_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+      case SCO_OP_MUL: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+      case SCO_OP_DIV: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+      case SCO_OP_NEG: st[sp - 1] = -st[sp - 1]; break;
+      case SCO_OP_SIN: st[sp - 1] = sin(st[sp - 1]); break;
+      case SCO_OP_COS: st[sp - 1] = cos(st[sp - 1]); break;
+      case SCO_OP_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
+      case SCO_OP_EXP: st[sp - 1] = exp(st[sp - 1]); break;
+      default: st[sp - 1] = st[sp - 1] * st[sp - 1]; break;       // SCO_OP_SQUARE
     }
-    return st[0];
   }
+  return st[0];
+}
+// d(program o) / d x_j by forward-mode differentiation: every stack slot carries (value, derivative along e_j); the rules,
+// in this order of operations, are the ones sco_py_amd/rowexpr.py:Program.jacobian applies on the host (the `grad` a caller
+// hands to the reference's Expr, expr.py:86-100), so host and device agree to rounding
+__device__ __forceinline__ double prog_dual(const RowCtx &c, int o, const double *th, int j) {
+  double sv[SCO_PROGRAM_STACK], sd[SCO_PROGRAM_STACK];
+  int sp = 0;
+  for (int w = c.pptr[o];; w++) {
+    const int op = c.pw[2 * w], arg = c.pw[2 * w + 1];
+    if (op == SCO_OP_END) break;
+    switch (op) {
+      case SCO_OP_X: sv[sp] = th[arg]; sd[sp++] = (arg == j) ? 1.0 : 0.0; break;
+      case SCO_OP_P: sv[sp] = c.ppar[arg]; sd[sp++] = 0.0; break;
+      case SCO_OP_C: sv[sp] = c.pconst[arg]; sd[sp++] = 0.0; break;
+      case SCO_OP_ADD: sp--; sv[sp - 1] = sv[sp - 1] + sv[sp]; sd[sp - 1] = sd[sp - 1] + sd[sp]; break;
+      case SCO_OP_SUB: sp--; sv[sp - 1] = sv[sp - 1] - sv[sp]; sd[sp - 1] = sd[sp - 1] - sd[sp]; break;
+      case SCO_OP_MUL: sp--; sd[sp - 1] = sd[sp - 1] * sv[sp] + sv[sp - 1] * sd[sp]; sv[sp - 1] = sv[sp - 1] * sv[sp]; break;
+      case SCO_OP_DIV: { sp--; const double qv = sv[sp - 1] / sv[sp]; sd[sp - 1] = (sd[sp - 1] - qv * sd[sp]) / sv[sp]; sv[sp - 1] = qv; break; }
+      case SCO_OP_NEG: sv[sp - 1] = -sv[sp - 1]; sd[sp - 1] = -sd[sp - 1]; break;
+      case SCO_OP_SIN: sd[sp - 1] = cos(sv[sp - 1]) * sd[sp - 1]; sv[sp - 1] = sin(sv[sp - 1]); break;
+      case SCO_OP_COS: sd[sp - 1] = -(sin(sv[sp - 1]) * sd[sp - 1]); sv[sp - 1] = cos(sv[sp - 1]); break;
+      case SCO_OP_SQRT: { const double r = sqrt(sv[sp - 1]); sd[sp - 1] = sd[sp - 1] / (2.0 * r); sv[sp - 1] = r; break; }
+      case SCO_OP_EXP: { const double ev = exp(sv[sp - 1]); sd[sp - 1] = ev * sd[sp - 1]; sv[sp - 1] = ev; break; }
+      default: sd[sp - 1] = (2.0 * sv[sp - 1]) * sd[sp - 1]; sv[sp - 1] = sv[sp - 1] * sv[sp - 1]; break;       // SCO_OP_SQUARE
+    }
+  }
+  return sd[0];
+}
+// f of row q at th (the raw function value: the right-hand side val is 0 for hinge rows and the equality rows of the state
+// families and target[r] for the reach rows and is applied by the callers, in the reference's order)
+__device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, const double *th, int pert, double h) {
+  if (q.eq == 1) return arm_ee(th, c.len, c.d, q.r, pert, h);
+  const int kp = q.r / c.O, o = q.r % c.O;
+  if (c.point == 3) return prog_eval(c, o, th, pert, h, -1, 0.0);      // SCO_FAM_STATE_PROGRAM: the row's postfix program
   if (c.point == 2) {                          // SCO_FAM_STATE_QUADRATIC: 1/2 x' Q x + a' x + c of row o
     const double *Q = c.qQ + (size_t)o * c.d * c.d, *av = c.qa + (size_t)o * c.d;
     double val = c.qc[o];
@@ -342,9 +383,9 @@ __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, co
   return arm_row(th, c.len, c.point_link[kp], c.point_frac[kp], c.obs[3 * o], c.obs[3 * o + 1], c.obs[3 * o + 2], pert, h);
 }
 __device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, const double *th, int j) {
-  if (q.eq) return arm_ee_grad(th, c.len, c.d, q.r, j);
+  if (q.eq == 1) return arm_ee_grad(th, c.len, c.d, q.r, j);
   const int kp = q.r / c.O, o = q.r % c.O;
-  if (c.point == 3) return 0.0;                // programs are differentiated numerically (sco_sqp_create refuses analytic_jac)
+  if (c.point == 3) return prog_dual(c, o, th, j);      // forward-mode differentiation of the row's program (r03)
   if (c.point == 2) {                          // a_j + sum_i Q_ji x_i  (Q symmetric)
     const double *Q = c.qQ + (size_t)o * c.d * c.d;
     double g = c.qa[(size_t)o * c.d + j];
@@ -358,7 +399,14 @@ __device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, con
   }
   return arm_row_grad(th, c.len, c.point_link[kp], c.point_frac[kp], c.obs[3 * o], c.obs[3 * o + 1], j);
 }
-__device__ __forceinline__ double row_rhs(const RowCtx &c, const RowRef &q) { return q.eq ? c.target[q.r] : 0.0; }
+// non-quadratic objective term of a timestep with up to two perturbed coordinates: the arm's end-effector term
+// (SCO_FAM_FLAG_EE_COST) or the objective program (SCO_FAM_FLAG_OBJ_PROGRAM: program index O)
+struct ObjCtx { int kind; const double *len; int d; double tx, ty, w; };
+__device__ __forceinline__ double obj_value(const ObjCtx &oc, const RowCtx &c, const double *th, int pi, double hi, int pj, double hj) {
+  if (oc.kind == 2) return prog_eval(c, c.O, th, pi, hi, pj, hj);
+  return arm_ee_cost(th, oc.len, oc.d, oc.tx, oc.ty, oc.w, pi, hi, pj, hj);
+}
+__device__ __forceinline__ double row_rhs(const RowCtx &c, const RowRef &q) { return q.eq == 1 ? c.target[q.r] : 0.0; }
 // violation of a row with value g = f - val: |g| for equality rows, max(g, 0) for hinge rows (prob.py:582-590)
 __device__ __forceinline__ double row_viol(const RowRef &q, double g) { return q.eq ? fabs(g) : fmax(g, 0.0); }
 
@@ -399,9 +447,12 @@ __device__ __forceinline__ double lin_ineq_hi(const SqpDev &s, int b, int i) {
 __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, QpDev q0) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n_x = s.n_x, d = s.d, m0 = q0.m;
-  const double c = (double)s.prox_count;
   const double *x0 = s.x0 + (size_t)b * n_x;
   for (int i = tid; i < n_x; i += SCO_BLOCK) {
+    // one (x_i - x0_i)^2 per Variable that holds the atom (prob.py:381-404): the descriptor's count is that of an atom
+    // covered by one block Variable; with blocks of S > 1 timesteps timestep t sits in `nblk` of them
+    const int ts = i / d, nblk = (ts < s.NBt - 1 ? ts : s.NBt - 1) - (ts - s.S + 1 > 0 ? ts - s.S + 1 : 0) + 1;
+    const double c = (double)(s.prox_count - 1 + nblk);
     // entries whose initial value is unknown (NaN) take no part in the distance (prob.py:394-404)
     const bool known = !isnan(x0[i]);
     q0.Pval[(size_t)b * q0.nnzP + i] = known ? 2.0 * c : 0.0;
@@ -479,8 +530,10 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
       if (i < d) lo = hi = s.start[(size_t)b * d + i];
       else if (i < s.m_pin) lo = hi = s.goal[(size_t)b * d + (i - d)];
       else if (i < s.m_lin) { lo = -INFINITY; hi = lin_ineq_hi(s, b, i); }
-      else if (i < s.m_lin + s.T * s.R) { lo = -INFINITY; hi = 0.0; }
-      else if (i < s.m_lin + s.m_nl) { lo = 0.0; hi = 0.0; }              // equality rows: set by convexify
+      else if (i < s.m_lin + s.m_nl) {                                  // hinge rows; equality rows are set by convexify
+        const RowRef qr = row_ref(i - s.m_lin, RowLay{s.T, s.NBt, s.R, s.Req});
+        lo = qr.eq ? 0.0 : -INFINITY; hi = 0.0;
+      }
       else if (i < s.m_lin + s.m_nl + n_x) { lo = -INFINITY; hi = INFINITY; }
       else { lo = 0.0; hi = INFINITY; }
       l[i] = lo; u[i] = hi; w[i] = 1;
@@ -513,11 +566,13 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
   __shared__ double red[NWAVE * 4];
   __shared__ double of0[260];           // f of the non-quadratic objective terms at the convexification point
   const int n_x = s.n_x, d = s.d, T = s.T, R = s.R, O = s.O, n = s.n, m = s.m;
+  const int ds = s.ds, NBt = s.NBt;             // state dimension of a block, number of timestep blocks
+  const RowLay L{T, NBt, R, s.Req};
   double *x = s.x + (size_t)b * n_x, *xs = s.x_saved + (size_t)b * n_x;
   const double *len = s.link_len + (size_t)b * d;
   const double *obs = s.obstacles + (size_t)b * O * 3;
-  double *gs = s.gsave + (size_t)b * s.m_nl, *J = s.J + (size_t)b * s.m_nl * d, *bm = s.bmod + (size_t)b * s.m_nl;
-  unsigned char *mask = s.mask + (size_t)b * s.m_nl * d;
+  double *gs = s.gsave + (size_t)b * s.m_nl, *J = s.J + (size_t)b * s.m_nl * ds, *bm = s.bmod + (size_t)b * s.m_nl;
+  unsigned char *mask = s.mask + (size_t)b * s.m_nl * ds;
   const double penalty = sc.penalty, trust = sc.trust;
   const int spawned = sc.spawned;
   int k_rows = sc.k;
@@ -527,21 +582,21 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     // Q3: which blocks sit on an already-seen / already-convexified rounded point
     __shared__ int ev_hit[260], cv_hit[260];
     const int H = s.H, HC = s.HC, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
-    const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point,
-                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O,
+    const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, ds, O, s.point,
+                  s.qQ + (size_t)b * O * ds * ds, s.qa + (size_t)b * O * ds, s.qc + (size_t)b * O,
                   s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par};
-    double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
-    double *ckey = s.ckey + (size_t)b * NB * HC * d, *cJ = s.cJ + (size_t)b * NB * HC * RM * d, *cb = s.cb + (size_t)b * NB * HC * RM;
+    double *hkey = s.hkey + (size_t)b * NB * H * ds, *hval = s.hval + (size_t)b * NB * H * RM;
+    double *ckey = s.ckey + (size_t)b * NB * HC * ds, *cJ = s.cJ + (size_t)b * NB * HC * RM * ds, *cb = s.cb + (size_t)b * NB * HC * RM;
     int *hn = s.hn + (size_t)b * NB, *cn = s.cn + (size_t)b * NB;
     for (int t = tid; t < NB; t += SCO_BLOCK) {
-      const double *xb = x + (t < T ? t : T - 1) * d;      // block T (equality rows) lives on the last timestep
-      ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * d, hn[t], d, xb) : -1;
-      cv_hit[t] = p.memo ? memo_find(ckey + (size_t)t * HC * d, cn[t], d, xb) : -1;
+      const double *xb = x + (t < NBt ? t : T - 1) * d;    // block NBt (reach equality rows) lives on the last timestep
+      ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * ds, hn[t], ds, xb) : -1;
+      cv_hit[t] = p.memo ? memo_find(ckey + (size_t)t * HC * ds, cn[t], ds, xb) : -1;
     }
     __syncthreads();
     // S1: f(x) per row, memoised on the rounded point (expr.py:34-41)
     for (int e = tid; e < m_nl; e += SCO_BLOCK) {
-      const RowRef q = row_ref(e, T, R);
+      const RowRef q = row_ref(e, L);
       double g;
       if (ev_hit[q.blk] >= 0) g = hval[((size_t)q.blk * H + ev_hit[q.blk]) * RM + q.r];
       else {
@@ -552,13 +607,15 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     }
     // S1/S2: Jacobian entry per thread (expr.py:61-69 numeric / :88 analytic); a block whose
     // rounded point was convexified before reuses that affine model (expr.py:362-365, 323-332)
-    for (int e = tid; e < m_nl * d; e += SCO_BLOCK) {
-      const int j = e % d;
-      const RowRef q = row_ref(e / d, T, R);
+    for (int e = tid; e < m_nl * ds; e += SCO_BLOCK) {
+      const int j = e % ds;
+      const RowRef q = row_ref(e / ds, L);
       const double *th = x + q.t * d;
       double val;
-      if (cv_hit[q.blk] >= 0) {
-        val = cJ[(((size_t)q.blk * HC + cv_hit[q.blk]) * RM + q.r) * d + j];
+      if (q.eq == 1 && j >= d) {
+        val = 0.0;                               // (a reach row lives on ONE timestep; its entry slots beyond dof do not exist)
+      } else if (cv_hit[q.blk] >= 0) {
+        val = cJ[(((size_t)q.blk * HC + cv_hit[q.blk]) * RM + q.r) * ds + j];
       } else if (s.analytic_jac) {
         val = row_grad(rc, q, th, j);
       } else {
@@ -583,7 +640,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         val = tab[FD_LEVELS - 1];
       }
       J[e] = val;
-      if (p.memo && cv_hit[q.blk] < 0 && cn[q.blk] < HC) cJ[(((size_t)q.blk * HC + cn[q.blk]) * RM + q.r) * d + j] = val;
+      if (p.memo && cv_hit[q.blk] < 0 && cn[q.blk] < HC) cJ[(((size_t)q.blk * HC + cn[q.blk]) * RM + q.r) * ds + j] = val;
       if (!spawned) mask[e] = (val != 0.0) ? 1 : 0;   // creation-time pattern (prob.py:264, 440)
     }
     __syncthreads();
@@ -594,9 +651,10 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     double *l = q1.l + (size_t)b * m, *u = q1.u + (size_t)b * m;
     int *w = q1.w + (size_t)b * m;
     for (int e = tid; e < m_nl; e += SCO_BLOCK) {
-      const RowRef q = row_ref(e, T, R);
+      const RowRef q = row_ref(e, L);
+      const int nj = q.eq == 1 ? d : ds;
       double acc = 0.0;
-      for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * x[q.t * d + j];
+      for (int j = 0; j < nj; j++) acc += J[(size_t)e * ds + j] * x[q.t * d + j];
       double bb = (gs[e] - acc) - row_rhs(rc, q);
       if (cv_hit[q.blk] >= 0) bb = cb[((size_t)q.blk * HC + cv_hit[q.blk]) * RM + q.r];
       else if (p.memo && cn[q.blk] < HC) cb[((size_t)q.blk * HC + cn[q.blk]) * RM + q.r] = bb;
@@ -605,17 +663,21 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
       if (q.eq) l[s.m_lin + e] = -bb;  // abs:   a x - p + n = -b        (prob.py:303-312, 480-484)
       w[s.m_lin + e] = k_rows;         // row present k times (prob.py:508-509)
     }
-    for (int e = tid; e < m_nl * d; e += SCO_BLOCK) {
-      const int j = e % d;
-      const RowRef q = row_ref(e / d, T, R);
-      const int pos = q.eq ? s.epos[j] + q.r : s.jpos[q.t * d + j] + q.r;
+    for (int e = tid; e < m_nl * ds; e += SCO_BLOCK) {
+      const int j = e % ds;
+      const RowRef q = row_ref(e / ds, L);
+      if (q.eq == 1 && j >= d) continue;
+      // column c = (timestep q.t + j / d, coordinate j % d) holds, below its linear entries, the R slots of every block
+      // that covers its timestep, in block order (sco_sqp_create)
+      const int c = q.t * d + j, tfirst = (c / d - s.S + 1 > 0) ? c / d - s.S + 1 : 0;
+      const int pos = q.eq == 1 ? s.epos[j] + q.r : s.jpos[c] + (q.blk - tfirst) * R + q.r;
       Av[pos] = mask[e] ? J[e] : 0.0;   // prob.py:493-504
     }
     double *qv = q1.q + (size_t)b * n;
     for (int i = tid; i < s.n_slack; i += SCO_BLOCK) qv[n_x + i] = slack_cost;   // prob.py:424-426
     if (s.cost) {
       // ---- non-quadratic objective terms: Expr.convexify(degree 2) (expr.py:143-153) per timestep block
-      const double tx = s.ctgt[(size_t)b * 2], ty = s.ctgt[(size_t)b * 2 + 1], cw = s.cw[b];
+      const ObjCtx oc{s.cost, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b]};
       double *oH = s.oH + (size_t)b * T * d * d, *oA = s.oA + (size_t)b * T * d, *ob = s.ob + (size_t)b * T;
       // f(x), memoised on the rounded point like every Expr.eval (expr.py:34-41); the term shares the point history of
       // its timestep's constraint block (same Variable, same evaluation points): its value is the block's last column
@@ -623,7 +685,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         double f;
         if (ev_hit[t] >= 0) f = hval[((size_t)t * H + ev_hit[t]) * RM + (RM - 1)];
         else {
-          f = arm_ee_cost(x + t * d, len, d, tx, ty, cw, -1, 0.0, -1, 0.0);
+          f = obj_value(oc, rc, x + t * d, -1, 0.0, -1, 0.0);
           if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * RM + (RM - 1)] = f;
         }
         of0[t] = f;
@@ -643,14 +705,14 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         for (int lv = 0; lv < FD_LEVELS; lv++) {
           const double hi = si / (double)(1 << lv), hj = sj / (double)(1 << lv);
           if (i == j) {
-            const double fp = arm_ee_cost(th, len, d, tx, ty, cw, i, hi, -1, 0.0);
-            const double fm = arm_ee_cost(th, len, d, tx, ty, cw, i, -hi, -1, 0.0);
+            const double fp = obj_value(oc, rc, th, i, hi, -1, 0.0);
+            const double fm = obj_value(oc, rc, th, i, -hi, -1, 0.0);
             tab[lv] = (fp - 2.0 * of0[t] + fm) / (hi * hi);
           } else {
-            const double fpp = arm_ee_cost(th, len, d, tx, ty, cw, i, hi, j, hj);
-            const double fpm = arm_ee_cost(th, len, d, tx, ty, cw, i, hi, j, -hj);
-            const double fmp = arm_ee_cost(th, len, d, tx, ty, cw, i, -hi, j, hj);
-            const double fmm = arm_ee_cost(th, len, d, tx, ty, cw, i, -hi, j, -hj);
+            const double fpp = obj_value(oc, rc, th, i, hi, j, hj);
+            const double fpm = obj_value(oc, rc, th, i, hi, j, -hj);
+            const double fmp = obj_value(oc, rc, th, i, -hi, j, hj);
+            const double fmm = obj_value(oc, rc, th, i, -hi, j, -hj);
             tab[lv] = (fpp - fpm - fmp + fmm) / (4.0 * hi * hj);
           }
         }
@@ -666,7 +728,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
 #pragma unroll
         for (int lv = 0; lv < FD_LEVELS; lv++) {
           const double h = h0 / (double)(1 << lv);
-          tab[lv] = (arm_ee_cost(th, len, d, tx, ty, cw, j, h, -1, 0.0) - arm_ee_cost(th, len, d, tx, ty, cw, j, -h, -1, 0.0)) / (2.0 * h);
+          tab[lv] = (obj_value(oc, rc, th, j, h, -1, 0.0) - obj_value(oc, rc, th, j, -h, -1, 0.0)) / (2.0 * h);
         }
         oA[e] = richardson(tab);
       }
@@ -703,7 +765,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     // S7: merit at the convexification point (prob.py:571-579), S4 prerequisite: save
     double v[2] = {traj_obj_partial(x, d, T, tid) + ((s.cost && tid < T) ? of0[tid] : 0.0), 0.0};
     for (int e = tid; e < m_nl; e += SCO_BLOCK) {
-      const RowRef q = row_ref(e, T, R);
+      const RowRef q = row_ref(e, L);
       v[1] += row_viol(q, gs[e] - row_rhs(rc, q));
     }
     block_reduce_sm<2, 0>(v, red);
@@ -711,9 +773,9 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
       // get_value(vectorize=True): per-block sums, then per-group sums in block order (prob.py:558-570)
       __shared__ double bsum[260];
       for (int blk = tid; blk < NB; blk += SCO_BLOCK) {
-        const int e0 = blk < T ? blk * R : T * R, cnt = blk < T ? R : s.NE;
+        const int e0 = blk < NBt ? blk * R : NBt * R, cnt = blk < NBt ? R : s.NE;
         double acc = 0.0;
-        for (int e = e0; e < e0 + cnt; e++) { const RowRef q = row_ref(e, T, R); acc += row_viol(q, gs[e] - row_rhs(rc, q)); }
+        for (int e = e0; e < e0 + cnt; e++) { const RowRef q = row_ref(e, L); acc += row_viol(q, gs[e] - row_rhs(rc, q)); }
         bsum[blk] = acc;
       }
       __syncthreads();
@@ -728,13 +790,13 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     // commit the new history entries (keys last, after every value has been written)
     if (p.memo)
       for (int t = tid; t < NB; t += SCO_BLOCK) {
-        const double *xb = x + (t < T ? t : T - 1) * d;
+        const double *xb = x + (t < NBt ? t : T - 1) * d;
         if (ev_hit[t] < 0 && hn[t] < H) {
-          for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(xb[j] * 1e6);
+          for (int j = 0; j < ds; j++) hkey[((size_t)t * H + hn[t]) * ds + j] = rint(xb[j] * 1e6);
           hn[t] += 1;
         } else if (ev_hit[t] < 0) atomicOr(&sc.flags, SCO_SQP_FLAG_MEMO_FULL);
         if (cv_hit[t] < 0 && cn[t] < HC) {
-          for (int j = 0; j < d; j++) ckey[((size_t)t * HC + cn[t]) * d + j] = rint(xb[j] * 1e6);
+          for (int j = 0; j < ds; j++) ckey[((size_t)t * HC + cn[t]) * ds + j] = rint(xb[j] * 1e6);
           cn[t] += 1;
         } else if (cv_hit[t] < 0) atomicOr(&sc.flags, SCO_SQP_FLAG_MEMO_FULL);
       }
@@ -770,10 +832,12 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   }
   __shared__ double red[NWAVE * 6];
   const int n_x = s.n_x, d = s.d, T = s.T, R = s.R, O = s.O, n = s.n;
+  const int ds = s.ds, NBt = s.NBt;
+  const RowLay L{T, NBt, R, s.Req};
   double *x = s.x + (size_t)b * n_x, *xs = s.x_saved + (size_t)b * n_x;
   const double *len = s.link_len + (size_t)b * d;
   const double *obs = s.obstacles + (size_t)b * O * 3;
-  const double *gs = s.gsave + (size_t)b * s.m_nl, *J = s.J + (size_t)b * s.m_nl * d, *bm = s.bmod + (size_t)b * s.m_nl;
+  const double *gs = s.gsave + (size_t)b * s.m_nl, *J = s.J + (size_t)b * s.m_nl * ds, *bm = s.bmod + (size_t)b * s.m_nl;
   const int status = q1.status[b], iters = q1.iters[b];
   // every scalar is read BEFORE the reduction's barriers; thread 0 rewrites them afterwards
   const double pen = sc.penalty, trust = sc.trust, merit = sc.merit, merit_viol0 = sc.merit_viol;
@@ -783,13 +847,13 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   // Q3: blocks of the trial point that round onto an already-seen point reuse its f values
   __shared__ int ev_hit[260];
   const int H = s.H, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
-  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point,
-                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O,
+  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, ds, O, s.point,
+                  s.qQ + (size_t)b * O * ds * ds, s.qa + (size_t)b * O * ds, s.qc + (size_t)b * O,
                   s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par};
-  double *hkey = s.hkey + (size_t)b * NB * H * d, *hval = s.hval + (size_t)b * NB * H * RM;
+  double *hkey = s.hkey + (size_t)b * NB * H * ds, *hval = s.hval + (size_t)b * NB * H * RM;
   int *hn = s.hn + (size_t)b * NB;
   for (int t = tid; t < NB; t += SCO_BLOCK)
-    ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * d, hn[t], d, xq + (t < T ? t : T - 1) * d) : -1;
+    ev_hit[t] = p.memo ? memo_find(hkey + (size_t)t * H * ds, hn[t], ds, xq + (t < NBt ? t : T - 1) * d) : -1;
   __syncthreads();
   // model violation uses the FULL Jacobian (prob.py:627-628), new violation f at the new point (prob.py:575-577)
   // v: quadratic objective, model violation, new violation, objective MODELS at the new point (prob.py:625-626),
@@ -809,17 +873,18 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
       double f;
       if (ev_hit[t] >= 0) f = hval[((size_t)t * H + ev_hit[t]) * RM + (RM - 1)];
       else {
-        f = arm_ee_cost(th, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b], -1, 0.0, -1, 0.0);
+        f = obj_value(ObjCtx{s.cost, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b]}, rc, th, -1, 0.0, -1, 0.0);
         if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * RM + (RM - 1)] = f;
       }
       v[4] += f;
     }
   }
   for (int e = tid; e < m_nl; e += SCO_BLOCK) {
-    const RowRef q = row_ref(e, T, R);
+    const RowRef q = row_ref(e, L);
     const double rhs = row_rhs(rc, q);
+    const int nj = q.eq == 1 ? d : ds;
     double acc = 0.0;
-    for (int j = 0; j < d; j++) acc += J[(size_t)e * d + j] * xq[q.t * d + j];
+    for (int j = 0; j < nj; j++) acc += J[(size_t)e * ds + j] * xq[q.t * d + j];
     v[1] += row_viol(q, acc + bm[e]);
     double g;
     if (ev_hit[q.blk] >= 0) g = hval[((size_t)q.blk * H + ev_hit[q.blk]) * RM + q.r];
@@ -834,8 +899,8 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   if (p.memo) {
     for (int t = tid; t < NB; t += SCO_BLOCK) {
       if (ev_hit[t] < 0 && hn[t] < H) {
-        const double *xb = xq + (t < T ? t : T - 1) * d;
-        for (int j = 0; j < d; j++) hkey[((size_t)t * H + hn[t]) * d + j] = rint(xb[j] * 1e6);
+        const double *xb = xq + (t < NBt ? t : T - 1) * d;
+        for (int j = 0; j < ds; j++) hkey[((size_t)t * H + hn[t]) * ds + j] = rint(xb[j] * 1e6);
         hn[t] += 1;
       } else if (ev_hit[t] < 0) {
         atomicOr(&sc.flags, SCO_SQP_FLAG_MEMO_FULL);
@@ -849,12 +914,13 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   if (s.G > 0) {
     __shared__ double bsum[260], gimp[32];
     for (int blk = tid; blk < NB; blk += SCO_BLOCK) {
-      const int e0 = blk < T ? blk * R : T * R, cnt = blk < T ? R : s.NE;
+      const int e0 = blk < NBt ? blk * R : NBt * R, cnt = blk < NBt ? R : s.NE;
       double acc = 0.0;
       for (int e = e0; e < e0 + cnt; e++) {
-        const RowRef q = row_ref(e, T, R);
+        const RowRef q = row_ref(e, L);
+        const int nj = q.eq == 1 ? d : ds;
         double ax = 0.0;
-        for (int j = 0; j < d; j++) ax += J[(size_t)e * d + j] * xq[q.t * d + j];
+        for (int j = 0; j < nj; j++) ax += J[(size_t)e * ds + j] * xq[q.t * d + j];
         acc += row_viol(q, ax + bm[e]);
       }
       bsum[blk] = acc;
@@ -939,15 +1005,16 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *
   const double *x = s.x + (size_t)b * n_x;
   const double *len = s.link_len + (size_t)b * d;
   const double *obs = s.obstacles + (size_t)b * O * 3;
-  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, d, O, s.point,
-                  s.qQ + (size_t)b * O * d * d, s.qa + (size_t)b * O * d, s.qc + (size_t)b * O,
+  const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, s.ds, O, s.point,
+                  s.qQ + (size_t)b * O * s.ds * s.ds, s.qa + (size_t)b * O * s.ds, s.qc + (size_t)b * O,
                   s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par};
+  const RowLay L{T, s.NBt, R, s.Req};
   double v[3] = {traj_obj_partial(x, d, T, tid), 0.0, 0.0};
   if (s.cost)
     for (int t = tid; t < T; t += SCO_BLOCK)
-      v[0] += arm_ee_cost(x + t * d, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b], -1, 0.0, -1, 0.0);
+      v[0] += obj_value(ObjCtx{s.cost, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b]}, rc, x + t * d, -1, 0.0, -1, 0.0);
   for (int e = tid; e < s.m_nl; e += SCO_BLOCK) {
-    const RowRef q = row_ref(e, T, R);
+    const RowRef q = row_ref(e, L);
     const double g = row_viol(q, row_value(rc, q, x + q.t * d, -1, 0.0) - row_rhs(rc, q));
     v[1] += g; v[2] = fmax(v[2], g);
   }
@@ -982,15 +1049,20 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
 
 extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
   if (!desc || !out) { sco_set_error("sco_sqp_create: null pointer"); return SCO_ERR_ARG; }
+  const int fam = desc->family & 15, span = desc->span > 0 ? desc->span : 1;
+  const bool statefam = fam == SCO_FAM_STATE_QUADRATIC || fam == SCO_FAM_STATE_PROGRAM;
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
-      desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS | SCO_FAM_FLAG_EE_COST)) ||
+      desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS | SCO_FAM_FLAG_EE_COST | SCO_FAM_FLAG_OBJ_PROGRAM)) ||
       ((desc->family & SCO_FAM_FLAG_EE_COST) && desc->dof > OBJ_DMAX) ||
-      ((desc->family & 15) != SCO_FAM_ARM_CIRCLES && (desc->family & 15) != SCO_FAM_ARM_REACH && (desc->family & 15) != SCO_FAM_POINT_CIRCLES &&
-       (desc->family & 15) != SCO_FAM_STATE_QUADRATIC && (desc->family & 15) != SCO_FAM_STATE_PROGRAM) ||
-      ((desc->family & 15) == SCO_FAM_POINT_CIRCLES && (desc->n_points != 1 || desc->dof < 2 || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
-      ((desc->family & 15) == SCO_FAM_STATE_QUADRATIC && (desc->n_points != 1 || desc->dof > OBJ_DMAX || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
-      ((desc->family & 15) == SCO_FAM_STATE_PROGRAM && (desc->n_points != 1 || desc->dof > OBJ_DMAX || desc->analytic_jac ||
-                                                        (desc->family & SCO_FAM_FLAG_EE_COST)))) {
+      (fam != SCO_FAM_ARM_CIRCLES && fam != SCO_FAM_ARM_REACH && fam != SCO_FAM_POINT_CIRCLES && !statefam) ||
+      (fam == SCO_FAM_POINT_CIRCLES && (desc->n_points != 1 || desc->dof < 2 || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
+      (statefam && (desc->n_points != 1 || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
+      (fam == SCO_FAM_STATE_QUADRATIC && desc->dof > OBJ_DMAX) ||
+      // blocks of `span` timesteps, equality rows and objective programs: the state families' extensions (r03)
+      desc->span < 0 || desc->span > 2 || desc->n_eq_rows < 0 || desc->n_eq_rows > desc->n_obstacles ||
+      (span > 1 && fam != SCO_FAM_STATE_PROGRAM) || (desc->n_eq_rows > 0 && !statefam) ||
+      (fam == SCO_FAM_STATE_PROGRAM && (span * desc->dof > SCO_STATE_MAX || span >= desc->horizon)) ||
+      ((desc->family & SCO_FAM_FLAG_OBJ_PROGRAM) && (fam != SCO_FAM_STATE_PROGRAM || span != 1 || desc->dof > OBJ_DMAX))) {
     sco_set_error("sco_sqp_create: bad descriptor"); return SCO_ERR_ARG;
   }
   int ndev = 0;
@@ -1019,12 +1091,15 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   }
   const int B = desc->batch, d = desc->dof, T = desc->horizon, K = desc->n_points, O = desc->n_obstacles;
   const bool reach = (desc->family & 15) == SCO_FAM_ARM_REACH, vel = (desc->family & SCO_FAM_FLAG_VEL_LIMITS) != 0;
-  const bool jl = (desc->family & SCO_FAM_FLAG_JOINT_LIMITS) != 0, cost = (desc->family & SCO_FAM_FLAG_EE_COST) != 0;
+  const bool jl = (desc->family & SCO_FAM_FLAG_JOINT_LIMITS) != 0;
+  const bool cost = (desc->family & (SCO_FAM_FLAG_EE_COST | SCO_FAM_FLAG_OBJ_PROGRAM)) != 0;
   const int NE = reach ? 2 : 0;                  // equality rows (end-effector x, y) on the last timestep
+  const int S = desc->span > 0 ? desc->span : 1, ds = S * d, NBt = T - S + 1, Req = desc->n_eq_rows;
   const int m_pin = reach ? d : 2 * d, dT1 = d * (T - 1), m_vel = vel ? 2 * dT1 : 0;
   const int m_jl = jl ? 2 * d * T : 0;
-  const int R = K * O, n_x = d * T, n_slack = T * R + 2 * NE, n = n_x + n_slack, m_lin = m_pin + m_vel + m_jl;
-  const int m_nl = T * R + NE, m = m_lin + m_nl + n;
+  // a hinge row has one slack, an equality row two (prob.py:258, 285-286); block-major, hinge rows of a block first
+  const int R = K * O, n_x = d * T, SB = R + Req, n_slack = NBt * SB + 2 * NE, n = n_x + n_slack, m_lin = m_pin + m_vel + m_jl;
+  const int m_nl = NBt * R + NE, m = m_lin + m_nl + n;
   // linear rows of column (t, j), ascending: pin, velocity rows "theta[t] - theta[t-1] <= vmax" (+1),
   // "theta[t+1] - theta[t] <= vmax" (-1), then the two negated rows
   auto linear_entries = [&](int t, int j, std::vector<int> &Ai, std::vector<double> &Av) {
@@ -1079,17 +1154,30 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
         const int t = col / d, j = col % d;
         linear_entries(t, j, Ai, a1c);
         jpos[col] = (int)Ai.size();
-        for (int r = 0; r < R; r++) { Ai.push_back(m_lin + t * R + r); a1c.push_back(0.0); }     // Jacobian slots
+        // Jacobian slots: the R rows of every block that covers timestep t (blocks t - S + 1 .. t), in block order
+        for (int blk = std::max(0, t - S + 1); blk <= std::min(t, NBt - 1); blk++)
+          for (int r = 0; r < R; r++) { Ai.push_back(m_lin + blk * R + r); a1c.push_back(0.0); }
         if (t == T - 1 && reach) {
           epos[j] = (int)Ai.size();
-          for (int r = 0; r < NE; r++) { Ai.push_back(m_lin + T * R + r); a1c.push_back(0.0); }
+          for (int r = 0; r < NE; r++) { Ai.push_back(m_lin + NBt * R + r); a1c.push_back(0.0); }
         }
         Ai.push_back(m_lin + m_nl + col); a1c.push_back(1.0);
       } else {
         // hinge slack i sits in hinge row i (-1); equality row r has p_r (slack T R + 2 r, -1) and n_r (+1)
         // (prob.py:265-275, 303-312); then the slack's bound row
-        const int sidx = col - n_x, ke = sidx - T * R;
-        Ai.push_back(m_lin + (ke < 0 ? sidx : T * R + ke / 2)); a1c.push_back((ke >= 0 && (ke & 1)) ? 1.0 : -1.0);
+        // slack columns block-major: per block its R - Req hinge slacks, then (p, n) of each of its Req equality rows;
+        // behind the blocks (p, n) of the reach rows
+        const int sidx = col - n_x;
+        int row; double sgn = -1.0;
+        if (sidx < NBt * SB) {
+          const int blk = sidx / SB, k = sidx % SB, nh = R - Req;
+          if (k < nh) row = blk * R + k;
+          else { row = blk * R + nh + (k - nh) / 2; if ((k - nh) & 1) sgn = 1.0; }
+        } else {
+          const int ke = sidx - NBt * SB;
+          row = NBt * R + ke / 2; if (ke & 1) sgn = 1.0;
+        }
+        Ai.push_back(m_lin + row); a1c.push_back(sgn);
         Ai.push_back(m_lin + m_nl + col); a1c.push_back(1.0);
       }
     }
@@ -1103,22 +1191,23 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   s.analytic_jac = desc->analytic_jac; s.trace_cap = 64;
   s.point = (desc->family & 15) == SCO_FAM_POINT_CIRCLES ? 1 : (desc->family & 15) == SCO_FAM_STATE_QUADRATIC ? 2 :
             (desc->family & 15) == SCO_FAM_STATE_PROGRAM ? 3 : 0;
-  s.NE = NE; s.NB = T + (reach ? 1 : 0); s.RM = std::max(R, NE) + (cost ? 1 : 0);     // + the objective term's value
-  s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl; s.cost = cost ? 1 : 0;
+  s.NE = NE; s.NB = NBt + (reach ? 1 : 0); s.RM = std::max(R, NE) + (cost ? 1 : 0);     // + the objective term's value
+  s.S = S; s.ds = ds; s.NBt = NBt; s.Req = Req;
+  s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl; s.cost = (desc->family & SCO_FAM_FLAG_OBJ_PROGRAM) ? 2 : cost ? 1 : 0;
   int rc = 0;
 #define AL(f, cnt) if ((rc = sq_alloc(h, (cnt), &s.f))) return rc;
   AL(x0, (size_t)B * n_x) AL(start, (size_t)B * d) AL(goal, (size_t)B * d) AL(link_len, (size_t)B * d)
   AL(obstacles, (size_t)B * O * 3) AL(target, (size_t)B * 2) AL(vmax, (size_t)B) AL(jlo, (size_t)B * d) AL(jhi, (size_t)B * d)
   {
     const bool quadf = (desc->family & 15) == SCO_FAM_STATE_QUADRATIC;
-    AL(qQ, quadf ? (size_t)B * O * d * d : 1) AL(qa, quadf ? (size_t)B * O * d : 1) AL(qc, quadf ? (size_t)B * O : 1)
+    AL(qQ, quadf ? (size_t)B * O * ds * ds : 1) AL(qa, quadf ? (size_t)B * O * ds : 1) AL(qc, quadf ? (size_t)B * O : 1)
   }
-  AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * d)
-  AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * d)
+  AL(x, (size_t)B * n_x) AL(x_saved, (size_t)B * n_x) AL(gsave, (size_t)B * m_nl) AL(J, (size_t)B * m_nl * ds)
+  AL(bmod, (size_t)B * m_nl) AL(trace, (size_t)B * s.trace_cap * TRACE_W) AL(mask, (size_t)B * m_nl * ds)
   AL(sc, (size_t)B) AL(active, (size_t)B) AL(n_active, SQP_MAX_GROUPS) AL(newqp, (size_t)B) AL(list_buf, (size_t)B)
   s.H = 40; s.HC = 24;
-  AL(hkey, (size_t)B * s.NB * s.H * d) AL(hval, (size_t)B * s.NB * s.H * s.RM) AL(ckey, (size_t)B * s.NB * s.HC * d)
-  AL(cJ, (size_t)B * s.NB * s.HC * s.RM * d) AL(cb, (size_t)B * s.NB * s.HC * s.RM) AL(hn, (size_t)B * s.NB)
+  AL(hkey, (size_t)B * s.NB * s.H * ds) AL(hval, (size_t)B * s.NB * s.H * s.RM) AL(ckey, (size_t)B * s.NB * s.HC * ds)
+  AL(cJ, (size_t)B * s.NB * s.HC * s.RM * ds) AL(cb, (size_t)B * s.NB * s.HC * s.RM) AL(hn, (size_t)B * s.NB)
   AL(cn, (size_t)B * s.NB)
   AL(cw, (size_t)B) AL(ctgt, (size_t)B * 2)
   AL(oH, cost ? (size_t)B * T * d * d : 1) AL(oA, cost ? (size_t)B * T * d : 1) AL(ob, cost ? (size_t)B * T : 1)
@@ -1151,6 +1240,7 @@ extern "C" int sco_sqp_destroy(sco_sqp *h) {
   if (h->qp0) sco_qp_destroy(h->qp0);
   if (h->qp1) sco_qp_destroy(h->qp1);
   for (void *p : h->allocs) (void)hipFree(p);
+  for (void *p : h->prog_buf) if (p) (void)hipFree(p);
   for (auto e : h->events) (void)hipEventDestroy(e);
   for (auto &ge : h->gevents) for (auto e : ge) (void)hipEventDestroy(e);
   for (auto e : h->done) (void)hipEventDestroy(e);
@@ -1262,20 +1352,25 @@ extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, c
   }
   if ((h->desc.family & 15) != SCO_FAM_STATE_PROGRAM) { sco_set_error("sco_sqp_load_program: family has no row programs"); return SCO_ERR_ARG; }
   if (!h->loaded) { sco_set_error("sco_sqp_load_program: call sco_sqp_load first"); return SCO_ERR_STATE; }
-  const int R = h->d.O, d = h->d.d;
-  if (n_words <= 0 || n_consts < 0 || n_params < 0 || row_ptr[0] != 0 || row_ptr[R] != n_words) {
-    sco_set_error("sco_sqp_load_program: bad program layout"); return SCO_ERR_ARG;
-  }
+  // the rows of a block, then (SCO_FAM_FLAG_OBJ_PROGRAM) the objective term of a timestep
+  const int R = h->d.O + (h->d.cost == 2 ? 1 : 0), ds = h->d.ds;
+  if (n_words <= 0 || n_consts < 0 || n_params < 0) { sco_set_error("sco_sqp_load_program: bad program layout"); return SCO_ERR_ARG; }
+  // the whole of row_ptr is checked BEFORE any word is read through it: 0 = first entry, strictly increasing, last = n_words
+  if (row_ptr[0] != 0) { sco_set_error("sco_sqp_load_program: bad program layout"); return SCO_ERR_ARG; }
+  for (int r = 0; r < R; r++)
+    if (row_ptr[r + 1] <= row_ptr[r] || row_ptr[r + 1] > n_words) { sco_set_error("sco_sqp_load_program: bad program layout"); return SCO_ERR_ARG; }
+  if (row_ptr[R] != n_words) { sco_set_error("sco_sqp_load_program: bad program layout"); return SCO_ERR_ARG; }
   // every row's program is run on the host once, symbolically: stack depth and operand indices
   for (int r = 0; r < R; r++) {
-    if (row_ptr[r + 1] <= row_ptr[r] || words[2 * (row_ptr[r + 1] - 1)] != SCO_OP_END) {
+    if (words[2 * (row_ptr[r + 1] - 1)] != SCO_OP_END) {
       sco_set_error("sco_sqp_load_program: a row's program must end with SCO_OP_END"); return SCO_ERR_ARG;
     }
+    const int nx = r < h->d.O ? ds : h->d.d;      // the objective term sees one timestep
     int sp = 0;
     for (int w = row_ptr[r]; w < row_ptr[r + 1] - 1; w++) {
       const int op = words[2 * w], arg = words[2 * w + 1];
       bool ok = true;
-      if (op == SCO_OP_X) { ok = arg >= 0 && arg < d; sp++; }
+      if (op == SCO_OP_X) { ok = arg >= 0 && arg < nx; sp++; }
       else if (op == SCO_OP_P) { ok = arg >= 0 && arg < n_params; sp++; }
       else if (op == SCO_OP_C) { ok = arg >= 0 && arg < n_consts; sp++; }
       else if (op >= SCO_OP_ADD && op <= SCO_OP_DIV) { ok = sp >= 2; sp--; }
@@ -1287,15 +1382,22 @@ extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, c
   }
   SCO_ON_DEVICE(h->device);
   SqpDev &s = h->d;
-  int rc;
-  int *pw = nullptr, *pptr = nullptr; double *pc = nullptr, *pp = nullptr;
-  if ((rc = sq_alloc(h, (size_t)2 * n_words, &pw)) || (rc = sq_alloc(h, (size_t)R + 1, &pptr)) ||
-      (rc = sq_alloc(h, (size_t)n_consts, &pc)) || (rc = sq_alloc(h, (size_t)s.batch * n_params, &pp))) return rc;
-  SCO_HIP(hipMemcpy(pw, words, (size_t)2 * n_words * sizeof(int), hipMemcpyHostToDevice));
-  SCO_HIP(hipMemcpy(pptr, row_ptr, ((size_t)R + 1) * sizeof(int), hipMemcpyHostToDevice));
-  if (n_consts) SCO_HIP(hipMemcpy(pc, consts, (size_t)n_consts * sizeof(double), hipMemcpyHostToDevice));
-  if (n_params) SCO_HIP(hipMemcpy(pp, params, (size_t)s.batch * n_params * sizeof(double), hipMemcpyHostToDevice));
-  s.pw = pw; s.pptr = pptr; s.pconst = pc; s.ppar = pp; s.n_par = n_params;
+  // the four buffers belong to the handle: a reload of the same sizes (new parameters per solve) reuses them, another
+  // size frees the old ones first
+  const size_t need[4] = {(size_t)2 * n_words * sizeof(int), ((size_t)R + 1) * sizeof(int), (size_t)std::max(n_consts, 1) * sizeof(double),
+                          std::max<size_t>((size_t)s.batch * n_params, 1) * sizeof(double)};
+  for (int k = 0; k < 4; k++)
+    if (h->prog_bytes[k] != need[k]) {
+      if (h->prog_buf[k]) { (void)hipFree(h->prog_buf[k]); h->prog_buf[k] = nullptr; h->prog_bytes[k] = 0; }
+      SCO_HIP(hipMalloc(&h->prog_buf[k], need[k]));
+      h->prog_bytes[k] = need[k];
+    }
+  SCO_HIP(hipMemcpy(h->prog_buf[0], words, (size_t)2 * n_words * sizeof(int), hipMemcpyHostToDevice));
+  SCO_HIP(hipMemcpy(h->prog_buf[1], row_ptr, ((size_t)R + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (n_consts) SCO_HIP(hipMemcpy(h->prog_buf[2], consts, (size_t)n_consts * sizeof(double), hipMemcpyHostToDevice));
+  if (n_params) SCO_HIP(hipMemcpy(h->prog_buf[3], params, (size_t)s.batch * n_params * sizeof(double), hipMemcpyHostToDevice));
+  s.pw = (const int *)h->prog_buf[0]; s.pptr = (const int *)h->prog_buf[1];
+  s.pconst = (const double *)h->prog_buf[2]; s.ppar = (const double *)h->prog_buf[3]; s.n_par = n_params;
   h->prog_loaded = true; h->solved = false;
   return SCO_OK;
 }

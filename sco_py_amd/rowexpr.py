@@ -12,6 +12,13 @@ a per-problem parameter vector p can be handed to the device as a small postfix 
 
 Both forms run the SAME operation sequence in double precision, so the host callable (reference, mirror API, oracle)
 and the device program agree to the last bits of sin / cos / sqrt / exp.
+
+r03: the state of a row may be the concatenation of ``span`` = 2 consecutive timesteps (X(i), i < 2 dof: the reference binds
+any Expr to any Variable, expr.py:413-437 -- swept volumes, dynamics); the last ``n_eq`` rows of a block may be equalities
+g(x, p) = 0 (EqExpr -> abs penalty, prob.py:280-315); one more expression may be a non-quadratic OBJECTIVE term of a timestep
+(Prob.add_obj_expr on a plain Expr, prob.py:88-104); and ``Program.jacobian`` differentiates the rows in forward mode with
+the same rules, in the same order of operations, as the device interpreter (csrc/sco_sqp.hip: prog_dual) -- the ``grad`` a
+caller hands to ``Expr(f, grad)`` (expr.py:86-100).
 """
 import numpy as np
 
@@ -66,20 +73,25 @@ def exp(a): return Node(OP_EXP, kids=(Node.lift(a),))
 class Program(object):
     """Rows compiled to the wire format of sco_sqp_load_program."""
 
-    def __init__(self, words, row_ptr, consts):
+    def __init__(self, words, row_ptr, consts, n_eq=0, span=1, objective=False):
         self.words = np.ascontiguousarray(words, dtype=np.int32).reshape(-1, 2)
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
         self.consts = np.ascontiguousarray(consts, dtype=np.float64)
-        self.n_rows = len(self.row_ptr) - 1
+        self.objective = bool(objective)           # the LAST program is an objective term, not a constraint row
+        self.n_rows = len(self.row_ptr) - 1 - (1 if self.objective else 0)      # constraint rows of a block
+        self.n_eq = int(n_eq)                      # how many of them (the last ones) are equalities
+        self.span = int(span)                      # timesteps per constraint block
         ops = self.words
         self.n_params = int(ops[ops[:, 0] == OP_P, 1].max()) + 1 if np.any(ops[:, 0] == OP_P) else 0
         self.n_state = int(ops[ops[:, 0] == OP_X, 1].max()) + 1 if np.any(ops[:, 0] == OP_X) else 0
 
-    def evaluate(self, x, p=()):
+    def evaluate(self, x, p=(), rows=None):
         """g (n_rows,) at state x with parameters p: the interpreter the device runs, in NumPy scalars."""
         x = np.asarray(x, dtype=np.float64).ravel(); p = np.asarray(p, dtype=np.float64).ravel()
-        out = np.zeros(self.n_rows)
-        for r in range(self.n_rows):
+        rows = range(self.n_rows) if rows is None else list(rows)
+        res = np.zeros(len(rows))
+        out = {}
+        for r in rows:
             st = []
             for op, arg in self.words[self.row_ptr[r]:self.row_ptr[r + 1] - 1]:
                 if op == OP_X: st.append(np.float64(x[arg]))
@@ -95,23 +107,77 @@ class Program(object):
                     b = st.pop(); a = st[-1]
                     st[-1] = a + b if op == OP_ADD else a - b if op == OP_SUB else a * b if op == OP_MUL else a / b
             out[r] = st[0]
-        return out
+        for k, r in enumerate(rows):
+            res[k] = out[r]
+        return res
 
-    def numpy_fn(self, p=()):
+    def jacobian(self, x, p=(), rows=None):
+        """d g / d x (len(rows), len(x)) by forward-mode differentiation: one pass per coordinate j with (value, derivative)
+        pairs on the stack -- the rules and their order of operations are those of the device (prog_dual)."""
+        x = np.asarray(x, dtype=np.float64).ravel(); p = np.asarray(p, dtype=np.float64).ravel()
+        rows = range(self.n_rows) if rows is None else list(rows)
+        J = np.zeros((len(rows), x.shape[0]))
+        one, zero, two = np.float64(1.0), np.float64(0.0), np.float64(2.0)
+        for k, r in enumerate(rows):
+            for j in range(x.shape[0]):
+                sv, sd = [], []
+                for op, arg in self.words[self.row_ptr[r]:self.row_ptr[r + 1] - 1]:
+                    if op == OP_X: sv.append(np.float64(x[arg])); sd.append(one if arg == j else zero)
+                    elif op == OP_P: sv.append(np.float64(p[arg])); sd.append(zero)
+                    elif op == OP_C: sv.append(np.float64(self.consts[arg])); sd.append(zero)
+                    elif op == OP_NEG: sv[-1] = -sv[-1]; sd[-1] = -sd[-1]
+                    elif op == OP_SIN: sd[-1] = np.cos(sv[-1]) * sd[-1]; sv[-1] = np.sin(sv[-1])
+                    elif op == OP_COS: sd[-1] = -(np.sin(sv[-1]) * sd[-1]); sv[-1] = np.cos(sv[-1])
+                    elif op == OP_SQRT: rt = np.sqrt(sv[-1]); sd[-1] = sd[-1] / (two * rt); sv[-1] = rt
+                    elif op == OP_EXP: ev = np.exp(sv[-1]); sd[-1] = ev * sd[-1]; sv[-1] = ev
+                    elif op == OP_SQUARE: sd[-1] = (two * sv[-1]) * sd[-1]; sv[-1] = sv[-1] * sv[-1]
+                    else:
+                        bv, bd = sv.pop(), sd.pop()
+                        av, ad = sv[-1], sd[-1]
+                        if op == OP_ADD: sv[-1] = av + bv; sd[-1] = ad + bd
+                        elif op == OP_SUB: sv[-1] = av - bv; sd[-1] = ad - bd
+                        elif op == OP_MUL: sd[-1] = ad * bv + av * bd; sv[-1] = av * bv
+                        else: qv = av / bv; sd[-1] = (ad - qv * bd) / bv; sv[-1] = qv
+                J[k, j] = sd[0]
+        return J
+
+    def numpy_fn(self, p=(), rows=None):
         """x -> g(x) for fixed parameters: the callable to wrap in the reference's / the mirror's Expr(f)."""
         p = np.array(p, dtype=np.float64)
-        return lambda x: self.evaluate(x, p)
+        return lambda x: self.evaluate(x, p, rows)
+
+    def numpy_jac(self, p=(), rows=None):
+        """x -> dg/dx for fixed parameters: the ``grad`` of Expr(f, grad)."""
+        p = np.array(p, dtype=np.float64)
+        return lambda x: self.jacobian(x, p, rows)
+
+    # the rows of a block by kind, and the objective term (index n_rows)
+    @property
+    def ineq_rows(self): return list(range(self.n_rows - self.n_eq))
+
+    @property
+    def eq_rows(self): return list(range(self.n_rows - self.n_eq, self.n_rows))
+
+    def objective_fn(self, p=()):
+        """x -> f(x) (a float): the objective term of a timestep (needs ``objective=``)."""
+        assert self.objective
+        p = np.array(p, dtype=np.float64)
+        return lambda x: float(self.evaluate(x, p, rows=[self.n_rows])[0])
 
 
-def compile_rows(rows):
-    """List of Node expressions (one per constraint row g_r(x, p) <= 0) -> Program."""
+def compile_rows(rows, eq_rows=(), objective=None, span=1):
+    """List of Node expressions -> Program.  ``rows``: inequality rows g_r(x, p) <= 0; ``eq_rows``: equality rows
+    g_r(x, p) = 0 (they follow the inequalities in a block); ``objective``: a non-quadratic objective term f(x, p) of ONE
+    timestep (span 1 only); ``span``: timesteps per constraint block (X(i) addresses i < span * dof)."""
+    if span not in (1, 2) or (objective is not None and span != 1):
+        raise ValueError("span is 1 or 2; an objective term needs span 1")
     words, row_ptr, consts = [], [0], []
-    for r in rows:
+    for r in list(rows) + list(eq_rows) + ([objective] if objective is not None else []):
         Node.lift(r).emit(words, consts)
         words.append((OP_END, 0))
         row_ptr.append(len(words))
-    prog = Program(words, row_ptr, consts)
-    for r in range(prog.n_rows):                      # the same checks the C side makes, with Python errors
+    prog = Program(words, row_ptr, consts, n_eq=len(list(eq_rows)), span=span, objective=objective is not None)
+    for r in range(len(prog.row_ptr) - 1):            # the same checks the C side makes, with Python errors
         sp = 0
         for op, arg in prog.words[prog.row_ptr[r]:prog.row_ptr[r + 1] - 1]:
             if op in (OP_X, OP_P, OP_C): sp += 1

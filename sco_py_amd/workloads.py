@@ -256,9 +256,74 @@ def corridor_program(d):
     return _PROGRAMS[d]
 
 
-def make_program_problem(i, d=2, T=20, noise=0.03, groups=None, vel_limit=None, joint_limit=None):
+def variant_program(variant, d):
+    """Programs of the r03 variants of the program family (compiled once per (variant, dof)):
+
+    "sweep"     span 2, dof >= 2: the MIDPOINT of the step (x_t, x_t+1) keeps out of two discs whose radius grows with the
+                squared step length (a swept-volume style keep-out: faster motion needs more clearance), and a step-length
+                limit that depends on the height of the midpoint -- inequality rows on two timesteps;
+    "dynamics"  span 2, dof = 3 (px, py, heading): the unicycle step px' - px = v cos(phi), py' - py = v sin(phi) as two
+                EQUALITY rows on (x_t, x_t+1) (v = p[0]: the reference's EqExpr on an Expr, lowered to the abs penalty),
+                plus a keep-out disc on x_t and a turn-rate limit |phi' - phi| <= p[5] as inequality rows;
+    "curve"     span 1, dof = 3: the third coordinate follows z = p[8] sin(p[9] x) (an equality row on ONE timestep) and the
+                two rippled discs of the corridor program keep out;
+    "attract"   span 1, dof >= 2: the corridor rows plus a NON-QUADRATIC OBJECTIVE TERM per timestep, a Gaussian well
+                -p[13] exp(-|x - g|^2 / 0.18) around g = p[14:16] (non-convex away from g: the eigenvalue shift acts)."""
+    key = (variant, d)
+    if key in _PROGRAMS:
+        return _PROGRAMS[key]
+    from .rowexpr import X, P, sin, cos, sqrt, exp, compile_rows
+    if variant == "sweep":
+        rows = []
+        mx, my = 0.5 * (X(0) + X(d)), 0.5 * (X(1) + X(d + 1))
+        step2 = (X(d) - X(0)) ** 2 + (X(d + 1) - X(1)) ** 2
+        for o in range(2):
+            dx, dy = mx - P(3 * o), my - P(3 * o + 1)
+            rows.append(P(3 * o + 2) * (1.0 + P(6) * step2) - sqrt(dx ** 2 + dy ** 2 + 1e-12))
+        rows.append(step2 - (P(7) + P(8) * my) ** 2)                  # shorter steps where the midpoint is low
+        prog = compile_rows(rows, span=2)
+    elif variant == "dynamics":
+        assert d == 3
+        ineq = [P(3) - sqrt((X(0) - P(1)) ** 2 + (X(1) - P(2)) ** 2 + 1e-12),            # keep-out disc on x_t
+                (X(5) - X(2)) ** 2 - P(5) ** 2]                                            # turn-rate limit
+        eq = [X(3) - X(0) - P(0) * cos(X(2)), X(4) - X(1) - P(0) * sin(X(2))]             # unicycle step, speed p[0]
+        prog = compile_rows(ineq, eq_rows=eq, span=2)
+    elif variant == "curve":
+        assert d == 3
+        rows = []
+        for o in range(2):
+            cx, cy, rad, rip = P(4 * o), P(4 * o + 1), P(4 * o + 2), P(4 * o + 3)
+            dx, dy = X(0) - cx, X(1) - cy
+            dist = sqrt(dx ** 2 + dy ** 2 + 1e-12)
+            rows.append(rad * (1.0 + rip * (dx / dist) * (dy / dist)) - dist)
+        prog = compile_rows(rows, eq_rows=[X(2) - P(8) * sin(P(9) * X(0))])
+    elif variant == "attract":
+        base = corridor_program(d)
+        # (rebuild the corridor rows as expressions: compile_rows wants Nodes, so the rows are written out again)
+        rows = []
+        for o in range(2):
+            cx, cy, rad, rip = P(4 * o), P(4 * o + 1), P(4 * o + 2), P(4 * o + 3)
+            dx, dy = X(0) - cx, X(1) - cy
+            dist = sqrt(dx ** 2 + dy ** 2 + 1e-12)
+            rows.append(rad * (1.0 + rip * (dx / dist) * (dy / dist)) - dist)
+        rows.append(X(1) - (P(8) + P(9) * sin(P(10) * X(0))))
+        rows.append(P(11) - 0.5 * exp(-((X(0) - P(12)) ** 2) * 4.0) - X(1))
+        if d > 2:
+            rows[-1] = rows[-1] + 0.05 * cos(X(2))
+        well = -(P(13) * exp(-((X(0) - P(14)) ** 2 + (X(1) - P(15)) ** 2) / 0.18))
+        prog = compile_rows(rows, objective=well)
+        assert prog.n_rows == base.n_rows
+    else:
+        raise ValueError("unknown program variant %r" % (variant,))
+    _PROGRAMS[key] = prog
+    return prog
+
+
+def make_program_problem(i, d=2, T=20, noise=0.03, groups=None, vel_limit=None, joint_limit=None, variant=None):
     """Seeded problem i of the program family (SCO_FAM_STATE_PROGRAM): the rows of corridor_program(d) with per-problem
-    parameters.  Same dictionary layout as make_problem (K = 1, O = 4 rows per timestep)."""
+    parameters.  Same dictionary layout as make_problem (K = 1, O = 4 rows per timestep).  ``variant``: see variant_program."""
+    if variant is not None:
+        return make_program_variant(i, variant, d=d, T=T, noise=noise, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
     rng = np.random.default_rng(9000 + i)
     start = np.concatenate([[-1.0, rng.uniform(-0.2, 0.2)], rng.uniform(-0.3, 0.3, size=d - 2)])
     goal = np.concatenate([[1.0, rng.uniform(-0.2, 0.2)], rng.uniform(-0.3, 0.3, size=d - 2)])
@@ -285,13 +350,72 @@ def make_program_problem(i, d=2, T=20, noise=0.03, groups=None, vel_limit=None, 
     return out
 
 
+def make_program_variant(i, variant, d=2, T=12, noise=0.03, groups=None, vel_limit=None, joint_limit=None):
+    """Seeded problem i of a r03 variant of the program family (variant_program)."""
+    rng = np.random.default_rng(9500 + 97 * (sorted(["sweep", "dynamics", "curve", "attract"]).index(variant)) + i)
+    prog = variant_program(variant, d)
+    start = np.concatenate([[-1.0, rng.uniform(-0.2, 0.2)], rng.uniform(-0.3, 0.3, size=d - 2)])
+    goal = np.concatenate([[1.0, rng.uniform(-0.2, 0.2)], rng.uniform(-0.3, 0.3, size=d - 2)])
+    if variant == "dynamics":
+        head = np.arctan2(goal[1] - start[1], goal[0] - start[0])
+        start[2] = head; goal[2] = head
+    if variant == "curve":
+        amp, freq = rng.uniform(0.15, 0.3), rng.uniform(1.5, 3.0)
+        start[2] = amp * np.sin(freq * start[0]); goal[2] = amp * np.sin(freq * goal[0])       # the pins sit on the curve
+    s = np.linspace(0.0, 1.0, T)[:, None]
+    x0 = (1 - s) * start[None, :] + s * goal[None, :] + noise * rng.standard_normal((T, d))
+
+    def disc(lo=0.3, hi=0.7):
+        a = rng.uniform(lo, hi)
+        return (1 - a) * start[:2] + a * goal[:2] + 0.05 * rng.standard_normal(2)
+
+    if variant == "sweep":
+        par = np.zeros(9)
+        for o in range(2):
+            par[3 * o:3 * o + 2] = disc(0.25 + 0.3 * o, 0.45 + 0.3 * o); par[3 * o + 2] = rng.uniform(0.12, 0.2)
+        par[6] = rng.uniform(1.0, 3.0)                               # clearance grows with the squared step
+        step = np.linalg.norm(goal[:2] - start[:2]) / (T - 1)
+        par[7] = rng.uniform(1.6, 2.2) * step; par[8] = rng.uniform(0.0, 0.4) * step
+    elif variant == "dynamics":
+        par = np.zeros(6)
+        par[0] = rng.uniform(1.05, 1.2) * np.linalg.norm(goal[:2] - start[:2]) / (T - 1)        # a little faster than the chord
+        par[1:3] = disc(0.4, 0.6); par[3] = rng.uniform(0.1, 0.18)
+        par[5] = rng.uniform(0.5, 0.9)
+    elif variant == "curve":
+        par = np.zeros(10)
+        for o in range(2):
+            par[4 * o:4 * o + 2] = disc(0.25 + 0.3 * o, 0.45 + 0.3 * o)
+            par[4 * o + 2] = rng.uniform(0.12, 0.2); par[4 * o + 3] = rng.uniform(-0.3, 0.3)
+        par[8:10] = (amp, freq)
+    else:                                                            # attract
+        par = np.zeros(16)
+        for o in range(2):
+            a = rng.uniform(0.25, 0.75)
+            par[4 * o:4 * o + 2] = (1 - a) * start[:2] + a * goal[:2] + 0.05 * rng.standard_normal(2)
+            par[4 * o + 2] = rng.uniform(0.12, 0.22); par[4 * o + 3] = rng.uniform(-0.3, 0.3)
+        par[8:11] = (rng.uniform(0.55, 0.75), rng.uniform(0.05, 0.15), rng.uniform(2.0, 4.0))
+        par[11:13] = (-rng.uniform(0.6, 0.8), rng.uniform(-0.3, 0.3))
+        par[13] = rng.uniform(0.2, 0.5); par[14:16] = (rng.uniform(-0.4, 0.4), rng.uniform(0.25, 0.5))
+    out = dict(d=d, T=T, K=1, O=prog.n_rows, x0=x0.ravel(), start=start, goal=goal, link_len=np.ones(d),
+               point_link=np.zeros(1, dtype=np.int32), point_frac=np.ones(1), obstacles=np.zeros((prog.n_rows, 3)), reach=False,
+               row_program=prog, row_params=par)
+    if groups is not None:
+        out["groups"] = block_groups(T - prog.span + 1, False, groups)
+    if vel_limit is not None:
+        out["vmax"] = float(vel_limit)
+    if joint_limit is not None:
+        out["jlo"] = np.minimum(start, goal) - float(joint_limit)
+        out["jhi"] = np.maximum(start, goal) + float(joint_limit)
+    return out
+
+
 def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None,
-                 ee_cost_weight=None, point=False, quadratic=False, program=False):
+                 ee_cost_weight=None, point=False, quadratic=False, program=False, variant=None):
     """Seeded problem i of the batch.  reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
     if program:
-        return make_program_problem(i, d=d, T=T, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
+        return make_program_problem(i, d=d, T=T, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit, variant=variant)
     if quadratic:
         return make_quadratic_problem(i, d=d, T=T, O=O, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
     if point:

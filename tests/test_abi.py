@@ -54,7 +54,7 @@ def test_struct_layouts_match_the_c_side():
     # sizes the C compiler gives the same declarations
     assert ctypes.sizeof(_lib.QpSettings) == 7 * 8 + 6 * 4 + 8
     assert ctypes.sizeof(_lib.SqpParams) == 9 * 8 + 7 * 4 + 4        # 7 ints, padded to the 8-byte alignment
-    assert ctypes.sizeof(_lib.TrajoptDesc) == 8 * 4
+    assert ctypes.sizeof(_lib.TrajoptDesc) == 10 * 4         # r03: + span, n_eq_rows
 
 
 def test_no_gpu_means_a_loud_failure_not_a_fallback():

@@ -745,8 +745,6 @@ def test_program_family_validation(gpu):
     import ctypes as C
     arrays, _ = af.make_batch(2, d=2, T=6, K=1, program=True)
     prog = arrays["row_program"]
-    with pytest.raises(ValueError):
-        sb.TrajOptBatch(2, 2, 6, 1, prog.n_rows, program=True, analytic_jac=True)
     with sb.TrajOptBatch(2, 2, 6, 1, prog.n_rows, program=True) as tb:
         lib = _lib.load()
         assert lib.sco_sqp_load(tb._h, _lib.dptr(arrays["x0"]), _lib.dptr(arrays["start"]), _lib.dptr(arrays["goal"]),
@@ -769,8 +767,18 @@ def test_program_family_validation(gpu):
         bad = prog.words.copy(); bad[1] = (99, 0)                                 # unknown opcode
         assert load(bad) != 0
         assert load(prog.words, npar=3) != 0                                      # the program reads parameter 12
+        # row_ptr is checked as a whole before any word is read through it (r02 advisor): not increasing, beyond the words
+        rp = prog.row_ptr.copy(); rp[1] = 10 ** 6
+        assert load(prog.words, row_ptr=rp) != 0
+        rp = prog.row_ptr.copy(); rp[2] = rp[1]
+        assert load(prog.words, row_ptr=rp) != 0
         assert load(prog.words) == 0
         tb.solve()
+        first = tb.fetch().x.copy()
+        for _ in range(3):                                                        # reloads reuse the handle's buffers
+            assert load(prog.words) == 0
+        tb.solve()
+        assert np.array_equal(tb.fetch().x, first)
 
 
 def test_joint_limits_7x20_batch_and_validation(gpu):
@@ -974,3 +982,72 @@ def test_opt_in_layouts_through_the_sliced_sqp_loop(gpu, monkeypatch, switch):
             outs.append(r)
     assert np.array_equal(outs[0].x, outs[1].x) and np.array_equal(outs[0].admm_iters, outs[1].admm_iters)
     _compare(outs[1], probs, range(2))
+
+
+@pytest.mark.parametrize("variant,kw", [("sweep", dict(d=2, T=8)), ("sweep", dict(d=3, T=6)), ("dynamics", dict(d=3, T=8)),
+                                        ("curve", dict(d=3, T=8)), ("attract", dict(d=2, T=8)),
+                                        ("sweep", dict(d=2, T=8, vel_limit=0.6, groups="split")),
+                                        ("dynamics", dict(d=3, T=8, joint_limit=0.4, groups="halves"))])
+@pytest.mark.parametrize("analytic", [False, True])
+def test_wide_program_blocks_match_oracle(gpu, variant, kw, analytic):
+    """r03 extensions of SCO_FAM_STATE_PROGRAM on the device: constraint blocks on two consecutive timesteps ("sweep":
+    swept-volume style keep-outs; "dynamics": the unicycle step as EQUALITY rows -> abs penalty with two slacks per row,
+    /root/reference/sco_py/sco_osqp/prob.py:280-315), an equality row on one timestep ("curve"), a non-quadratic objective
+    program per timestep ("attract": prob.py:88-104, expr.py:143-153), each with numeric (Richardson central differences)
+    and with forward-mode analytic Jacobians (expr.py:86-100) -- decision for decision against the oracle."""
+    if variant == "attract" and analytic:
+        pytest.skip("the objective term is always differentiated numerically (as in the reference: Expr without grad / hess)")
+    arrays, probs = af.make_batch(6, K=1, program=True, variant=variant, **kw)
+    res = sb.solve_batch(arrays, analytic_jac=analytic)
+    _compare(res, probs, range(6), analytic=analytic)
+
+
+def test_wide_program_blocks_match_reference_golden_runs(gpu):
+    """The same extensions against runs of the REFERENCE's own modules (tests/golden/make_golden_prog.py ->
+    trajopt_prog2.npz): trajectory to 1e-6, success flag, and the status of every QP."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from prog_cases import CASES2
+    g = np.load(os.path.join(GOLD, "trajopt_prog2.npz"))
+    for prefix, kw, i, aj in CASES2:
+        arrays, _ = af.make_batch(1, first=i, **kw)
+        res = sb.solve_batch(arrays, analytic_jac=aj)
+        assert np.abs(res.x[0] - g[prefix + "x"]).max() < TOL, (prefix, np.abs(res.x[0] - g[prefix + "x"]).max())
+        assert bool(res.success[0]) == bool(g[prefix + "success"]), prefix
+        nq = int(g[prefix + "n_qp"])
+        assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix
+        if arrays["row_program"].n_eq == 0 and not arrays["row_program"].objective:
+            # (equality rows: the reference's slack column order is another one, an ADMM run that stops on max_iter may
+            # end one termination check apart; objective terms: numeric Hessians, DESIGN 4)
+            assert [int(v) for v in res.trace[0][:, 7]] == [int(g["%sqp%d_iters" % (prefix, k)]) for k in range(nq)], prefix
+
+
+def test_wide_program_blocks_above_the_cu_count_and_descriptor_rules(gpu):
+    """300 dynamics problems (round selection, time slices) sampled against the oracle; success means every row of every
+    block holds at the returned trajectory; descriptor rules of the extensions."""
+    arrays, probs = af.make_batch(300, d=3, T=8, K=1, program=True, variant="dynamics")
+    res = sb.solve_batch(arrays)
+    _compare(res, probs, range(0, 300, 61))
+    prog = arrays["row_program"]
+    for b in np.nonzero(res.success)[0][:40]:
+        x = res.x[b]
+        for t in range(8 - 1):
+            g = prog.evaluate(x[t * 3:(t + 2) * 3], arrays["row_params"][b])
+            assert g[prog.ineq_rows].max() < 1e-3 and np.abs(g[prog.eq_rows]).max() < 1e-3
+    from sco_py_amd.rowexpr import X, compile_rows
+    with pytest.raises(_lib.ScoHipError):                       # span 2 of a horizon of 2 leaves one block: allowed; 3 is not a span
+        sb.TrajOptBatch(1, 20, 6, 1, 1, program=compile_rows([X(0) + X(39)], span=2))       # 2 x 20 > 32 state coordinates
+    with pytest.raises(ValueError):
+        compile_rows([X(0)], objective=X(1), span=2)           # objective terms live on one timestep
+    import ctypes as C
+    lib = _lib.load()
+    for fam, span, neq in ((sb.SCO_FAM_ARM_CIRCLES, 2, 0), (sb.SCO_FAM_ARM_CIRCLES, 1, 1), (sb.SCO_FAM_STATE_QUADRATIC, 2, 0),
+                           (sb.SCO_FAM_STATE_PROGRAM, 3, 0), (sb.SCO_FAM_STATE_PROGRAM, 1, 5),
+                           (sb.SCO_FAM_STATE_PROGRAM | sb.SCO_FAM_FLAG_OBJ_PROGRAM, 2, 0)):
+        h = C.c_void_p()
+        desc = _lib.TrajoptDesc(1, 3, 6, 1, 2, fam, 0, 2, span, neq)
+        assert lib.sco_sqp_create(0, C.byref(desc), C.byref(h)) == -1, (fam, span, neq)      # SCO_ERR_ARG
+    h = C.c_void_p()                                           # equality rows are open to the quadratic-row family too
+    desc = _lib.TrajoptDesc(1, 3, 6, 1, 2, sb.SCO_FAM_STATE_QUADRATIC, 0, 2, 1, 1)
+    assert lib.sco_sqp_create(0, C.byref(desc), C.byref(h)) == 0
+    assert lib.sco_sqp_destroy(h) == 0

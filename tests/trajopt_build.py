@@ -55,7 +55,29 @@ def build_prob(mods, pr, analytic_jac=False):
 
     R = pr["K"] * pr["O"]
     step_vars = []
-    for t in range(T):
+    prog = pr.get("row_program")
+    span = prog.span if prog is not None else 1
+    wide = prog is not None and (span > 1 or prog.n_eq > 0)
+    if wide:
+        # r03 program blocks: one Variable per block of `span` consecutive timesteps (the reference binds any Expr to any
+        # Variable, expr.py:413-437); the block's inequality rows are one LEqExpr, its equality rows one EqExpr with val 0
+        # (-> abs penalty, prob.py:280-315), both on that Variable, inequalities first
+        for t in range(T - span + 1):
+            sv = mods.Variable(atoms[t * d:(t + span) * d, :], pr["x0"][t * d:(t + span) * d].reshape(span * d, 1).copy())
+            step_vars.append(sv)
+            gids = pr["groups"][t] if pr.get("groups") is not None else None
+            for cls, rows in ((mods.LEqExpr, prog.ineq_rows), (mods.EqExpr, prog.eq_rows)):
+                if not rows:
+                    continue
+
+                def f(x, pr=pr, rows=rows):
+                    return pr["row_program"].evaluate(x.ravel(), pr["row_params"], rows).reshape(-1, 1)
+
+                def grad(x, pr=pr, rows=rows):
+                    return pr["row_program"].jacobian(x.ravel(), pr["row_params"], rows)
+                e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
+                prob.add_cnt_expr(mods.BoundExpr(cls(e, np.zeros((len(rows), 1))), sv), gids)
+    for t in range(0 if wide else T):
         sv = mods.Variable(atoms[t * d:(t + 1) * d, :], pr["x0"][t * d:(t + 1) * d].reshape(d, 1).copy())
         step_vars.append(sv)
 
@@ -72,6 +94,8 @@ def build_prob(mods, pr, analytic_jac=False):
         grad = None
         if analytic_jac:
             def grad(x, pr=pr):
+                if pr.get("row_program") is not None:       # forward-mode derivative of the compiled rows
+                    return pr["row_program"].jacobian(x.ravel(), pr["row_params"])
                 if pr.get("quad_Q") is not None:
                     return af.quad_rows_jac(x.ravel(), pr["quad_Q"], pr["quad_a"], pr["quad_c"])
                 if pr.get("point"):
@@ -81,6 +105,12 @@ def build_prob(mods, pr, analytic_jac=False):
         e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
         gids = pr["groups"][t] if pr.get("groups") is not None else None
         prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(e, np.zeros((R, 1))), sv), gids)
+    if prog is not None and prog.objective:
+        # the program family's objective term: one plain Expr per timestep Variable (prob.py:88-104), degree-2 convexified
+        for t in range(T):
+            def fo(x, pr=pr):
+                return np.array([[pr["row_program"].evaluate(x.ravel(), pr["row_params"], rows=[pr["row_program"].n_rows])[0]]])
+            prob.add_obj_expr(mods.BoundExpr(mods.Expr(fo), step_vars[t]))
     if pr.get("cost_weight") is not None:
         # non-quadratic objective terms, one Expr per timestep Variable: numeric gradient and Hessian, degree-2
         # convexification with the eigenvalue shift (expr.py:102-156; prob.py:88-104)
