@@ -336,6 +336,9 @@ __device__ __forceinline__ double prog_eval(const RowCtx &c, int o, const double
 // in this order of operations, are the ones sco_py_amd/rowexpr.py:Program.jacobian applies on the host (the `grad` a caller
 // hands to the reference's Expr, expr.py:86-100), so host and device agree to rounding
 __device__ __forceinline__ double prog_dual(const RowCtx &c, int o, const double *th, int j) {
+  // no fused multiply-adds here: the host applies the rules operation by operation (NumPy), and a derivative that differs in
+  // its last bit can move the iteration count of a slowly converging QP by many termination checks
+#pragma clang fp contract(off)
   double sv[SCO_PROGRAM_STACK], sd[SCO_PROGRAM_STACK];
   int sp = 0;
   for (int w = c.pptr[o];; w++) {

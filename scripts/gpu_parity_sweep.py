@@ -14,21 +14,27 @@ for tok in sys.argv[4:]:                                         # reach, vel, g
     if tok == "jl": KW["joint_limit"] = 0.2
     if tok == "point": KW.update(point=True, d=2, T=20, K=1, O=3)
     if tok == "quad": KW.update(quadratic=True, d=3, T=12, K=1, O=4)
+    if tok == "prog": KW.update(program=True, d=2, T=12, K=1)                     # corridor rows (r02 form)
+    if tok.startswith("prog:"):                                                    # prog:sweep | prog:dynamics | prog:curve | prog:attract
+        v = tok.split(":")[1]
+        KW.update(program=True, variant=v, d=3 if v in ("dynamics", "curve") else 2, T=10, K=1)
+    if tok == "ajac": AJ = True
+AJ = "ajac" in sys.argv[4:]
 
 
 def ref_one(i):
     params = sr.SolverParams(compound_penalty=False, duplicate_rows=False, max_qp_solves=20) if MODE == "intended" else None
-    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i, **KW)), params, emulate_memo=True)
+    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i, **KW), analytic_jac=AJ), params, emulate_memo=True)
     return i, out.trace, out.x, out.success
 
 if __name__ == "__main__":
     first, N = int(sys.argv[1]), int(sys.argv[2])
-    with ProcessPoolExecutor(32) as ex:                 # oracle on the host cores first (no GPU touched yet)
+    with ProcessPoolExecutor(int(os.environ.get("SWEEP_PROCS", "16"))) as ex:                 # oracle on the host cores first (no GPU touched yet)
         refs = list(ex.map(ref_one, range(first, first + N), chunksize=4))
     from sco_py_amd import batch as sb, _lib
     arrays, _ = af.make_batch(N, first=first, **KW)
     p = _lib.default_sqp_params(compound_penalty=0, duplicate_rows=0, max_sqp_iters=20) if MODE == "intended" else None
-    res = sb.solve_batch(arrays, params=p)
+    res = sb.solve_batch(arrays, params=p, analytic_jac=AJ)
     bad = 0; worst = 0.0
     for k, (i, tr, x, ok) in enumerate(refs):
         g = res.trace[k]
