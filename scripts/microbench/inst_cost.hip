@@ -26,7 +26,8 @@ __device__ __forceinline__ double quad1(double v) {
 
 // mode: 0 independent fma (10 chains x 10), 1 dependent fma chain (100), 2 fold32 x 20 (dependent pairs), 3 fold16 x 20,
 //       4 quad step x 20 (dependent), 5 barrier x 10, 6 LDS write -> barrier -> read (b64) x 10, 7 ds_read_b128 x 16 + wait,
-//       8 the r02 5-row reduction (fold32 x3, fold16 x2, quad x4), 9 dependent ds_read_b64 chain (pointer chase) x 20
+//       8 the r02 5-row reduction (fold32 x3, fold16 x2, quad x4), 9 dependent ds_read_b64 chain (pointer chase) x 20,
+//       10 the same reduction by v_mfma_f64_4x4x4, 11 / 12 a whole W phase (45 fma + reduction) with either reduction
 template <int MODE>
 __global__ __launch_bounds__(512) void k(double *out, long long *cyc, int reps) {
   __shared__ __attribute__((aligned(16))) double lds[4096];
@@ -82,6 +83,47 @@ __global__ __launch_bounds__(512) void k(double *out, long long *cyc, int reps) 
       t0_ += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4e, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, 0x4e, 0xf, 0xf, true));
       t1_ += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi1, 0x4e, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo1, 0x4e, 0xf, 0xf, true));
       a[0] = t0_; a[1] = t1_; a[2] += t0_; a[3] += t1_; a[4] += t0_;
+    } else if (MODE == 10) {
+      // the same 5-row reduction on the matrix pipe: v_mfma_f64_4x4x4 with B = 1 sums over lane >> 4 and hands the result
+      // to the lanes with lane >> 4 = (source lane & 3); applied twice it sums all 16 lanes of a block ((lane >> 2) & 3).
+      // Second application: each lane passes on the value whose index is its own lane & 3 -> 4 rows at once.
+      double d1[5];
+#pragma unroll
+      for (int v = 0; v < 5; v++) d1[v] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[v], 1.0, 0.0, 0, 0, 0);
+      const int pq = tid & 3;
+      const double sel = pq == 0 ? d1[0] : pq == 1 ? d1[1] : pq == 2 ? d1[2] : d1[3];
+      const double t0_ = __builtin_amdgcn_mfma_f64_4x4x4f64(sel, 1.0, 0.0, 0, 0, 0);
+      const double t1_ = __builtin_amdgcn_mfma_f64_4x4x4f64(d1[4], 1.0, 0.0, 0, 0, 0);
+      a[0] = t0_; a[1] = t1_; a[2] += t0_; a[3] += t1_; a[4] += t0_;
+    } else if (MODE == 11) {
+      // 45 independent multiply-adds (5 chains x 9) + the swap reduction: one W phase without its LDS reads
+      double acc[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+      for (int cc = 0; cc < 9; cc++)
+#pragma unroll
+        for (int rr = 0; rr < 5; rr++) acc[rr] = __builtin_fma(a[(rr + cc) % 10], x + cc, acc[rr]);
+      const double u0 = fold32(acc[0], acc[1]), u1 = fold32(acc[2], acc[3]), u2_ = fold32(acc[4], 0.0);
+      double t0_ = fold16(u0, u1), t1_ = fold16(u2_, 0.0);
+      t0_ = quad1(t0_); t1_ = quad1(t1_);
+      const int lo = __double2loint(t0_), hi = __double2hiint(t0_), lo1 = __double2loint(t1_), hi1 = __double2hiint(t1_);
+      t0_ += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4e, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, 0x4e, 0xf, 0xf, true));
+      t1_ += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi1, 0x4e, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo1, 0x4e, 0xf, 0xf, true));
+      a[0] = t0_ * 1e-3 + 1.0; a[1] = t1_ * 1e-3 + 1.0;
+    } else if (MODE == 12) {
+      // the same W phase with the reduction on the matrix pipe
+      double acc[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+      for (int cc = 0; cc < 9; cc++)
+#pragma unroll
+        for (int rr = 0; rr < 5; rr++) acc[rr] = __builtin_fma(a[(rr + cc) % 10], x + cc, acc[rr]);
+      double d1[5];
+#pragma unroll
+      for (int v = 0; v < 5; v++) d1[v] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[v], 1.0, 0.0, 0, 0, 0);
+      const int pq = tid & 3;
+      const double sel = pq == 0 ? d1[0] : pq == 1 ? d1[1] : pq == 2 ? d1[2] : d1[3];
+      const double t0_ = __builtin_amdgcn_mfma_f64_4x4x4f64(sel, 1.0, 0.0, 0, 0, 0);
+      const double t1_ = __builtin_amdgcn_mfma_f64_4x4x4f64(d1[4], 1.0, 0.0, 0, 0, 0);
+      a[0] = t0_ * 1e-3 + 1.0; a[1] = t1_ * 1e-3 + 1.0;
     } else if (MODE == 9) {
 #pragma unroll
       for (int j = 0; j < 20; j++) p = (unsigned int)*(const double *)((const char *)lds + p);
@@ -117,6 +159,9 @@ int main() {
     run<7>("16 ds_read_b128 + 16 adds", 16, threads);
     run<8>("5-row reduction of the W phase", 1, threads);
     run<9>("dependent ds_read_b64 (pointer chase)", 20, threads);
+    run<10>("5-row reduction by 7 v_mfma_f64_4x4x4", 1, threads);
+    run<11>("W phase: 45 fma + swap reduction", 1, threads);
+    run<12>("W phase: 45 fma + mfma reduction", 1, threads);
   }
   return 0;
 }
