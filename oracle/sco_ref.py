@@ -517,7 +517,18 @@ def trajopt_flat(prob, analytic_jac=False):
                 f = prog.numpy_fn(prob["row_params"], rows)
                 jac = prog.numpy_jac(prob["row_params"], rows) if analytic_jac else None
                 blocks.append(Block(kind, f, idx, np.zeros(len(rows)), jac=jac, groups=gids))
-    for t in range(T if not (prog is not None and (span > 1 or prog.n_eq > 0)) else 0):
+    if prob.get("quad_n_eq"):
+        # quadratic rows with equality rows (r03): the block's inequality rows are one LEqExpr, its last quad_n_eq rows one
+        # EqExpr (val 0) on the same timestep Variable
+        ne = int(prob["quad_n_eq"])
+        for t in range(T):
+            idx = np.arange(t * d, (t + 1) * d)
+            gids = prob["groups"][t] if prob.get("groups") is not None else None
+            for kind, sl in (("leq", slice(0, R - ne)), ("eq", slice(R - ne, R))):
+                f = (lambda th, pr=prob, sl=sl: af.quad_rows(th, pr["quad_Q"][sl], pr["quad_a"][sl], pr["quad_c"][sl]))
+                jac = (lambda th, pr=prob, sl=sl: af.quad_rows_jac(th, pr["quad_Q"][sl], pr["quad_a"][sl], pr["quad_c"][sl])) if analytic_jac else None
+                blocks.append(Block(kind, f, idx, np.zeros(len(range(R)[sl])), jac=jac, groups=gids))
+    for t in range(T if not ((prog is not None and (span > 1 or prog.n_eq > 0)) or prob.get("quad_n_eq")) else 0):
         if prob.get("row_program") is not None:  # SCO_FAM_STATE_PROGRAM: closed-form rows
             f = prob["row_program"].numpy_fn(prob["row_params"])
             jac = prob["row_program"].numpy_jac(prob["row_params"]) if analytic_jac else None

@@ -58,7 +58,7 @@ class TrajOptBatch(object):
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
                  prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False, point=False,
-                 quadratic=False, program=False):
+                 quadratic=False, program=False, n_eq_rows=0):
         self.B, self.d, self.T, self.K, self.O = int(batch), int(dof), int(horizon), int(n_points), int(n_obstacles)
         self.n_x = self.d * self.T
         self.device = int(device)
@@ -78,7 +78,10 @@ class TrajOptBatch(object):
         # the r02 form: one timestep per block, inequality rows only, no objective term
         prog = program if hasattr(program, "row_ptr") else None
         self.span = prog.span if prog is not None else 1
-        self.n_eq = prog.n_eq if prog is not None else 0
+        # equality rows: the program says so itself; the quadratic-row family takes n_eq_rows (the last rows of a timestep)
+        self.n_eq = prog.n_eq if prog is not None else (int(n_eq_rows) if self.quadratic else 0)
+        if n_eq_rows and not (self.quadratic or prog is not None):
+            raise ValueError("equality rows inside a block exist for the quadratic-row and program families")
         self.obj_program = bool(prog is not None and prog.objective)
         self.n_blocks = self.T - self.span + 1
         desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O,
@@ -240,7 +243,8 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
                       prox_count=prox_count, reach=bool(a.get("reach")), vel_limits=a.get("vmax") is not None,
                       joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
                       point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None,
-                      program=a.get("row_program") if a.get("row_program") is not None else False) as tb:
+                      program=a.get("row_program") if a.get("row_program") is not None else False,
+                      n_eq_rows=a.get("quad_n_eq", 0)) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                 target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
                 cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),

@@ -194,11 +194,13 @@ def make_point_problem(i, d=2, T=20, O=3, noise=0.03, groups=None, vel_limit=Non
     return out
 
 
-def make_quadratic_problem(i, d=2, T=20, O=3, noise=0.03, groups=None, vel_limit=None, joint_limit=None):
+def make_quadratic_problem(i, d=2, T=20, O=3, noise=0.03, groups=None, vel_limit=None, joint_limit=None, n_eq=0):
     """Seeded problem i of the quadratic-row family (SCO_FAM_STATE_QUADRATIC): a state x_t in R^d moves from start to goal;
     per timestep O rows 1/2 x' Q_r x + a_r' x + c_r <= 0: keep-OUT ellipsoids on the straight path (concave rows,
     1 - (x - m)' M (x - m) <= 0), for O >= 3 the last row a keep-IN ball around the path's midpoint (convex) and for O >= 4
-    the row before it a half-space.  Same dictionary layout as make_problem (K = 1; link data and obstacles are placeholders)."""
+    the row before it a half-space.  Same dictionary layout as make_problem (K = 1; link data and obstacles are placeholders).
+    ``n_eq`` = 1 (r03) appends an EQUALITY row: the state stays on a sphere through start and goal, |x - m|^2 = rad^2 (an
+    EqExpr on a quadratic Expr -> abs penalty, prob.py:280-315); the dictionary then has O + 1 rows and quad_n_eq = 1."""
     rng = np.random.default_rng(7000 + i)
     start = rng.uniform(-1.0, 1.0, size=d)
     goal = -start + 0.3 * rng.standard_normal(d)
@@ -220,9 +222,19 @@ def make_quadratic_problem(i, d=2, T=20, O=3, noise=0.03, groups=None, vel_limit
     if O >= 3:                                                          # keep-in ball |x - mid|^2 <= rad^2
         mid = 0.5 * (start + goal); rad = 0.75 * np.linalg.norm(goal - start) + 0.4
         Q[O - 1] = 2.0 * np.eye(d); a[O - 1] = -2.0 * mid; c[O - 1] = mid @ mid - rad ** 2
+    if n_eq:
+        assert n_eq == 1 and d >= 2
+        chord = goal - start
+        perp = rng.standard_normal(d); perp -= (perp @ chord) / (chord @ chord) * chord; perp /= np.linalg.norm(perp)
+        m = 0.5 * (start + goal) + rng.uniform(0.8, 1.5) * np.linalg.norm(chord) * perp       # on the bisector: |start - m| = |goal - m|
+        rad2 = float((start - m) @ (start - m))
+        Q = np.concatenate([Q, 2.0 * np.eye(d)[None]]); a = np.vstack([a, -2.0 * m]); c = np.append(c, m @ m - rad2)
+        O = O + 1
     out = dict(d=d, T=T, K=1, O=O, x0=x0.ravel(), start=start, goal=goal, link_len=np.ones(d),
                point_link=np.zeros(1, dtype=np.int32), point_frac=np.ones(1), obstacles=np.zeros((O, 3)), reach=False,
                quad_Q=Q, quad_a=a, quad_c=c)
+    if n_eq:
+        out["quad_n_eq"] = int(n_eq)
     if groups is not None:
         out["groups"] = block_groups(T, False, groups)
     if vel_limit is not None:
@@ -410,14 +422,14 @@ def make_program_variant(i, variant, d=2, T=12, noise=0.03, groups=None, vel_lim
 
 
 def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None,
-                 ee_cost_weight=None, point=False, quadratic=False, program=False, variant=None):
+                 ee_cost_weight=None, point=False, quadratic=False, program=False, variant=None, n_eq=0):
     """Seeded problem i of the batch.  reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
     if program:
         return make_program_problem(i, d=d, T=T, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit, variant=variant)
     if quadratic:
-        return make_quadratic_problem(i, d=d, T=T, O=O, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
+        return make_quadratic_problem(i, d=d, T=T, O=O, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit, n_eq=n_eq)
     if point:
         return make_point_problem(i, d=d, T=T, O=O, groups=groups, vel_limit=vel_limit, joint_limit=joint_limit)
     is_reach = bool(reach)
@@ -469,6 +481,8 @@ def make_batch(B, first=0, **kw):
     if p0.get("quad_Q") is not None:
         extra["quad_Q"] = np.stack([p["quad_Q"] for p in probs]); extra["quad_a"] = np.stack([p["quad_a"] for p in probs])
         extra["quad_c"] = np.stack([p["quad_c"] for p in probs])
+        if p0.get("quad_n_eq"):
+            extra["quad_n_eq"] = p0["quad_n_eq"]
     if p0.get("groups") is not None:
         extra["groups"] = p0["groups"]
     if p0.get("vmax") is not None:

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden as mg                      # noqa: E402
 from oracle import arm_family as af           # noqa: E402
-from quad_cases import CASES                 # noqa: E402
+from quad_cases import CASES, CASES2         # noqa: E402
 
 
 def main():
@@ -23,6 +23,11 @@ def main():
         mg.pack(prefix, mg.run_trajopt(mods, af.make_problem(i, **kw)), out)
     np.savez_compressed(os.path.join(HERE, "trajopt_quad.npz"), **out)
     print("trajopt_quad.npz", os.path.getsize(os.path.join(HERE, "trajopt_quad.npz")), "bytes")
+    out = {}                                  # r03: an equality row per timestep (EqExpr on a quadratic Expr)
+    for prefix, kw, i, aj in CASES2:
+        mg.pack(prefix, mg.run_trajopt(mods, af.make_problem(i, **kw), analytic_jac=aj), out)
+    np.savez_compressed(os.path.join(HERE, "trajopt_quad2.npz"), **out)
+    print("trajopt_quad2.npz", os.path.getsize(os.path.join(HERE, "trajopt_quad2.npz")), "bytes")
 
 
 if __name__ == "__main__":

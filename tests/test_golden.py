@@ -560,3 +560,24 @@ def test_mirror_api_reproduces_reference_for_wide_program_blocks(oracle_qp_backe
         assert [a["status"] for a in gold] == [r["status"] for r in oracle_qp_backend]
         assert ok == bool(g[prefix + "success"])
         assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 2e-7
+
+
+def _quad2_cases():
+    import sys
+    sys.path.insert(0, GOLD)
+    from quad_cases import CASES2
+    return CASES2
+
+
+@pytest.mark.parametrize("case", _quad2_cases(), ids=lambda c: c[0])
+def test_flat_oracle_reproduces_reference_for_quadratic_rows_with_an_equality(case):
+    """SCO_FAM_STATE_QUADRATIC with n_eq_rows = 1 (r03): per timestep an EqExpr on a quadratic Expr -- the state stays on a
+    sphere through start and goal -- lowered to the abs penalty (prob.py:280-315); runs of the reference's own modules."""
+    prefix, kw, i, aj = case
+    g = np.load(os.path.join(GOLD, "trajopt_quad2.npz"))
+    pr = af.make_problem(i, **kw)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr, analytic_jac=aj), record_qps=True)
+    _compare_sequence(ct.load_golden_qps(g, prefix), out.qps, prefix, xtol=1e-7, qptol=1e-7)
+    assert out.success == bool(g[prefix + "success"])
+    assert np.abs(out.x - g[prefix + "x"]).max() < 2e-7
+    assert abs(out.max_violation - float(g[prefix + "max_violation"])) < 1e-7

@@ -1051,3 +1051,25 @@ def test_wide_program_blocks_above_the_cu_count_and_descriptor_rules(gpu):
     desc = _lib.TrajoptDesc(1, 3, 6, 1, 2, sb.SCO_FAM_STATE_QUADRATIC, 0, 2, 1, 1)
     assert lib.sco_sqp_create(0, C.byref(desc), C.byref(h)) == 0
     assert lib.sco_sqp_destroy(h) == 0
+
+
+def test_quadratic_rows_with_an_equality_row(gpu):
+    """SCO_FAM_STATE_QUADRATIC with n_eq_rows = 1 (r03): the last row of every timestep is an EQUALITY (the state stays on a
+    sphere through start and goal; EqExpr on a quadratic Expr -> abs penalty with two slacks per row,
+    /root/reference/sco_py/sco_osqp/prob.py:280-315) -- against the oracle decision for decision (numeric and analytic
+    Jacobians) and against runs of the reference's own modules (tests/golden/trajopt_quad2.npz)."""
+    for kw, aj in ((dict(d=2, T=8, K=1, O=3), False), (dict(d=3, T=6, K=1, O=4), True), (dict(d=2, T=8, K=1, O=3, groups="split"), False)):
+        arrays, probs = af.make_batch(6, quadratic=True, n_eq=1, **kw)
+        res = sb.solve_batch(arrays, analytic_jac=aj)
+        _compare(res, probs, range(6), analytic=aj)
+    import sys
+    sys.path.insert(0, GOLD)
+    from quad_cases import CASES2
+    g = np.load(os.path.join(GOLD, "trajopt_quad2.npz"))
+    for prefix, kw, i, aj in CASES2:
+        arrays, _ = af.make_batch(1, first=i, **kw)
+        res = sb.solve_batch(arrays, analytic_jac=aj)
+        assert np.abs(res.x[0] - g[prefix + "x"]).max() < TOL, prefix
+        assert bool(res.success[0]) == bool(g[prefix + "success"]), prefix
+        nq = int(g[prefix + "n_qp"])
+        assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix

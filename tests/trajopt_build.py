@@ -77,6 +77,22 @@ def build_prob(mods, pr, analytic_jac=False):
                     return pr["row_program"].jacobian(x.ravel(), pr["row_params"], rows)
                 e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
                 prob.add_cnt_expr(mods.BoundExpr(cls(e, np.zeros((len(rows), 1))), sv), gids)
+    if pr.get("quad_n_eq"):
+        # quadratic rows with equality rows (r03): per timestep one LEqExpr and one EqExpr (val 0) on the same Variable
+        ne = int(pr["quad_n_eq"])
+        for t in range(T):
+            sv = mods.Variable(atoms[t * d:(t + 1) * d, :], pr["x0"][t * d:(t + 1) * d].reshape(d, 1).copy())
+            step_vars.append(sv)
+            gids = pr["groups"][t] if pr.get("groups") is not None else None
+            for cls, sl in ((mods.LEqExpr, slice(0, R - ne)), (mods.EqExpr, slice(R - ne, R))):
+                def f(x, pr=pr, sl=sl):
+                    return af.quad_rows(x.ravel(), pr["quad_Q"][sl], pr["quad_a"][sl], pr["quad_c"][sl]).reshape(-1, 1)
+
+                def grad(x, pr=pr, sl=sl):
+                    return af.quad_rows_jac(x.ravel(), pr["quad_Q"][sl], pr["quad_a"][sl], pr["quad_c"][sl])
+                e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
+                prob.add_cnt_expr(mods.BoundExpr(cls(e, np.zeros((len(range(R)[sl]), 1))), sv), gids)
+        wide = True
     for t in range(0 if wide else T):
         sv = mods.Variable(atoms[t * d:(t + 1) * d, :], pr["x0"][t * d:(t + 1) * d].reshape(d, 1).copy())
         step_vars.append(sv)
