@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--workload", choices=["7x20", "12x50"], default="7x20",
                     help="7x20 = BASELINE configs[2] (headline); 12x50 = configs[4] shape (structured global-memory tier)")
     ap.add_argument("--cpu-problems", type=int, default=16, help="size of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--aux-12x50", type=int, default=1024,
+    ap.add_argument("--aux-12x50", type=int, default=2048,
                     help="batch of the 12-DOF x 50 line reported under aux in a default 7x20 run (0 = skip)")
     ap.add_argument("--aux-b4096", type=int, default=1, help="also report a 4096-problem 7x20 step under aux (0 = skip)")
     ap.add_argument("--intended", action="store_true",
