@@ -226,6 +226,10 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
   rh.lay8 = !rh.aligned && ns_min == 2 && l8 && l8[0] == '1' && pl.n_c > 128 && pl.n_c <= 8 * AL_TC;
   rh.merged = rh.aligned ||
               (ns_min == 2 && closed && closed[0] == '1' && rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim));
+  {
+    const char *sp = getenv("SCO_QP_RL_SPLIT");
+    rh.split = !rh.merged && 2 * pl.n_c <= LT && !(sp && sp[0] == '0');
+  }
   if (!rh.merged) {
     // two row slots per thread; a pattern with more rows than that (velocity + joint limits at 7-DOF x 20: 1100) takes
     // the three-slot instantiation.  The rows of an eliminated variable (<= 2) always sit in slots 0 and 1 of its thread.
@@ -236,7 +240,10 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
         thr_elim[e] = e;
         for (size_t q = 0; q < erows[e].size(); q++) slot_row[q * LT + e] = erows[e][q];
       }
-      for (int c = 0; c < pl.n_c; c++) thr_core[LT - 1 - c] = c;   // far from the eliminated-variable threads
+      // far from the eliminated-variable threads.  Split form (r03): the entries of a core column go to TWO neighbouring
+      // lanes (owner = even lane, helper = odd lane: half of the operand pairs each), their partial sums meet in one
+      // quad_perm step -- phase (1) reads half as many operands per lane and runs on twice as many wavefronts
+      for (int c = 0; c < pl.n_c; c++) thr_core[rh.split ? LT - 2 - 2 * c : LT - 1 - c] = c;
       int cur = 0;
       std::vector<int> order;                        // free slots: threads without an eliminated variable first
       for (int q = 0; q < ns; q++) for (int t = pl.n_e; t < LT; t++) order.push_back(q * LT + t);
@@ -325,6 +332,11 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
       std::vector<std::pair<int, int>> ent;
       for (int p = pl.Ap[j]; p < pl.Ap[j + 1]; p++) ent.push_back({pos[pl.Ai[p]], p});
       colp[t] = make_pairs(ent);
+      if (rh.split) {                                    // the second half of the pairs: the helper lane t + 1
+        const size_t keep = (colp[t].size() + 1) / 2;
+        colp[t + 1].assign(colp[t].begin() + keep, colp[t].end());
+        colp[t].resize(keep);
+      }
       maxc = std::max(maxc, colp[t].size());
     }
     for (int q = 0; q < NSv; q++) {
@@ -402,8 +414,8 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
     if (c >= 0) {
       const int j = pl.core_var[c];
       rh.role[t] = c; rh.role[(size_t)LT + t] = j; rh.role[(size_t)11 * LT + t] = pl.Pdiag[j];
-      for (size_t k = 0; k < colp[t].size(); k++) rh.off[k * LT + t] = (unsigned short)(16 * colp[t][k].p);
     }
+    for (size_t k = 0; k < colp[t].size(); k++) rh.off[k * LT + t] = (unsigned short)(16 * colp[t][k].p);   // owner or helper
     const int e = thr_elim[t];
     if (e >= 0) {
       rh.role[(size_t)2 * LT + t] = e; rh.role[(size_t)3 * LT + t] = pl.elim_var[e];
@@ -492,6 +504,7 @@ struct RlArgs {
   int *status, *iters;
   int warm;          // start from the previous (unscaled) solution held in x / y instead of zero
   int merged;        // closed thread assignment (rl_assign_closed): no barrier between phases (Y) and (1)
+  int colsplit;      // a core column's entries sit in two neighbouring lanes: their partial sums are added across the lane pair
   // time slicing (slice > 0): at most `slice` iterations per launch; an unfinished solve leaves status 0,
   // its iteration count in prog[b] and its scaled state in the s* arrays, and the next launch resumes it
   // bit-exactly (nothing is recomputed)
@@ -669,6 +682,7 @@ template <int CW>
 __device__ __forceinline__ double rl_dot_col(int w, const double *V, unsigned int *o, const double *vec) {
   if (w <= 0) return 0.0;
   if (w <= 4) return rl_dot<4>(V, o, vec);
+  if (w <= 6) return rl_dot<6>(V, o, vec);          // half of a 6-pair column (split form)
   if (w <= 8) return rl_dot<8>(V, o, vec);
   if constexpr (CW > 12) { if (w <= 12) return rl_dot<12>(V, o, vec); }
   if constexpr (CW > 16) { if (w <= 16) return rl_dot<16>(V, o, vec); }
@@ -742,6 +756,12 @@ __device__ __forceinline__ double rl_fold16(double a, double b) {
   const rl_uint2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
   const rl_uint2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
   return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+// both lanes of a pair (lane ^ 1) end up with the pair's sum
+__device__ __forceinline__ double rl_pair_sum(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return v + __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xb1, 0xf, 0xf, true),     // quad_perm [1,0,3,2]
+                              __builtin_amdgcn_update_dpp(0, lo, 0xb1, 0xf, 0xf, true));
 }
 // all four lanes of a quad end up with the quad's sum
 __device__ __forceinline__ double rl_quad_sum(double v) {
@@ -946,6 +966,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   const double cinv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(cinv_v)), __builtin_amdgcn_readfirstlane(__double2loint(cinv_v)));
   const double alpha = a.alpha, sigma = a.sigma;
   const bool merged = AL || a.merged != 0;
+  const bool colsplit = a.colsplit != 0;
   const int it0 = a.slice > 0 ? a.prog[b] : 0;
   if (it0 > 0) {
     // resume an unfinished solve: every loop-carried value comes back from memory
@@ -1030,7 +1051,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     STAMP(6)
     // (1) core right-hand side
     {
-      const double dv = (RL_ABLATE & 1) ? 0.0 : (RL_VARIANT & 128) ? rl_dot_col_pre<CW>(wcol, pcol, co, s_tv) : rl_dot_col<CW>(wcol, vcol, co, s_tv);
+      double dv = (RL_ABLATE & 1) ? 0.0 : (RL_VARIANT & 128) ? rl_dot_col_pre<CW>(wcol, pcol, co, s_tv) : rl_dot_col<CW>(wcol, vcol, co, s_tv);
+      if (colsplit) dv = rl_pair_sum(dv);
       if (cown >= 0) rvw[k * RVS] = (sigma * xcv - qc) + dv;
     }
     STAMP(0)
@@ -1199,7 +1221,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
             w4[6] += r_w[q] * (r_us[q] * fmax(dy, 0.0) + r_ls[q] * fmin(dy, 0.0));
           }
         }
-        const double aty_c = rl_dot_col<CW>(wcol, vcol, co, swy);     // whole wave: the trip count is wave-uniform
+        double aty_c = rl_dot_col<CW>(wcol, vcol, co, swy);     // whole wave: the trip count is wave-uniform
+        if (colsplit) { const double both = rl_pair_sum(aty_c); aty_c = cown >= 0 ? both : 0.0; }   // a helper lane owns no column
         CSTAMP(1)
         {
           const int cix = cown >= 0 ? cown : n_c;        // the table's zero column
@@ -1251,7 +1274,8 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               __syncthreads();
               double nat[1] = {0.0};
               {
-                const double dv = rl_dot_col<CW>(wcol, vcol, co, swy);
+                double dv = rl_dot_col<CW>(wcol, vcol, co, swy);
+                if (colsplit) dv = rl_pair_sum(dv);
                 if (cown >= 0) nat[0] = fabs(dv / Dg[RL_CVAR]);
               }
               if (eown >= 0) nat[0] = fmax(nat[0], fabs((r_ae[0] * (r_w[0] * dyp[0]) + r_ae[1] * (r_w[1] * dyp[1])) / Dg[RL_EVAR]));
@@ -1425,7 +1449,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.As = d.As; ra.W = d.W; ra.qs = d.qs; ra.kee_inv = d.kee_inv; ra.ls = d.ls; ra.us = d.us; ra.rho = d.rho;
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
-  ra.warm = a.warm; ra.merged = rh.merged ? 1 : 0;
+  ra.warm = a.warm; ra.merged = rh.merged ? 1 : 0; ra.colsplit = rh.split ? 1 : 0;
   ra.slice = a.slice; ra.prog = d.prog;
   ra.ad_interval = a.adaptive ? a.ad_interval : 0; ra.ad_tol = a.ad_tol;
   ra.rho_b = d.rho_b; ra.rflag = d.rflag; ra.smask = d.smask; ra.nupd = d.nupd; ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.st = d.st; ra.sg = d.sg;

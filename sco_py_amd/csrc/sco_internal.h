@@ -129,6 +129,7 @@ struct RlHost {
   bool merged = false;             // closed thread assignment: phases (Y) and (1) share a wavefront, one barrier less per iteration
   bool aligned = false;            // closed assignment + the W rows of a wavefront's core columns in that wavefront: phases
                                    // (3), (Y), (1) are wavefront-local, ONE barrier per iteration (double-buffered right-hand side)
+  bool split = false;              // a core column's entries in two neighbouring lanes (owner + helper), phase (1) on twice the lanes
   bool lay8 = false;               // 8 column groups of the W tile (3 x 18) with the open assignment
   int NS = 2;                      // row slots per thread (3: patterns with more than 1024 rows)
   SellHost Ac, Ar[3];
