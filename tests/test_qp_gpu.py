@@ -554,3 +554,19 @@ def test_opt_in_layouts_of_the_row_local_kernel_give_the_same_answer(gpu, monkey
     assert lib.sco_debug_plan_build(n, m, ip(Pp), ip(Pi), ip(Ap), ip(Ai), 1, ip(sizes)) == 0
     assert lib.sco_debug_rl_plan(ip(info)) == 0
     assert info[0] == 1 and info[6] == (1 if switch.endswith("ALIGNED") else 2) and info[2] == 3 and info[3] == 18
+
+
+def test_split_and_unsplit_column_plans_give_the_same_answer(gpu, monkeypatch):
+    """r03 default: a core column's operand pairs sit in two neighbouring lanes (owner + helper) and their partial sums are
+    joined by one quad_perm step -- phase (1) and the test's A'y read half as many operands per lane.  SCO_QP_RL_SPLIT=0 keeps
+    one lane per column (the r02 plan): same status and iteration count, solutions to 1e-10 (another order of the column sums),
+    for the 7x20 shape, a wide pattern (8 pairs per column) and small shapes; both agree with the oracle."""
+    rng = np.random.default_rng(29)
+    for probs in ([penalty_qp(rng, 20, 7, 10) for _ in range(3)], [penalty_qp(rng, 5, 3, 4) for _ in range(2)],
+                  [penalty_qp(rng, 12, 4, 14) for _ in range(2)]):
+        monkeypatch.delenv("SCO_QP_RL_SPLIT", raising=False)
+        base = _check(probs)
+        monkeypatch.setenv("SCO_QP_RL_SPLIT", "0")
+        alt = _check(probs)
+        assert np.array_equal(base[2], alt[2]) and np.array_equal(base[3], alt[3])
+        assert np.abs(base[1] - alt[1]).max() < 1e-10
