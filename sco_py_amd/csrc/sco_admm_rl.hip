@@ -354,7 +354,9 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
   }
   if (maxc > (NSv > 2 ? LCW_MAX3 : LCW_MAX) / 2) return false;
   if (maxc > LCW / 2 || maxr > LRW / 2) rh.CW = LCW_MAX;      // the wide instantiation: 8 pairs per column, 5 per row
-  if (NSv > 2) rh.CW = LCW_MAX3;                              // three row slots: 10 pairs per column, 5 per row
+  // three row slots: 10 pairs per column thread, 5 per row -- unless the split plan leaves every column thread <= 6 pairs and
+  // every row <= 4 (velocity + joint limits at 7-DOF x 20: 5 + 5 pairs): then the narrow offsets do, with far fewer registers
+  if (NSv > 2) rh.CW = (maxc <= LCW / 2 && maxr <= LRW / 2) ? LCW : LCW_MAX3;
   // ---- sliced-ELL images in thread order: two value slots per pair
   // Open assignment: item = thread.  Closed assignments spread every kind of work over all wavefronts (a wavefront holds
   // ~21 of the 140 columns), so an image with one item per THREAD would be 8 full slices per operator and overflow LDS:
@@ -905,8 +907,10 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
       r_ls[q] = a.ls[(size_t)b * m + i]; r_us[q] = a.us[(size_t)b * m + i];
       r_rho[q] = a.rho[(size_t)b * m + i]; r_rinv[q] = 1.0 / r_rho[q];
       r_w[q] = (double)a.w[(size_t)b * m + i];
-      const int ep = a.role[(size_t)ROLE_EPOS(q) * LT + tid];
-      if (ep >= 0) r_ae[q] = gAs[ep];
+      // (a third slot never holds a row of an eliminated variable -- rl_plan_build -- so its a_e is the constant 0 and the
+      // compiler drops the register and the terms that carry it)
+      const int ep = q < 2 ? a.role[(size_t)ROLE_EPOS(q) * LT + tid] : -1;
+      if (q < 2 && ep >= 0) r_ae[q] = gAs[ep];
     }
   }
   // which row slots this wavefront uses at all, and whether it owns an eliminated variable (wave-uniform)
@@ -1474,6 +1478,8 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   }
   if (rh.NS == 3) {
     // three row slots per thread and ten operand pairs per column (velocity + joint limits at 7-DOF x 20: 1100 rows)
+    if (rh.CW == LCW && rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW, 3>(ra, nwg, rh.lds_bytes, st);
+    if (rh.CW == LCW && rh.TR == 5 && rh.TC == 10) return rl_launch_one<5, 10, LCW, 3>(ra, nwg, rh.lds_bytes, st);
     if (rh.TR == 5 && rh.TC == 9) return rl_launch_one<5, 9, LCW_MAX3, 3>(ra, nwg, rh.lds_bytes, st);
     if (rh.TR == 5 && rh.TC == 10) return rl_launch_one<5, 10, LCW_MAX3, 3>(ra, nwg, rh.lds_bytes, st);
     sco_set_error("rl_launch: unsupported tile");

@@ -112,15 +112,16 @@ def test_malformed_patterns_are_rejected():
     ("circles", {}, 12), ("objective terms", dict(ee_cost_weight=1.0), 12),
     ("reach", dict(reach=True), 16), ("velocity limits", dict(vel_limit=0.3), 12),
     ("joint limits", dict(joint_limit=0.2), 12),
-    ("velocity + joint limits", dict(vel_limit=0.3, joint_limit=0.2), 20),
+    ("velocity + joint limits", dict(vel_limit=0.3, joint_limit=0.2), 12),
     ("reach + velocity limits", dict(reach=True, vel_limit=0.3), 16)])
 def test_which_device_families_land_on_the_row_local_tier(name, kw, cw):
     """Host-side plan of the fastest ADMM tier (csrc/sco_admm_rl.hip: rl_plan_build) for the penalty QP of every device
     family at 7-DOF x 20: gather-dots take operands in aligned pairs; CW = 12: a column thread <= 6 pairs, a row <= 4, two
     row slots per thread; 16 (wide): 8 / 5; 20: the three-slot instantiation (10 / 5, up to 1536 rows) that velocity + joint
-    limits (1100 rows) needs.  r03: a column's pairs are split over two neighbouring lanes (owner + helper), so the 8 pairs
+    limits (1100 rows) needed until r03.  r03: a column's pairs are split over two neighbouring lanes (owner + helper), so the 8 pairs
     of a column with velocity or joint limits are 4 + 4 and fit the default instantiation; reach keeps the wide one for its
-    5-pair rows, and reach + velocity limits (9 pairs in a last-timestep column: 5 + 4) no longer needs three row slots."""
+    5-pair rows, reach + velocity limits (9 pairs in a last-timestep column: 5 + 4) no longer needs three row slots, and
+    velocity + joint limits (1100 rows: three row slots) runs the three-slot kernel with the narrow offsets (5 + 5 pairs)."""
     fits = True
     from oracle import arm_family as af
     from oracle import sco_ref as sr
