@@ -199,7 +199,8 @@ void sco_sqp_default_params(sco_sqp_params *p);
                                   g[r](x) = 1/2 x' Q_r x + a_r' x + c_r <= 0 per timestep with per-problem coefficients
                                   (sco_sqp_load_quadratic), Q_r symmetric and of either sign -- keep-out ellipses, keep-in
                                   discs, half-planes, products of coordinates ...; dof <= 16, n_points must be 1; link_len /
-                                  point_* / obstacles of sco_sqp_load are not read.  Flags as for SCO_FAM_POINT_CIRCLES */
+                                  point_* / obstacles of sco_sqp_load are not read.  The last n_eq_rows rows may be equalities
+                                  (EqExpr -> abs penalty, prob.py:280-315).  Flags as for SCO_FAM_POINT_CIRCLES */
 #define SCO_FAM_STATE_PROGRAM 5 /* closed-form rows given as small postfix programs over the state of a constraint block and a
                                   per-problem parameter vector (sco_sqp_load_program) -- what the reference's Expr(f) is for
                                   any f one can write down with + - * / sin cos sqrt exp.  A block is `span` (1 or 2)
@@ -292,11 +293,15 @@ int sco_sqp_load(sco_sqp *h, const double *x0, const double *start, const double
  * timestep must reach (`goal` of sco_sqp_load is then unused and may repeat `start`). */
 int sco_sqp_load_target(sco_sqp *h, const double *target);
 /* SCO_FAM_STATE_QUADRATIC only, after sco_sqp_load: Q[batch][n_obstacles][dof*dof] (symmetric), a[batch][n_obstacles][dof],
- * c[batch][n_obstacles]. */
+ * c[batch][n_obstacles].  With n_eq_rows > 0 the last n_eq_rows rows of every timestep are equalities g = 0 (r03). */
 int sco_sqp_load_quadratic(sco_sqp *h, const double *Q, const double *a, const double *c);
 /* SCO_FAM_STATE_PROGRAM only, after sco_sqp_load: row r's program is words[2 * row_ptr[r] .. 2 * row_ptr[r+1]) as (op, arg)
- * pairs, the last one SCO_OP_END (row_ptr[n_obstacles] = n_words); consts[n_consts]; params[batch][n_params]
- * (n_params may be 0).  The programs are checked (stack depth, indices) before anything is uploaded. */
+ * pairs, the last one SCO_OP_END; consts[n_consts]; params[batch][n_params] (n_params may be 0).  There are R = n_obstacles
+ * programs (the rows of a block: inequalities first, then the n_eq_rows equalities; SCO_OP_X addresses the span * dof numbers
+ * of the block's state), with SCO_FAM_FLAG_OBJ_PROGRAM one more -- the objective term of a timestep, SCO_OP_X < dof --
+ * and row_ptr[R] (or row_ptr[R + 1]) = n_words.  row_ptr is checked as a whole (first entry 0, strictly increasing, last =
+ * n_words) before any word is read through it, then every program (stack depth, operand indices, one result) before anything
+ * is uploaded.  May be called again (new parameters per solve): the handle reuses its buffers. */
 int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts, const double *consts,
                          int n_params, const double *params);
 /* SCO_FAM_FLAG_VEL_LIMITS only, after sco_sqp_load: vmax[batch] > 0, one limit per problem. */
