@@ -41,7 +41,9 @@
 // 2 register pin on the packed offsets (the r01 form), 4 unpadded right-hand side, 8 eight iterations per loop trip,
 // 16 no termination test (the loop structure around it stays), 32 the checked iteration writes no test scratch,
 // 64 wave-uniform row-slot masks in phase (Y) (r03: slower, 0.955 against 0.933 us), 128 values of the gather-dots read
-// before the barrier in front of their phase
+// before the barrier in front of their phase, 512 the guard around the eliminated variable's update put back, 4096 the guard
+// around the t' store put back (r03 removed both: profiles/r03_ab.txt section 7; tried there and dropped: gather-dot dispatch
+// widest first -- slower --, no barrier behind the termination test and unguarded stores of the W totals -- no change)
 #ifndef RL_VARIANT
 #define RL_VARIANT 0
 #endif
@@ -306,7 +308,7 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
     rh.zpos = npos;
     npos += 2;
     for (int i = 0; i < m; i++) if (ncore[i] == 0) pos[i] = npos++;    // written, never gathered (no predicate in the loop)
-    if (npos > LCAP_M) return false;
+    if (npos > LCAP_M - 1) return false;                 // position LCAP_M - 1 takes the stores of empty row slots
   }
   const int zcore = (pl.n_c + 1) & ~1;                 // always-zero pair of the core vectors
   if (zcore + 2 > LCAP_NC) return false;
@@ -1133,7 +1135,10 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           r_y[q] += dyq[q]; r_z[q] = zn;
           tq[q] = r_w[q] * (r_rho[q] * zn - r_y[q]);
         }
-        if (eown >= 0) {
+        // No guard (r03; RL_VARIANT & 512 puts `if (eown >= 0)` back): a thread without an eliminated variable has
+        // x_e = q_e = 1 / K_ee = a_e = 0, so every line below leaves exact zeros -- and the loop loses two selects and an
+        // exec-mask region (1.045 -> 1.027 us per iteration, profiles/r03_ab.txt section 7)
+        if (!(RL_VARIANT & 512) || eown >= 0) {
           const double xn = alpha * xte + (1.0 - alpha) * xe;
           if (chk) dxe = xn - xe;           // only the termination test reads the steps
           xe = xn;
@@ -1141,11 +1146,18 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
           ge = rhs_e * kinv;
         }
 #pragma unroll
-        for (int q = 0; q < NS; q++)
+        for (int q = 0; q < NS; q++) {
+          if constexpr ((RL_VARIANT & 4096) == 0) {
+            // no exec-mask region around the store of every iteration (r03): an empty slot writes its t' to position
+            // LCAP_M - 1, which no row owns (rl_plan_build) and nobody gathers: 1.027 -> 1.011 us per iteration
+            if ((msk >> q) & 1) s_tv[r_p[q] >= 0 ? r_p[q] : LCAP_M - 1] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
+            if (chk && ((msk >> q) & 1) && r_p[q] >= 0) { swy[r_p[q]] = r_w[q] * r_y[q]; sdy[r_p[q]] = dyq[q]; }
+          } else
           if (((msk >> q) & 1) && r_p[q] >= 0) {
             s_tv[r_p[q]] = tq[q] - (r_w[q] * r_rho[q]) * r_ae[q] * ge;
             if (chk) { swy[r_p[q]] = r_w[q] * r_y[q]; sdy[r_p[q]] = dyq[q]; }
           }
+        }
       };
       if (!(RL_VARIANT & 64)) rows(std::integral_constant<int, (1 << NS) - 1>());
       else if (NS == 2 && rmask == 1) rows(std::integral_constant<int, 1>());
