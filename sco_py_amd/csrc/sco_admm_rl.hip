@@ -216,8 +216,9 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
   // LDS instructions per wavefront and iteration, and an iteration costs what its instructions cost, not what its
   // barriers cost.
   const char *al = getenv("SCO_QP_RL_ALIGNED");
+  const bool want_closed = (al && al[0] == '1') || (closed && closed[0] == '1');     // SCO_QP_RL_CLOSED (r02) = the aligned form now
   std::vector<std::vector<int>> wave_cols;
-  rh.aligned = allow_aligned && ns_min == 2 && al && al[0] == '1' && pl.n_c > 128 && pl.n_c <= 8 * AL_TC &&
+  rh.aligned = allow_aligned && ns_min == 2 && want_closed && pl.n_c > 128 && pl.n_c <= 8 * AL_TC &&
                rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim, AL_ROWS, &wave_cols);
   // The 8-column-group W layout with the OPEN assignment (r03): the W phase costs 3 swap folds + one quad step per
   // wavefront instead of 5 + 4 (a lane-swap instruction costs ~12 cycles, a multiply-add 4.5: scripts/microbench/inst_cost.hip),
@@ -226,12 +227,12 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
   // instead of 5 reads of the right-hand side eat what the reduction saves.  Opt-in: SCO_QP_RL_LAY8=1.
   const char *l8 = getenv("SCO_QP_RL_LAY8");
   rh.lay8 = !rh.aligned && ns_min == 2 && l8 && l8[0] == '1' && pl.n_c > 128 && pl.n_c <= 8 * AL_TC;
-  rh.merged = rh.aligned ||
-              (ns_min == 2 && closed && closed[0] == '1' && rl_assign_closed(pl, row_elim, erows, slot_row, thr_core, thr_elim));
-  {
-    const char *sp = getenv("SCO_QP_RL_SPLIT");
-    rh.split = !rh.merged && 2 * pl.n_c <= LT && !(sp && sp[0] == '0');
-  }
+  rh.merged = rh.aligned;
+  // every open plan puts a core column on a lane pair (2 n_c <= 312 lanes: n_c <= LCAP_NC - 4); SCO_QP_RL_SPLIT=0 keeps
+  // all of a column's pairs on the owner and leaves the helper lane empty (the r02 distribution of the work)
+  const char *sp = getenv("SCO_QP_RL_SPLIT");
+  const bool split_pairs = !(sp && sp[0] == '0');
+  rh.split = !rh.merged;
   if (!rh.merged) {
     // two row slots per thread; a pattern with more rows than that (velocity + joint limits at 7-DOF x 20: 1100) takes
     // the three-slot instantiation.  The rows of an eliminated variable (<= 2) always sit in slots 0 and 1 of its thread.
@@ -334,7 +335,7 @@ static bool rl_plan_build_ns(const QpPlan &pl, RlHost &rh, const int ns_min, con
       std::vector<std::pair<int, int>> ent;
       for (int p = pl.Ap[j]; p < pl.Ap[j + 1]; p++) ent.push_back({pos[pl.Ai[p]], p});
       colp[t] = make_pairs(ent);
-      if (rh.split) {                                    // the second half of the pairs: the helper lane t + 1
+      if (rh.split && split_pairs) {                     // the second half of the pairs: the helper lane t + 1
         const size_t keep = (colp[t].size() + 1) / 2;
         colp[t + 1].assign(colp[t].begin() + keep, colp[t].end());
         colp[t].resize(keep);
@@ -507,8 +508,6 @@ struct RlArgs {
   double *x, *y, *resid;
   int *status, *iters;
   int warm;          // start from the previous (unscaled) solution held in x / y instead of zero
-  int merged;        // closed thread assignment (rl_assign_closed): no barrier between phases (Y) and (1)
-  int colsplit;      // a core column's entries sit in two neighbouring lanes: their partial sums are added across the lane pair
   // time slicing (slice > 0): at most `slice` iterations per launch; an unfinished solve leaves status 0,
   // its iteration count in prog[b] and its scaled state in the s* arrays, and the next launch resumes it
   // bit-exactly (nothing is recomputed)
@@ -695,6 +694,7 @@ __device__ __forceinline__ double rl_dot_col(int w, const double *V, unsigned in
 template <int RW>
 __device__ __forceinline__ double rl_dot_row_w(int w, const double *V, unsigned int *o, const double *vec) {
   if (w <= 0) return 0.0;
+  if constexpr ((RL_VARIANT & 65536) != 0) return rl_dot<RW>(V, o, vec);      // all or nothing: one branch, padded pairs read zeros
   if (w <= 2) return rl_dot<2>(V, o, vec);
   if (w <= 4) return rl_dot<4>(V, o, vec);
   if constexpr (RW > LRW) { if (w <= LRW) return rl_dot<LRW>(V, o, vec); }
@@ -971,8 +971,10 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   const double cinv_v = 1.0 / cscale;
   const double cinv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(cinv_v)), __builtin_amdgcn_readfirstlane(__double2loint(cinv_v)));
   const double alpha = a.alpha, sigma = a.sigma;
-  const bool merged = AL || a.merged != 0;
-  const bool colsplit = a.colsplit != 0;
+  // compile-time since r03 (a wave-uniform RUN-TIME test of either in the loop cost 2.2 % and 1.1 % of an iteration,
+  // profiles/r03_ab.txt section 8): only the aligned closed assignment drops barriers, and every other plan puts a core
+  // column on a lane PAIR (owner + helper; SCO_QP_RL_SPLIT=0 leaves the helper without entries)
+  constexpr bool merged = AL, colsplit = !AL;
   const int it0 = a.slice > 0 ? a.prog[b] : 0;
   if (it0 > 0) {
     // resume an unfinished solve: every loop-carried value comes back from memory
@@ -1465,7 +1467,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.As = d.As; ra.W = d.W; ra.qs = d.qs; ra.kee_inv = d.kee_inv; ra.ls = d.ls; ra.us = d.us; ra.rho = d.rho;
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
-  ra.warm = a.warm; ra.merged = rh.merged ? 1 : 0; ra.colsplit = rh.split ? 1 : 0;
+  ra.warm = a.warm;
   ra.slice = a.slice; ra.prog = d.prog;
   ra.ad_interval = a.adaptive ? a.ad_interval : 0; ra.ad_tol = a.ad_tol;
   ra.rho_b = d.rho_b; ra.rflag = d.rflag; ra.smask = d.smask; ra.nupd = d.nupd; ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.st = d.st; ra.sg = d.sg;
