@@ -680,9 +680,53 @@ __device__ __forceinline__ double rl_dot(const double *V, unsigned int *o, const
   return a0 + a1;
 }
 
+// The gather-dots of the loop, dispatched on the wave-uniform trip count with NESTED tiers (r03) --
+// `if (w > 0) { pairs of tier 0; if (w > t1) { ...; if (w > t2) { .. }}}`, once for the loads and once for the multiply-adds
+// (pair order as in rl_dot: the results are bit-identical).  The widest path -- the wavefronts on the critical path -- only
+// falls through branches that are not taken; the chain of `if (w <= t) return rl_dot<t>` it replaces left three TAKEN
+// branches behind every dot (0.973 -> 0.956 us per iteration, profiles/r03_ab.txt section 8;
+// RL_VARIANT & 131072 puts the chain back)
+#define RL_LD(h) { val[h] = *(const dbl2 *)(V + 128 * (h)); g[h] = *(const dbl2 *)((const char *)vec + (((h) & 1) ? (o[(h) / 2] >> 16) : (o[(h) / 2] & 0xffffu))); }
+#define RL_FM(h) { a0 += val[h].x * g[h].x; a1 += val[h].y * g[h].y; }
+template <int CW>
+__device__ __forceinline__ double rl_dot_col_nested(int w, const double *V, unsigned int *o, const double *vec) {
+  dbl2 val[CW / 2], g[CW / 2];
+  double a0 = 0.0, a1 = 0.0;
+  if (w > 0) { RL_LD(0) RL_LD(1)
+    if (w > 4) { RL_LD(2)
+      if (w > 6) { RL_LD(3)
+        if (w > 8) { RL_LD(4) RL_LD(5)
+          if constexpr (CW > 12) { if (w > 12) { RL_LD(6) RL_LD(7)
+            if constexpr (CW > 16) { if (w > 16) { RL_LD(8) RL_LD(9) } } } } } } } }
+  if (w > 0) { RL_FM(0) RL_FM(1)
+    if (w > 4) { RL_FM(2)
+      if (w > 6) { RL_FM(3)
+        if (w > 8) { RL_FM(4) RL_FM(5)
+          if constexpr (CW > 12) { if (w > 12) { RL_FM(6) RL_FM(7)
+            if constexpr (CW > 16) { if (w > 16) { RL_FM(8) RL_FM(9) } } } } } } } }
+  return a0 + a1;
+}
+template <int RW>
+__device__ __forceinline__ double rl_dot_row_nested(int w, const double *V, unsigned int *o, const double *vec) {
+  dbl2 val[RW / 2], g[RW / 2];
+  double a0 = 0.0, a1 = 0.0;
+  if (w > 0) { RL_LD(0)
+    if (w > 2) { RL_LD(1)
+      if (w > 4) { RL_LD(2) RL_LD(3)
+        if constexpr (RW > LRW) { if (w > LRW) { RL_LD(4) } } } } }
+  if (w > 0) { RL_FM(0)
+    if (w > 2) { RL_FM(1)
+      if (w > 4) { RL_FM(2) RL_FM(3)
+        if constexpr (RW > LRW) { if (w > LRW) { RL_FM(4) } } } } }
+  return a0 + a1;
+}
+#undef RL_LD
+#undef RL_FM
+
 // dispatch on the wave-uniform trip count so padded slots cost nothing
 template <int CW>
 __device__ __forceinline__ double rl_dot_col(int w, const double *V, unsigned int *o, const double *vec) {
+  if constexpr ((RL_VARIANT & 131072) == 0) return rl_dot_col_nested<CW>(w, V, o, vec);
   if (w <= 0) return 0.0;
   if (w <= 4) return rl_dot<4>(V, o, vec);
   if (w <= 6) return rl_dot<6>(V, o, vec);          // half of a 6-pair column (split form)
@@ -693,8 +737,8 @@ __device__ __forceinline__ double rl_dot_col(int w, const double *V, unsigned in
 }
 template <int RW>
 __device__ __forceinline__ double rl_dot_row_w(int w, const double *V, unsigned int *o, const double *vec) {
+  if constexpr ((RL_VARIANT & 131072) == 0) return rl_dot_row_nested<RW>(w, V, o, vec);
   if (w <= 0) return 0.0;
-  if constexpr ((RL_VARIANT & 65536) != 0) return rl_dot<RW>(V, o, vec);      // all or nothing: one branch, padded pairs read zeros
   if (w <= 2) return rl_dot<2>(V, o, vec);
   if (w <= 4) return rl_dot<4>(V, o, vec);
   if constexpr (RW > LRW) { if (w <= LRW) return rl_dot<LRW>(V, o, vec); }
