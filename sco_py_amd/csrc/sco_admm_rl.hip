@@ -724,9 +724,12 @@ __device__ __forceinline__ double rl_dot_row_nested(int w, const double *V, unsi
 #undef RL_FM
 
 // dispatch on the wave-uniform trip count so padded slots cost nothing
-template <int CW>
+// NEST: nested tiers (the two-row-slot kernels); the three-row-slot kernels keep the chain -- with every pair of a dot loaded
+// ahead of the multiply-adds they spill inside the loop (velocity + joint limits 1.39 -> 1.53, reach + velocity + joint limits
+// 1.91 -> 2.72 us per problem-iteration, profiles/r03_family_speed.txt)
+template <int CW, bool NEST = true>
 __device__ __forceinline__ double rl_dot_col(int w, const double *V, unsigned int *o, const double *vec) {
-  if constexpr ((RL_VARIANT & 131072) == 0) return rl_dot_col_nested<CW>(w, V, o, vec);
+  if constexpr (NEST && (RL_VARIANT & 131072) == 0) return rl_dot_col_nested<CW>(w, V, o, vec);
   if (w <= 0) return 0.0;
   if (w <= 4) return rl_dot<4>(V, o, vec);
   if (w <= 6) return rl_dot<6>(V, o, vec);          // half of a 6-pair column (split form)
@@ -735,9 +738,9 @@ __device__ __forceinline__ double rl_dot_col(int w, const double *V, unsigned in
   if constexpr (CW > 16) { if (w <= 16) return rl_dot<16>(V, o, vec); }
   return rl_dot<CW>(V, o, vec);
 }
-template <int RW>
+template <int RW, bool NEST = true>
 __device__ __forceinline__ double rl_dot_row_w(int w, const double *V, unsigned int *o, const double *vec) {
-  if constexpr ((RL_VARIANT & 131072) == 0) return rl_dot_row_nested<RW>(w, V, o, vec);
+  if constexpr (NEST && (RL_VARIANT & 131072) == 0) return rl_dot_row_nested<RW>(w, V, o, vec);
   if (w <= 0) return 0.0;
   if (w <= 2) return rl_dot<2>(V, o, vec);
   if (w <= 4) return rl_dot<4>(V, o, vec);
@@ -895,7 +898,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   constexpr int RW = CW > LCW ? LRW_MAX : LRW;     // value slots per row: the wide instantiation takes 5 operand pairs
   constexpr int RO = (RW / 2 + 1) / 2;
   unsigned int co[CW / 4], ro[NS][RO];             // pair offsets, two per register
-  auto rl_dot_row = [&](int w, const double *V, unsigned int *o, const double *vec) __attribute__((always_inline)) { return rl_dot_row_w<RW>(w, V, o, vec); };
+  auto rl_dot_row = [&](int w, const double *V, unsigned int *o, const double *vec) __attribute__((always_inline)) { return rl_dot_row_w<RW, NS == 2>(w, V, o, vec); };
 #pragma unroll
   for (int k = 0; k < CW / 4; k++) co[k] = pack(2 * k);
 #pragma unroll
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
     STAMP(6)
     // (1) core right-hand side
     {
-      double dv = (RL_ABLATE & 1) ? 0.0 : (RL_VARIANT & 128) ? rl_dot_col_pre<CW>(wcol, pcol, co, s_tv) : rl_dot_col<CW>(wcol, vcol, co, s_tv);
+      double dv = (RL_ABLATE & 1) ? 0.0 : (RL_VARIANT & 128) ? rl_dot_col_pre<CW>(wcol, pcol, co, s_tv) : rl_dot_col<CW, NS == 2>(wcol, vcol, co, s_tv);
       if (colsplit) dv = rl_pair_sum(dv);
       if (cown >= 0) rvw[k * RVS] = (sigma * xcv - qc) + dv;
     }
@@ -1283,7 +1286,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
             w4[6] += r_w[q] * (r_us[q] * fmax(dy, 0.0) + r_ls[q] * fmin(dy, 0.0));
           }
         }
-        double aty_c = rl_dot_col<CW>(wcol, vcol, co, swy);     // whole wave: the trip count is wave-uniform
+        double aty_c = rl_dot_col<CW, NS == 2>(wcol, vcol, co, swy);     // whole wave: the trip count is wave-uniform
         if (colsplit) { const double both = rl_pair_sum(aty_c); aty_c = cown >= 0 ? both : 0.0; }   // a helper lane owns no column
         CSTAMP(1)
         {
@@ -1336,7 +1339,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
               __syncthreads();
               double nat[1] = {0.0};
               {
-                double dv = rl_dot_col<CW>(wcol, vcol, co, swy);
+                double dv = rl_dot_col<CW, NS == 2>(wcol, vcol, co, swy);
                 if (colsplit) dv = rl_pair_sum(dv);
                 if (cown >= 0) nat[0] = fabs(dv / Dg[RL_CVAR]);
               }
