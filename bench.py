@@ -315,9 +315,7 @@ def main():
         qp_solves = steps * int(res.qp_solves.sum())
         tb.close()
         if world > 1:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if use_gloo else "cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+            elapsed = sd.max_over_ranks(elapsed)                  # device tensor under RCCL, host tensor under gloo
         return dict(dims=dims, B=B, total=total, steps=steps, elapsed=elapsed, sco_iters=sco_iters, admm_ms=admm_ms,
                     qp_launches=qp_launches, groups=groups, stage_ms=stage_ms / steps, it_proj=it_proj, it_pen=it_pen, qp_solves=qp_solves,
                     success=float(np.mean(allrec["success"] != 0)))

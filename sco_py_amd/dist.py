@@ -30,15 +30,34 @@ def pack_results(merit, max_violation, success, sqp_iters):
     return rec
 
 
-def gather_results(local, total, device=None):
+def collective_device():
+    """Where the tensors of this module's collectives live: the current HIP device under RCCL ("nccl"), host memory under gloo."""
+    import torch.distributed as dist
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
+def max_over_ranks(value):
+    """MAX of a float over the ranks (the clock of a timed region, bench.py); `value` itself without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=collective_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_results(local, total, device=None, force_collective=False):
     """All-gather the per-problem result records of every rank.
 
     local: structured array (RESULT_DTYPE) of this rank's shard; total: batch size
     over all ranks.  Returns the (total,) structured array on every rank.  With no
-    initialised process group (single process) it returns `local` unchanged."""
+    initialised process group (single process) it returns `local` unchanged; so it does in a
+    group of one rank unless `force_collective` asks for the collective all the same (a one-GPU
+    box runs the RCCL calls of the N > 1 path that way, tests/test_dist_gpu.py)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         assert len(local) == total
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -48,7 +67,7 @@ def gather_results(local, total, device=None):
     item = RESULT_DTYPE.itemsize
     buf = np.zeros(cap * item, dtype=np.uint8)
     buf[: len(local) * item] = np.frombuffer(local.tobytes(), dtype=np.uint8)
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    dev = device if device is not None else collective_device()
     send = torch.from_numpy(buf).to(dev)
     recv = torch.empty(world * cap * item, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send)

@@ -34,6 +34,7 @@ def _worker(rank, world, port, total, q):
     idx = np.arange(lo, hi)
     rec = sd.pack_results(idx * 1.5, idx * 0.25, idx % 2 == 0, idx + 10)
     out = sd.gather_results(rec, total)
+    assert sd.collective_device() == "cpu" and sd.max_over_ranks(1.0 + rank) == float(world)      # the clock of bench.py
     q.put((rank, out.tobytes()))
     dist.barrier()
     dist.destroy_process_group()
@@ -56,6 +57,30 @@ def test_gloo_all_gather_of_result_records(total):
     want = sd.pack_results(idx * 1.5, idx * 0.25, idx % 2 == 0, idx + 10)
     for r in range(2):
         assert np.array_equal(np.frombuffer(got[r], dtype=sd.RESULT_DTYPE), want)
+
+
+def _one_rank_worker(port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    rec = sd.pack_results([1.0, 2.0, 3.0], [0.0, 0.5, 0.25], [True, False, True], [3, 4, 5])
+    short = sd.gather_results(rec, 3)
+    forced = sd.gather_results(rec, 3, force_collective=True)
+    q.put((short is rec, forced is not rec and forced.tobytes() == rec.tobytes(), sd.max_over_ranks(2.5)))
+    dist.destroy_process_group()
+
+
+def test_group_of_one_rank_takes_the_collective_only_when_forced():
+    """tests/test_dist_gpu.py runs the RCCL calls this way on a one-GPU box; here the same switch under gloo."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(port, q))
+    p.start()
+    assert q.get(timeout=120) == (True, True, 2.5)
+    p.join(timeout=60)
+    assert p.exitcode == 0
 
 
 class _StubShard(object):

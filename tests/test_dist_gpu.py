@@ -73,3 +73,20 @@ def test_bench_with_two_ranks_on_one_device_rccl_branch(gpu):
     out = _json_line(p.stdout)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["aux"]["backend"] == "nccl"
     assert out["aux"]["sco_iters_per_step"] == _single_rank_iters(128, 2)
+
+
+def test_rccl_calls_of_the_sharded_path_in_a_group_of_one_rank(gpu):
+    """What a one-GPU box CAN run of the RCCL branch: a communicator of one rank is a real RCCL communicator.  A fresh child
+    process (tests/rccl_one_rank.py) initialises the group exactly as bench.py does, solves a small shard through
+    libsco_hip.so and sends its records through dist.gather_results (forced past the one-rank shortcut: all_gather_into_tensor
+    on uint8 DEVICE tensors), dist.max_over_ranks (all_reduce MAX on a float64 device tensor) and two barriers."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = 29500 + (os.getpid() % 400)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank.py"), str(port)], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    out = _json_line(p.stdout)
+    assert out["backend"] == "nccl" and out["device"] == "cuda" and out["world"] == 1
+    assert out["identical"] and out["clock"] == 1.25
+    assert out["sqp_iters"] == _single_rank_iters(24, 1)
