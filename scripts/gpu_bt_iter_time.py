@@ -3,6 +3,9 @@ the same problem replicated B times, first penalty QP capped at 4000 ADMM iterat
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sco_py_amd import _build
+if os.environ.get("SCO_LIB_OVERRIDE"):
+    _build.LIB = os.environ["SCO_LIB_OVERRIDE"]; print("library", _build.LIB)
 from oracle import arm_family as af
 from sco_py_amd import batch as sb, _lib
 one, _ = af.make_batch(1, d=12, T=50, K=10, O=10)
