@@ -21,7 +21,8 @@
 //   * the vectors that cross threads (x~, t, eliminated rhs, core rhs and solution,
 //     the 16-way partial sums of the W mat-vec) sit in static LDS (44 KB) at
 //     compile-time addresses;
-//   * kernel arguments are a slim struct (no SGPR spills in the loop).
+//   * kernel arguments are a slim struct (no SGPR spills in the loop);
+//   * r03: the solve parks and resumes like the other on-chip kernels (time slicing, adaptive rho).
 #include "sco_internal.h"
 
 #include <algorithm>
@@ -143,6 +144,12 @@ struct RegArgs {
   const int *w, *core_of, *Fp, *Fi, *Fpos, *active;
   double *x, *y, *resid;
   int *status, *iters;
+  // park / resume (time slicing, adaptive rho; r03 -- the same protocol as qp_admm_fast_kernel): the loop carries x, z, y
+  // and t = w (rho z - y); a parked solve leaves the first three in sx / sz / sy and its iteration count in prog
+  int slice, adaptive, ad_interval;
+  double ad_tol;
+  int *prog, *rflag, *smask, *nupd;
+  double *sx, *sz, *sy, *rho_b;
 };
 
 __device__ __forceinline__ double rwmax(double v) {
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(RT) void qp_admm_reg_kernel(RegArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (a.active && !a.active[b]) return;
   const int n = a.n, m = a.m, n_e = a.n_e, n_c = a.n_c;
+  const int it0 = a.slice > 0 ? a.prog[b] : 0;         // > 0: a parked solve resumes from its scaled x, z, y
 
   __shared__ double s_xt[CAP_N];          // x~ (and rhs before the solve)
   __shared__ double s_tv[CAP_M];          // t = w (rho z - y)
@@ -269,6 +277,7 @@ __global__ __launch_bounds__(RT) void qp_admm_reg_kernel(RegArgs a) {
   const int ej = a.role[(size_t)2 * RT + tid];
   if (colon) {
     qj = a.qs[(size_t)b * n + tid]; cj = a.core_of[tid];
+    if (it0 > 0) xj = a.sx[(size_t)b * n + tid];
     if (ej >= 0) kinv = a.kee_inv[(size_t)b * n_e + ej];
   }
   // core-owner state
@@ -286,6 +295,7 @@ __global__ __launch_bounds__(RT) void qp_admm_reg_kernel(RegArgs a) {
       r_ls[q] = a.ls[(size_t)b * m + i]; r_us[q] = a.us[(size_t)b * m + i];
       r_rho[q] = a.rho[(size_t)b * m + i]; r_rinv[q] = 1.0 / r_rho[q];
       r_w[q] = (double)a.w[(size_t)b * m + i];
+      if (it0 > 0) { r_z[q] = a.sz[(size_t)b * m + i]; r_y[q] = a.sy[(size_t)b * m + i]; }
     }
   }
   for (int i = tid; i < CAP_M; i += RT) s_tv[i] = 0.0;
@@ -293,11 +303,18 @@ __global__ __launch_bounds__(RT) void qp_admm_reg_kernel(RegArgs a) {
   for (int i = tid; i < CAP_N; i += RT) { s_ge[i] = 0.0; s_xt[i] = 0.0; }
   const double cscale = a.cscale[b];
   const double alpha = a.alpha, sigma = a.sigma;
+  if (a.adaptive && tid == 0) { a.smask[b] = 0; a.rflag[b] = 0; }
   __syncthreads();
+  if (it0 > 0) {                      // t with the rho in force now (it may have changed while the solve was parked)
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      if (r_on[q]) s_tv[tid + q * RT] = r_w[q] * (r_rho[q] * r_z[q] - r_y[q]);
+    __syncthreads();
+  }
 
   int status = 0, iter = 0;
   double pri = 0.0, dua = 0.0;
-  for (iter = 1; iter <= a.max_iter; iter++) {
+  for (iter = it0 + 1; iter <= a.max_iter; iter++) {
     const bool chk = (a.check > 0 && iter % a.check == 0) || iter == a.max_iter;
     // (1) rhs_j = sigma x_j - q_j + sum_i A_ij t_i
     double gev = 0.0;
@@ -360,6 +377,8 @@ __global__ __launch_bounds__(RT) void qp_admm_reg_kernel(RegArgs a) {
     if (!chk) continue;
 
     // ---- termination test (formulas of admm_check in sco_qp.hip) -------------------------
+    const bool adapt_pt = a.adaptive && iter % a.ad_interval == 0 && iter < a.max_iter;
+    double vs[7] = {0, 0, 0, 0, 0, 0, 0};         // adaptive rho: the same norms of the SCALED iterates
     for (int approximate = 0; approximate < 2 && !status; approximate++) {
       if (approximate && iter < a.max_iter) break;
       const double *Ps = a.Ps + (size_t)b * a.nnzP;
@@ -376,6 +395,7 @@ __global__ __launch_bounds__(RT) void qp_admm_reg_kernel(RegArgs a) {
           v[0] = fmax(v[0], fabs(ei * (ax - r_z[q])));
           v[1] = fmax(v[1], fabs(ei * r_z[q]));
           v[2] = fmax(v[2], fabs(ei * ax));
+          if (adapt_pt) { vs[0] = fmax(vs[0], fabs(ax - r_z[q])); vs[1] = fmax(vs[1], fabs(r_z[q])); vs[2] = fmax(vs[2], fabs(ax)); }
         }
       if (colon) {
         double px = 0.0;
@@ -383,6 +403,7 @@ __global__ __launch_bounds__(RT) void qp_admm_reg_kernel(RegArgs a) {
         const double aty = reg_dot<CW>(vc, co, swy);
         const double dj = 1.0 / Dg[tid];
         v[3] = fabs(dj * (qj + px + aty)); v[4] = fabs(dj * qj); v[5] = fabs(dj * aty); v[6] = fabs(dj * px);
+        if (adapt_pt) { vs[3] = fabs(qj + px + aty); vs[4] = fabs(qj); vs[5] = fabs(aty); vs[6] = fabs(px); }
       }
       rblock_reduce<7, true>(v, s_red);
       pri = v[0]; dua = cinv * v[3];
@@ -461,7 +482,30 @@ __global__ __launch_bounds__(RT) void qp_admm_reg_kernel(RegArgs a) {
     }
     __syncthreads();     // scratch slab is reused by the next iteration's partial sums
     if (status) break;
+    double rho_new = 0.0;
+    if (adapt_pt) {
+      // OSQP's rho estimate (same rule as admm_rho_estimate in sco_qp.hip)
+      rblock_reduce<7, true>(vs, s_red);
+      const double rho = a.rho_b[b];
+      const double pn = vs[0] / (fmax(vs[1], vs[2]) + 1e-10);
+      const double dn = vs[3] / (fmax(vs[4], fmax(vs[5], vs[6])) + 1e-10);
+      const double est = fmin(fmax(rho * sqrt(pn / (dn + 1e-10)), SCO_RHO_MIN), 1e6);
+      if (est > rho * a.ad_tol || est < rho / a.ad_tol) rho_new = est;
+    }
+    if (iter < a.max_iter && (rho_new > 0.0 || (a.slice > 0 && iter == it0 + a.slice))) {
+      // rho must change or the slice is used up: park the solve
+      if (colon) a.sx[(size_t)b * n + tid] = xj;
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (r_on[q]) { a.sz[(size_t)b * m + tid + q * RT] = r_z[q]; a.sy[(size_t)b * m + tid + q * RT] = r_y[q]; }
+      if (tid == 0) {
+        a.prog[b] = iter; a.status[b] = 0; a.iters[b] = iter;
+        if (rho_new > 0.0) { a.rho_b[b] = rho_new; a.rflag[b] = 1; a.smask[b] = 1; a.nupd[b] += 1; }
+      }
+      return;
+    }
   }
+  if (a.slice > 0 && tid == 0) a.prog[b] = 0;
   if (!status) status = SCO_QP_MAX_ITER_REACHED;
   if (iter > a.max_iter) iter = a.max_iter;
   {
@@ -546,6 +590,9 @@ int reg_launch(const AdmmArgs &a, const RegHost &rh, const RegDev &rd, hipStream
   ra.rho = d.rho; ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E;
   ra.w = d.w; ra.core_of = d.core_of; ra.Fp = d.Fp; ra.Fi = d.Fi; ra.Fpos = d.Fpos; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
+  ra.slice = a.slice; ra.adaptive = a.adaptive; ra.ad_interval = a.ad_interval; ra.ad_tol = a.ad_tol;
+  ra.prog = d.prog; ra.rflag = d.rflag; ra.smask = d.smask; ra.nupd = d.nupd;
+  ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.rho_b = d.rho_b;
   const int key = rh.TR * 10000 + rh.TC * 100 + rh.PX;
   switch (key) {
     case 10210: return reg_launch_one<1, 2, 12, 8, 10>(ra, d.batch, rh.lds_bytes, st);

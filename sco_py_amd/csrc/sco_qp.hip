@@ -1061,12 +1061,12 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
       sco_set_error("adaptive_rho needs adaptive_rho_tolerance > 1 and check_termination > 0"); return SCO_ERR_ARG;
     }
   }
-  // kernel of the on-chip tiers: the register-offset kernel cannot park a solve; adaptive rho skips it
+  // kernel of the on-chip tiers (every one of them parks and resumes a solve; the register-offset kernel since r03)
   enum { K_RL, K_REG, K_FAST, K_GENERIC };
-  const int kern = qp->use_rl ? K_RL : (qp->use_reg && !adaptive) ? K_REG : qp->use_fast ? K_FAST : K_GENERIC;
-  const bool can_park = qp->use_big ? qp->use_bt : kern != K_REG;
+  const int kern = qp->use_rl ? K_RL : qp->use_reg ? K_REG : qp->use_fast ? K_FAST : K_GENERIC;
+  const bool can_park = qp->use_big ? qp->use_bt : true;
   if (!can_park || st->check_termination <= 0 || (slice <= 0 && !adaptive)) {
-    slice = 0;                                  // the register / sliced-ELL / global-memory kernels run to the end
+    slice = 0;                                  // one launch per solve (always so on the dense global-memory form)
   } else {
     // slices end on a termination check; adaptive rho without time slicing parks only when rho changes
     if (slice <= 0) slice = st->max_iter;

@@ -374,7 +374,7 @@ def test_a_qp_that_needs_the_global_memory_tier_by_itself(gpu):
     assert info["n_core"] > 256 and info["lds_admm"] == 0
 
 
-@pytest.mark.parametrize("tier", ["row-local", "generic", "sliced-ELL-instead-of-register", "structured"])
+@pytest.mark.parametrize("tier", ["row-local", "generic", "register", "sliced-ELL", "structured"])
 def test_adaptive_rho_matches_the_oracle_rule(gpu, monkeypatch, tier):
     """adaptive_rho=True (solver.py:39 / osqp_utils.py:13; off in the reference's defaults): OSQP's rho update
     every 4 x check_termination iterations.  The solve is parked at each update point, rho re-estimated from the
@@ -386,13 +386,17 @@ def test_adaptive_rho_matches_the_oracle_rule(gpu, monkeypatch, tier):
         monkeypatch.setenv("SCO_QP_NO_RL", "1")
     if tier == "generic":
         monkeypatch.setenv("SCO_QP_NO_REG", "1"); monkeypatch.setenv("SCO_QP_NO_FAST", "1")
+    if tier == "sliced-ELL":
+        monkeypatch.setenv("SCO_QP_NO_REG", "1")       # "register": the register-offset kernel parks since r03
     rng = np.random.default_rng(23)
     r = 20 if tier == "structured" else 4                            # 20 rows per block: dense row chunks
     probs = [penalty_qp(rng, 6, 3, r) for _ in range(6)]
     m = len(probs[0][3])
     w = np.ones((6, m), dtype=np.int32); w[:, 3:3 + 6 * r] = 2
     st = _lib.default_qp_settings(adaptive_rho=1)
-    _, x_ad, st_ad, it_ad = _check(probs, w=w, settings=st, adaptive_rho=1, expand_dups=0, resid_tol=1e-7)
+    info, x_ad, st_ad, it_ad = _check(probs, w=w, settings=st, adaptive_rho=1, expand_dups=0, resid_tol=1e-7)
+    if tier == "register":
+        assert info["lds_admm"] > 44032                 # static LDS of qp_admm_reg_kernel + its value images
     _, x_fx, st_fx, it_fx = _check(probs, w=w, expand_dups=0)
     assert not np.array_equal(it_ad, it_fx)                          # some of them did change rho
     ok = (st_ad == 1) & (st_fx == 1)

@@ -438,11 +438,13 @@ def test_diagnostic_flags(gpu):
     assert np.all(res.qp_solves[~capped] <= 3)
 
 
-@pytest.mark.parametrize("tier", ["row-local", "sliced-ELL", "generic", "structured"])
+@pytest.mark.parametrize("tier", ["row-local", "register", "sliced-ELL", "generic", "structured"])
 def test_time_slicing_changes_the_schedule_not_the_results(gpu, monkeypatch, tier):
     """sco_sqp_params.admm_slice: parked and resumed ADMM solves continue bit-exactly, so any slice length
-    gives the same trajectories, decisions and iteration counts as one launch per QP (row-local, sliced-ELL, generic
-    and structured global-memory kernels)."""
+    gives the same trajectories, decisions and iteration counts as one launch per QP (row-local, register-offset --
+    since r03 --, sliced-ELL, generic and structured global-memory kernels)."""
+    if tier == "register":
+        monkeypatch.setenv("SCO_QP_NO_RL", "1")
     if tier == "generic":
         for k in ("SCO_QP_NO_RL", "SCO_QP_NO_REG", "SCO_QP_NO_FAST"):
             monkeypatch.setenv(k, "1")
