@@ -82,8 +82,7 @@ typedef struct sco_qp_settings {
                                test, rho <- rho sqrt(normalised primal / normalised dual residual) clipped to
                                [1e-6, 1e6], taken when it leaves [rho / tol, rho tol]; the reduced system is then
                                refactored and the solve resumes from its iterates (the solve is parked and resumed
-                               around every update).  Runs on the on-chip tiers (a pattern of the register-offset
-                               tier is solved by the sliced-ELL or generic kernel) and on the structured form of the
+                               around every update).  Runs on every on-chip tier and on the structured form of the
                                global-memory tier; its dense form answers SCO_ERR_CAPACITY.  Not part of parity mode.  */
   int adaptive_rho_interval;/* 0 = 4 x check_termination (OSQP's value when it does not time itself: 100)         */
   double adaptive_rho_tolerance; /* OSQP default 5                                                                  */
