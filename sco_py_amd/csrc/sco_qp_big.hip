@@ -333,6 +333,60 @@ __device__ __forceinline__ double big_row_core_dot(const QpDev &d, const double 
 // Termination test on the unscaled residuals + infeasibility certificates (formulas of
 // admm_check in sco_qp.hip); every thread of the workgroup calls it.  Returns the status
 // (0 = keep iterating).
+// Sparse dot products of the termination test with EIGHT entries in flight (r03).  One thread walks one row or column
+// (a core column of 12-DOF x 50 holds 105 entries) and every entry is an index load followed by the gather it addresses:
+// taken one at a time the walk is a chain of dependent memory round trips -- the test was 13 % of an iteration's time at
+// 12-DOF x 50.  The eight index loads, then the eight gathers, go out together; the multiply-adds keep the order of the
+// one-at-a-time loop, so every sum has the same bits as before.
+#define BIG_CHK_U 8
+// sum_s As[Rpos[s]] * vec[Rj[s]] over s in [s0, s1)
+__device__ __forceinline__ double big_row_dot8(const QpDev &d, const double *As, const double *vec, int s0, int s1) {
+  double acc = 0.0;
+  for (int s = s0; s < s1; s += BIG_CHK_U) {
+    int pos[BIG_CHK_U], cj[BIG_CHK_U];
+    double av[BIG_CHK_U], xv[BIG_CHK_U];
+#pragma unroll
+    for (int u = 0; u < BIG_CHK_U; u++) { const int su = s + u < s1 ? s + u : s1 - 1; pos[u] = d.Rpos[su]; cj[u] = d.Rj[su]; }
+#pragma unroll
+    for (int u = 0; u < BIG_CHK_U; u++) { av[u] = As[pos[u]]; xv[u] = vec[cj[u]]; }
+#pragma unroll
+    for (int u = 0; u < BIG_CHK_U; u++) if (s + u < s1) acc += av[u] * xv[u];
+  }
+  return acc;
+}
+// sum_t Ps[Fpos[t]] * vec[Fi[t]] over t in [t0, t1)
+__device__ __forceinline__ double big_p_dot8(const QpDev &d, const double *Ps, const double *vec, int t0, int t1) {
+  double acc = 0.0;
+  for (int t = t0; t < t1; t += BIG_CHK_U) {
+    int pos[BIG_CHK_U], ci[BIG_CHK_U];
+    double pv[BIG_CHK_U], xv[BIG_CHK_U];
+#pragma unroll
+    for (int u = 0; u < BIG_CHK_U; u++) { const int tu = t + u < t1 ? t + u : t1 - 1; pos[u] = d.Fpos[tu]; ci[u] = d.Fi[tu]; }
+#pragma unroll
+    for (int u = 0; u < BIG_CHK_U; u++) { pv[u] = Ps[pos[u]]; xv[u] = vec[ci[u]]; }
+#pragma unroll
+    for (int u = 0; u < BIG_CHK_U; u++) if (t + u < t1) acc += pv[u] * xv[u];
+  }
+  return acc;
+}
+// sum_t As[t] * yv[Ai[t]] * w[Ai[t]] (WFIRST: As[t] * (w[Ai[t]] * yv[Ai[t]])) over t in [t0, t1)
+template <bool WFIRST>
+__device__ __forceinline__ double big_col_dot8(const QpDev &d, const double *As, const double *yv, const int *w, int t0, int t1) {
+  double acc = 0.0;
+  for (int t = t0; t < t1; t += BIG_CHK_U) {
+    int ri[BIG_CHK_U], wi[BIG_CHK_U];
+    double av[BIG_CHK_U], yy[BIG_CHK_U];
+#pragma unroll
+    for (int u = 0; u < BIG_CHK_U; u++) { const int tu = t + u < t1 ? t + u : t1 - 1; ri[u] = d.Ai[tu]; av[u] = As[tu]; }
+#pragma unroll
+    for (int u = 0; u < BIG_CHK_U; u++) { yy[u] = yv[ri[u]]; wi[u] = w[ri[u]]; }
+#pragma unroll
+    for (int u = 0; u < BIG_CHK_U; u++)
+      if (t + u < t1) { if (WFIRST) acc += av[u] * ((double)wi[u] * yy[u]); else acc += av[u] * yy[u] * (double)wi[u]; }
+  }
+  return acc;
+}
+
 struct BigChk {
   const double *As, *Ps, *qs, *ls, *us, *Dg, *Eg, *x, *y, *z, *sdx;
   double *sdy;
@@ -356,15 +410,13 @@ __device__ int big_check(const BigArgs &a, const BigChk &k, int iter, double *re
     if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
     double v[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < m; i += NT) {
-      double ax = 0.0;
-      for (int s = d.Rp[i]; s < d.Rp[i + 1]; s++) ax += As[d.Rpos[s]] * x[d.Rj[s]];
+      const double ax = big_row_dot8(d, As, x, d.Rp[i], d.Rp[i + 1]);
       const double ei = 1.0 / Eg[i];
       v[0] = fmax(v[0], fabs(ei * (ax - z[i]))); v[1] = fmax(v[1], fabs(ei * z[i])); v[2] = fmax(v[2], fabs(ei * ax));
     }
     for (int j = tid; j < n; j += NT) {
-      double px = 0.0, aty = 0.0;
-      for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += Ps[d.Fpos[t]] * x[d.Fi[t]];
-      for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) { const int i = d.Ai[t]; aty += As[t] * y[i] * (double)w[i]; }
+      const double px = big_p_dot8(d, Ps, x, d.Fp[j], d.Fp[j + 1]);
+      const double aty = big_col_dot8<false>(d, As, y, w, d.Ap[j], d.Ap[j + 1]);
       const double dj = 1.0 / Dg[j];
       v[3] = fmax(v[3], fabs(dj * (qs[j] + px + aty))); v[4] = fmax(v[4], fabs(dj * qs[j]));
       v[5] = fmax(v[5], fabs(dj * aty)); v[6] = fmax(v[6], fabs(dj * px));
@@ -447,14 +499,12 @@ __device__ double big_rho_estimate(const BigArgs &a, const BigChk &k, double *re
   const int tid = threadIdx.x, n = d.n, m = d.m;
   double v[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int i = tid; i < m; i += NT) {
-    double ax = 0.0;
-    for (int s = d.Rp[i]; s < d.Rp[i + 1]; s++) ax += k.As[d.Rpos[s]] * k.x[d.Rj[s]];
+    const double ax = big_row_dot8(d, k.As, k.x, d.Rp[i], d.Rp[i + 1]);
     v[0] = fmax(v[0], fabs(ax - k.z[i])); v[1] = fmax(v[1], fabs(k.z[i])); v[2] = fmax(v[2], fabs(ax));
   }
   for (int j = tid; j < n; j += NT) {
-    double px = 0.0, aty = 0.0;
-    for (int t = d.Fp[j]; t < d.Fp[j + 1]; t++) px += k.Ps[d.Fpos[t]] * k.x[d.Fi[t]];
-    for (int t = d.Ap[j]; t < d.Ap[j + 1]; t++) { const int i = d.Ai[t]; aty += k.As[t] * ((double)k.w[i] * k.y[i]); }
+    const double px = big_p_dot8(d, k.Ps, k.x, d.Fp[j], d.Fp[j + 1]);
+    const double aty = big_col_dot8<true>(d, k.As, k.y, k.w, d.Ap[j], d.Ap[j + 1]);
     v[3] = fmax(v[3], fabs(px + k.qs[j] + aty)); v[4] = fmax(v[4], fabs(k.qs[j]));
     v[5] = fmax(v[5], fabs(aty)); v[6] = fmax(v[6], fabs(px));
   }
@@ -969,11 +1019,14 @@ struct BtDenseRegs {
   int r0, r1, e, j, ncols, pos0, cs, c0, pbase, ln;
   bool two, on;
 };
-template <int NC>
+// FULL: the chunk uses all NC columns of its instantiation (ncols is then a compile-time constant and the column masks --
+// a compare, a 64-bit select mask and, with the scalar registers this kernel spills, three v_readlane reloads per column
+// -- drop out of the loads, the dot product, the products and the stores of the column totals)
+template <int NC, bool FULL = false>
 __device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int ch, int lane, bool first, const BtPtrs &q, BtDenseRegs<NC> &R) {
   R.on = lane < dsc[1];
   R.ln = R.on ? lane : dsc[1] - 1;
-  R.ncols = dsc[2]; R.pos0 = dsc[5]; R.cs = dsc[6]; R.c0 = dsc[4]; R.pbase = dsc[14];
+  R.ncols = FULL ? NC : dsc[2]; R.pos0 = dsc[5]; R.cs = dsc[6]; R.c0 = dsc[4]; R.pbase = dsc[14];
   R.r0 = dsc[3] + R.ln; R.e = dsc[7] + R.ln; R.j = dsc[8] + R.ln;
   R.two = dsc[9] >= 0;
   R.r1 = R.two ? dsc[9] + R.ln : R.r0;
@@ -1041,12 +1094,12 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
   }
 }
 // chunks A and, if hasB, B: loads of both before the arithmetic of either
-template <int NC>
+template <int NC, bool FULL = false>
 __device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const int (&dB)[CH_STRIDE], int chA, int chB, bool hasB, int lane,
                                               bool chk, bool first, const BtPtrs &q) {
   BtDenseRegs<NC> RA, RB;
-  bt_dense_load<NC>(dA, chA, lane, first, q, RA);
-  if (hasB) bt_dense_load<NC>(dB, chB, lane, first, q, RB);
+  bt_dense_load<NC, FULL>(dA, chA, lane, first, q, RA);
+  if (hasB) bt_dense_load<NC, FULL>(dB, chB, lane, first, q, RB);
   bt_dense_compute<NC>(RA, lane, chk, q);
   if (hasB) bt_dense_compute<NC>(RB, lane, chk, q);
 }
@@ -1187,11 +1240,21 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   double *x = d.x + (size_t)b * n, *y = d.y + (size_t)b * m;     // scaled iterates; unscaled at the end
   double *ws = a.ws + (size_t)b * a.ws_stride;
   double *z = ws, *tp = z + m, *sdy = tp + m, *ge = sdy + m, *sdx = ge + n_e, *prod = sdx + n;
-  const double cscale = d.cscale[b], alpha = a.alpha, sigma = a.sigma;
+  const double cscale = d.cscale[b];
+  // Scalar kernel arguments of the iteration loop through opaque copies, and the termination test / park path through a
+  // fresh view of the argument segment (r03): rho, sigma, alpha, the four tolerances, max_iter and check arrive in ONE
+  // 16-word scalar load, hipcc keeps the 16 words as one register tuple for as long as any of them lives, and -- scalar
+  // registers being what this kernel spills -- the row loop reloaded all 16 words six times per chunk pair (96 of its
+  // 150 v_readlane).  With the copies the tuple dies in the prologue; the test, every 25th iteration, loads what it
+  // needs from the (constant) argument segment again.
+  double alpha = a.alpha, sigma = a.sigma, rho_arg = a.rho;
+  int max_iter = a.max_iter, check = a.check;
+  asm volatile("" : "+s"(alpha), "+s"(sigma), "+s"(rho_arg), "+s"(max_iter), "+s"(check));
+  const BigArgs *akp = (const BigArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   // v shares the storage of t': the start point's t' is only read by the prologue below
   const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, use_part ? s_part : nullptr, alpha, sigma,
-                  tp, s_cflag, a.per_problem_rho ? d.rho_b[b] : a.rho, a.ccon ? a.ccon[b] : 1.0,
-                  1.0 / (a.per_problem_rho ? d.rho_b[b] : a.rho)};
+                  tp, s_cflag, a.per_problem_rho ? d.rho_b[b] : rho_arg, a.ccon ? a.ccon[b] : 1.0,
+                  1.0 / (a.per_problem_rho ? d.rho_b[b] : rho_arg)};
 
   {
     const double *blk = a.bt_blk + (size_t)b * a.bt_stride;
@@ -1296,8 +1359,8 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
 #else
 #define BSTAMP(k)
 #endif
-  for (iter = it0 + 1; iter <= a.max_iter; iter++) {
-    const bool chk = (a.check > 0 && iter % a.check == 0) || iter == a.max_iter;
+  for (iter = it0 + 1; iter <= max_iter; iter++) {
+    const bool chk = (check > 0 && iter % check == 0) || iter == max_iter;
     const bool first = iter == it0 + 1;       // dense rows: z, y from their arrays (start, resume); afterwards from v
     BSTAMP(11)
     // (1) core right-hand side r_c = sigma x_c - q_c + (A' t)_c
@@ -1380,7 +1443,8 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
           for (int k = 0; k < CH_STRIDE; k++) dsb[k] = __builtin_amdgcn_readfirstlane(s_dsc[chb * CH_STRIDE + k]);
           if (dsb[0] == 0 && (dsb[2] + 3) / 4 == (ncols + 3) / 4) { hasB = true; ch = chb; }
         }
-        if (ncols <= 4) bt_dense_pair<4>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
+        if (ncols == BS && (!hasB || dsb[2] == BS)) bt_dense_pair<BS, true>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
+        else if (ncols <= 4) bt_dense_pair<4>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
         else if (ncols <= 8) bt_dense_pair<8>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
         else if (ncols <= 12) bt_dense_pair<12>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
         else bt_dense_pair<16>(dsc, dsb, cha, chb, hasB, lane, chk, first, bp);
@@ -1403,17 +1467,19 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
     if (!chk) continue;
     double rho_new = 0.0;
     {
+      const BigArgs *ak = akp;
+      asm volatile("" : "+s"(ak));                 // the arguments as the segment holds them, loaded here
       BigChk ck{As, Ps, qs, ls, us, Dg, Eg, x, y, z, sdx, sdy, w, cscale};
-      status = big_check<BTT>(a, ck, iter, red, pri, dua);
-      if (!status && a.adaptive && iter % a.ad_interval == 0 && iter < a.max_iter) {
-        const double rho_b = d.rho_b[b], est = big_rho_estimate<BTT>(a, ck, red, rho_b);
-        if (est > rho_b * a.ad_tol || est < rho_b / a.ad_tol) rho_new = est;
+      status = big_check<BTT>(*ak, ck, iter, red, pri, dua);
+      if (!status && ak->adaptive && iter % ak->ad_interval == 0 && iter < max_iter) {
+        const double rho_b = d.rho_b[b], est = big_rho_estimate<BTT>(*ak, ck, red, rho_b);
+        if (est > rho_b * ak->ad_tol || est < rho_b / ak->ad_tol) rho_new = est;
       }
     }
     __syncthreads();
     BSTAMP(10)
     if (status) break;
-    if (iter < a.max_iter && (rho_new > 0.0 || (a.slice > 0 && iter == it0 + a.slice))) {
+    if (iter < max_iter && (rho_new > 0.0 || (a.slice > 0 && iter == it0 + a.slice))) {
       // rho must change (setup + factorisation run again, then the solve resumes) or the slice is used up: park.
       // x, y stay in place (scaled) and so does the workspace (z, g_e, products) unless rho changes: then setup
       // uses the front of the workspace as scratch, so z goes to the save area; the LDS partial sums always do
@@ -1432,7 +1498,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   }
   if (a.slice > 0 && tid == 0) d.prog[b] = 0;
   if (!status) status = SCO_QP_MAX_ITER_REACHED;
-  if (iter > a.max_iter) iter = a.max_iter;
+  if (iter > max_iter) iter = max_iter;
 #ifdef SCO_STAMP
   if (lane == 0 && b == 0 && a.stamp) {
     for (int k = 0; k < 14; k++) a.stamp[wave * 16 + k] = (double)st_acc[k];

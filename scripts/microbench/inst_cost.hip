@@ -27,7 +27,8 @@ __device__ __forceinline__ double quad1(double v) {
 // mode: 0 independent fma (10 chains x 10), 1 dependent fma chain (100), 2 fold32 x 20 (dependent pairs), 3 fold16 x 20,
 //       4 quad step x 20 (dependent), 5 barrier x 10, 6 LDS write -> barrier -> read (b64) x 10, 7 ds_read_b128 x 16 + wait,
 //       8 the r02 5-row reduction (fold32 x3, fold16 x2, quad x4), 9 dependent ds_read_b64 chain (pointer chase) x 20,
-//       10 the same reduction by v_mfma_f64_4x4x4, 11 / 12 a whole W phase (45 fma + reduction) with either reduction
+//       10 the same reduction by v_mfma_f64_4x4x4, 11 / 12 a whole W phase (45 fma + reduction) with either reduction,
+//       13 v_readlane_b32 x 16 (reload of spilled SGPRs), 14 v_mov_b32 x 16
 template <int MODE>
 __global__ __launch_bounds__(512) void k(double *out, long long *cyc, int reps) {
   __shared__ __attribute__((aligned(16))) double lds[4096];
@@ -124,6 +125,25 @@ __global__ __launch_bounds__(512) void k(double *out, long long *cyc, int reps) 
       const double t0_ = __builtin_amdgcn_mfma_f64_4x4x4f64(sel, 1.0, 0.0, 0, 0, 0);
       const double t1_ = __builtin_amdgcn_mfma_f64_4x4x4f64(d1[4], 1.0, 0.0, 0, 0, 0);
       a[0] = t0_ * 1e-3 + 1.0; a[1] = t1_ * 1e-3 + 1.0;
+    } else if (MODE == 13) {
+      // 16 v_readlane_b32 into 16 different SGPRs, then one use of each (what a reload of spilled SGPRs costs)
+      int s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15;
+      const int src = __double2loint(a[0]);
+      asm volatile("v_readlane_b32 %0, %16, 0\n\tv_readlane_b32 %1, %16, 1\n\tv_readlane_b32 %2, %16, 2\n\tv_readlane_b32 %3, %16, 3\n\t"
+                   "v_readlane_b32 %4, %16, 4\n\tv_readlane_b32 %5, %16, 5\n\tv_readlane_b32 %6, %16, 6\n\tv_readlane_b32 %7, %16, 7\n\t"
+                   "v_readlane_b32 %8, %16, 8\n\tv_readlane_b32 %9, %16, 9\n\tv_readlane_b32 %10, %16, 10\n\tv_readlane_b32 %11, %16, 11\n\t"
+                   "v_readlane_b32 %12, %16, 12\n\tv_readlane_b32 %13, %16, 13\n\tv_readlane_b32 %14, %16, 14\n\tv_readlane_b32 %15, %16, 15\n\ts_nop 1"
+                   : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(s4), "=s"(s5), "=s"(s6), "=s"(s7), "=s"(s8), "=s"(s9), "=s"(s10),
+                     "=s"(s11), "=s"(s12), "=s"(s13), "=s"(s14), "=s"(s15) : "v"(src));
+      p += (unsigned)(s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7 + s8 + s9 + s10 + s11 + s12 + s13 + s14 + s15) & 8u;
+    } else if (MODE == 14) {
+      // 16 v_mov_b32 VGPR -> VGPR (the same count of plain 32-bit VALU operations, for comparison)
+      int v0 = (int)p, v1, v2, v3;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %4\n\tv_mov_b32 %3, %4" : "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v0) : "v"(v0));
+        p += (unsigned)(v1 + v2 + v3) & 8u;
+      }
     } else if (MODE == 9) {
 #pragma unroll
       for (int j = 0; j < 20; j++) p = (unsigned int)*(const double *)((const char *)lds + p);
@@ -162,6 +182,8 @@ int main() {
     run<10>("5-row reduction by 7 v_mfma_f64_4x4x4", 1, threads);
     run<11>("W phase: 45 fma + swap reduction", 1, threads);
     run<12>("W phase: 45 fma + mfma reduction", 1, threads);
+    run<13>("16 v_readlane_b32 to 16 SGPRs", 16, threads);
+    run<14>("16 v_mov_b32 (VGPR to VGPR)", 16, threads);
   }
   return 0;
 }
