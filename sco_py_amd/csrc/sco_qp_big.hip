@@ -1022,6 +1022,12 @@ struct BtDenseRegs {
 // FULL: the chunk uses all NC columns of its instantiation (ncols is then a compile-time constant and the column masks --
 // a compare, a 64-bit select mask and, with the scalar registers this kernel spills, three v_readlane reloads per column
 // -- drop out of the loads, the dot product, the products and the stores of the column totals)
+// Element `idx` (>= 0; the arrays are far below 4 GB) of a per-problem array with a wave-uniform base: the byte offset is
+// formed in 32 bits, so the access is `global_load v, v_off, s[base:base+1]` -- one 32-bit shift per lane instead of a sign
+// extension and a 64-bit shift-add (r03: ~30 accesses per chunk).
+__device__ __forceinline__ double bt_ldg(const double *base, int idx) { return *(const double *)((const char *)base + (unsigned)idx * 8u); }
+__device__ __forceinline__ int bt_ldgi(const int *base, int idx) { return *(const int *)((const char *)base + (unsigned)idx * 4u); }
+__device__ __forceinline__ void bt_stg(double *base, int idx, double v) { *(double *)((char *)base + (unsigned)idx * 8u) = v; }
 template <int NC, bool FULL = false>
 __device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int ch, int lane, bool first, const BtPtrs &q, BtDenseRegs<NC> &R) {
   R.on = lane < dsc[1];
@@ -1031,28 +1037,28 @@ __device__ __forceinline__ void bt_dense_load(const int (&dsc)[CH_STRIDE], int c
   R.two = dsc[9] >= 0;
   R.r1 = R.two ? dsc[9] + R.ln : R.r0;
 #pragma unroll
-  for (int k = 0; k < NC; k++) R.av[k] = q.As[R.pos0 + (k < R.ncols ? k : 0) * R.cs + R.ln];
+  for (int k = 0; k < NC; k++) R.av[k] = bt_ldg(q.As, R.pos0 + (k < R.ncols ? k : 0) * R.cs + R.ln);
   const int ep0 = dsc[10] + dsc[11] * R.ln, ep1 = R.two ? dsc[12] + dsc[13] * R.ln : ep0;
   // per-row constants the chunk's rows are known to share are not loaded (flags: qp_setup_big_kernel; wave-uniform)
   const int fl = __builtin_amdgcn_readfirstlane(q.s_cflag[ch]), fs = fl >> 8;
   // first iteration of a launch: z and y as the start / the previous launch left them; afterwards one number per row
   double vp = 0.0, vs = 0.0;
-  R.p.zc = 0.0; R.p.ae = q.As[ep0]; R.s.zc = 0.0; R.s.ae = q.As[ep1];
-  if (first) { R.p.z = q.z[R.r0]; R.p.y = q.y[R.r0]; R.s.z = q.z[R.r1]; R.s.y = q.y[R.r1]; }
-  else { vp = q.v[R.r0]; vs = q.v[R.r1]; }
-  if (fl & 1) R.p.l = -SCO_INFTY; else if (fl & 2) R.p.l = 0.0; else R.p.l = q.ls[R.r0];
-  if (fl & 4) R.p.u = SCO_INFTY; else R.p.u = q.us[R.r0];
-  if (fl & 8) { R.p.rh = q.rho0; R.p.ri = q.rinv0; } else { R.p.rh = q.rho[R.r0]; R.p.ri = 1.0 / R.p.rh; }
-  if (fl & 16) R.p.w = 1.0; else if (fl & 32) R.p.w = q.wk; else R.p.w = (double)q.w[R.r0];
+  R.p.zc = 0.0; R.p.ae = bt_ldg(q.As, ep0); R.s.zc = 0.0; R.s.ae = bt_ldg(q.As, ep1);
+  if (first) { R.p.z = bt_ldg(q.z, R.r0); R.p.y = bt_ldg(q.y, R.r0); R.s.z = bt_ldg(q.z, R.r1); R.s.y = bt_ldg(q.y, R.r1); }
+  else { vp = bt_ldg(q.v, R.r0); vs = bt_ldg(q.v, R.r1); }
+  if (fl & 1) R.p.l = -SCO_INFTY; else if (fl & 2) R.p.l = 0.0; else R.p.l = bt_ldg(q.ls, R.r0);
+  if (fl & 4) R.p.u = SCO_INFTY; else R.p.u = bt_ldg(q.us, R.r0);
+  if (fl & 8) { R.p.rh = q.rho0; R.p.ri = q.rinv0; } else { R.p.rh = bt_ldg(q.rho, R.r0); R.p.ri = 1.0 / R.p.rh; }
+  if (fl & 16) R.p.w = 1.0; else if (fl & 32) R.p.w = q.wk; else R.p.w = (double)bt_ldgi(q.w, R.r0);
   if (!R.two) { R.s.l = R.p.l; R.s.u = R.p.u; R.s.rh = R.p.rh; R.s.ri = R.p.ri; R.s.w = R.p.w; }      // r1 = r0: never used
   else {
-    if (fs & 1) R.s.l = -SCO_INFTY; else if (fs & 2) R.s.l = 0.0; else R.s.l = q.ls[R.r1];
-    if (fs & 4) R.s.u = SCO_INFTY; else R.s.u = q.us[R.r1];
-    if (fs & 8) { R.s.rh = q.rho0; R.s.ri = q.rinv0; } else { R.s.rh = q.rho[R.r1]; R.s.ri = 1.0 / R.s.rh; }
-    if (fs & 16) R.s.w = 1.0; else if (fs & 32) R.s.w = q.wk; else R.s.w = (double)q.w[R.r1];
+    if (fs & 1) R.s.l = -SCO_INFTY; else if (fs & 2) R.s.l = 0.0; else R.s.l = bt_ldg(q.ls, R.r1);
+    if (fs & 4) R.s.u = SCO_INFTY; else R.s.u = bt_ldg(q.us, R.r1);
+    if (fs & 8) { R.s.rh = q.rho0; R.s.ri = q.rinv0; } else { R.s.rh = bt_ldg(q.rho, R.r1); R.s.ri = 1.0 / R.s.rh; }
+    if (fs & 16) R.s.w = 1.0; else if (fs & 32) R.s.w = q.wk; else R.s.w = (double)bt_ldgi(q.w, R.r1);
   }
   if (!first) { bt_row_zy(R.p, vp); bt_row_zy(R.s, vs); }
-  R.g = q.ge[R.e]; R.ki = q.kinv[R.e]; R.xo = q.x[R.j]; R.qj = q.qs[R.j];
+  R.g = bt_ldg(q.ge, R.e); R.ki = bt_ldg(q.kinv, R.e); R.xo = bt_ldg(q.x, R.j); R.qj = bt_ldg(q.qs, R.j);
 }
 template <int NC>
 __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, bool chk, const BtPtrs &q) {
@@ -1072,15 +1078,15 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
   const double xte = R.g - R.ki * (rwp * R.p.ae * R.p.zc);         // the second row has no core entry
   double zn, yn, dy, vv;
   const double tq0 = bt_row_step_v(R.p, q.alpha, xte, zn, yn, dy, vv);
-  if (R.on) { q.v[R.r0] = vv; if (chk) { q.z[R.r0] = zn; q.y[R.r0] = yn; q.sdy[R.r0] = dy; } }
+  if (R.on) { bt_stg(q.v, R.r0, vv); if (chk) { bt_stg(q.z, R.r0, zn); bt_stg(q.y, R.r0, yn); bt_stg(q.sdy, R.r0, dy); } }
   double tq1 = 0.0;
   if (R.two) {
     tq1 = bt_row_step_v(R.s, q.alpha, xte, zn, yn, dy, vv);
-    if (R.on) { q.v[R.r1] = vv; if (chk) { q.z[R.r1] = zn; q.y[R.r1] = yn; q.sdy[R.r1] = dy; } }
+    if (R.on) { bt_stg(q.v, R.r1, vv); if (chk) { bt_stg(q.z, R.r1, zn); bt_stg(q.y, R.r1, yn); bt_stg(q.sdy, R.r1, dy); } }
   }
   const double xn = q.alpha * xte + (1.0 - q.alpha) * R.xo;
   const double gn = bt_ge(q.sigma, xn, R.qj, R.p.ae, tq0, R.s.ae, tq1, R.ki);
-  if (R.on) { if (chk) q.sdx[R.j] = xn - R.xo; q.x[R.j] = xn; q.ge[R.e] = gn; }
+  if (R.on) { if (chk) bt_stg(q.sdx, R.j, xn - R.xo); bt_stg(q.x, R.j, xn); bt_stg(q.ge, R.e, gn); }
   const double t0 = R.on ? tq0 - rwp * R.p.ae * gn : 0.0;
   if (q.s_part) {
     double pv[NC];
@@ -1090,7 +1096,7 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
   } else if (R.on) {
 #pragma unroll
     for (int k = 0; k < NC; k++)
-      if (k < R.ncols) q.prod[R.pos0 + k * R.cs + lane] = R.av[k] * t0;
+      if (k < R.ncols) bt_stg(q.prod, R.pos0 + k * R.cs + lane, R.av[k] * t0);
   }
 }
 // chunks A and, if hasB, B: loads of both before the arithmetic of either
