@@ -108,6 +108,7 @@ struct BigArgs {
   double *bt_blk; size_t bt_stride;
   const int *ch_desc, *it, *cent;
   int nchunks, npart, use_part;
+  int bt_triple;     // 1: three dense chunks in flight per wavefront where they qualify (SCO_QP_BT_TRIPLE=0: pairs only)
   // park / resume of the structured kernel (time slicing, adaptive rho; see RlArgs in sco_admm_rl.hip)
   int slice, adaptive, ad_interval, per_problem_rho;
   double ad_tol;
@@ -1099,6 +1100,57 @@ __device__ __forceinline__ void bt_dense_compute(BtDenseRegs<NC> &R, int lane, b
       if (k < R.ncols) bt_stg(q.prod, R.pos0 + k * R.cs + lane, R.av[k] * t0);
   }
 }
+// ---- three chunks in flight (r03) ------------------------------------------------------------------------------
+// Between its loads and its arithmetic a chunk is only what was loaded: the values of A, the two slack coefficients, v of
+// both rows, the upper bound of the primary row and the four numbers of the eliminated variable -- 21 doubles per lane
+// at 12 columns (+ 4 row / variable indices).  That is what BtLean holds; the full BtDenseRegs (78 registers) is built
+// from it, the descriptor and the chunk's flags only when the arithmetic starts, so THREE chunks' loads fit the
+// register file where two full sets did.  Eligible (bt_lean_ok): chunks of full width whose flags say that every other
+// per-row constant is a known value -- lower bounds, rho and weights of both rows, the upper bound of the secondary rows
+// (hinge rows with their slack rows, qp_setup_big_kernel) -- on every iteration but the first of a launch (which reads z
+// and y, not v).
+template <int NC>
+struct BtLean { double av[NC], ae0, ae1, v0, v1, u0, g, ki, xo, qj; int r0, r1, e, j; };
+__device__ __forceinline__ bool bt_lean_ok(int fl, bool two) {
+  const int fs = fl >> 8;
+  return (fl & 3) && (fl & 8) && (fl & 48) && (!two || ((fs & 3) && (fs & 4) && (fs & 8) && (fs & 48)));
+}
+template <int NC>
+__device__ __forceinline__ void bt_lean_load(const int (&dsc)[CH_STRIDE], int fl, int lane, const BtPtrs &q, BtLean<NC> &L) {
+  const int ln = lane < dsc[1] ? lane : dsc[1] - 1;
+  const bool two = dsc[9] >= 0;
+  L.r0 = dsc[3] + ln; L.r1 = two ? dsc[9] + ln : L.r0; L.e = dsc[7] + ln; L.j = dsc[8] + ln;
+#pragma unroll
+  for (int k = 0; k < NC; k++) L.av[k] = bt_ldg(q.As, dsc[5] + k * dsc[6] + ln);
+  const int ep0 = dsc[10] + dsc[11] * ln, ep1 = two ? dsc[12] + dsc[13] * ln : ep0;
+  L.ae0 = bt_ldg(q.As, ep0); L.ae1 = bt_ldg(q.As, ep1);
+  L.v0 = bt_ldg(q.v, L.r0); L.v1 = bt_ldg(q.v, L.r1);
+  L.u0 = SCO_INFTY;
+  if (!(fl & 4)) L.u0 = bt_ldg(q.us, L.r0);
+  L.g = bt_ldg(q.ge, L.e); L.ki = bt_ldg(q.kinv, L.e); L.xo = bt_ldg(q.x, L.j); L.qj = bt_ldg(q.qs, L.j);
+}
+template <int NC>
+__device__ __forceinline__ void bt_lean_compute(const int *s_dsc, int ch, int lane, bool chk, const BtPtrs &q, const BtLean<NC> &L) {
+  const int nact = __builtin_amdgcn_readfirstlane(s_dsc[ch * CH_STRIDE + 1]);
+  const int fl = __builtin_amdgcn_readfirstlane(q.s_cflag[ch]), fs = fl >> 8;
+  BtDenseRegs<NC> R;
+  R.on = lane < nact;
+  R.ln = R.on ? lane : nact - 1;
+  R.ncols = NC; R.pos0 = 0; R.cs = 0;
+  R.c0 = __builtin_amdgcn_readfirstlane(s_dsc[ch * CH_STRIDE + 4]);
+  R.pbase = __builtin_amdgcn_readfirstlane(s_dsc[ch * CH_STRIDE + 14]);
+  R.two = __builtin_amdgcn_readfirstlane(s_dsc[ch * CH_STRIDE + 9]) >= 0;
+  R.r0 = L.r0; R.r1 = L.r1; R.e = L.e; R.j = L.j;
+#pragma unroll
+  for (int k = 0; k < NC; k++) R.av[k] = L.av[k];
+  R.p.zc = 0.0; R.p.ae = L.ae0; R.s.zc = 0.0; R.s.ae = L.ae1;
+  R.p.l = (fl & 1) ? -SCO_INFTY : 0.0; R.p.u = L.u0; R.p.rh = q.rho0; R.p.ri = q.rinv0; R.p.w = (fl & 16) ? 1.0 : q.wk;
+  if (!R.two) { R.s.l = R.p.l; R.s.u = R.p.u; R.s.rh = R.p.rh; R.s.ri = R.p.ri; R.s.w = R.p.w; }
+  else { R.s.l = (fs & 1) ? -SCO_INFTY : 0.0; R.s.u = SCO_INFTY; R.s.rh = q.rho0; R.s.ri = q.rinv0; R.s.w = (fs & 16) ? 1.0 : q.wk; }
+  bt_row_zy(R.p, L.v0); bt_row_zy(R.s, L.v1);
+  R.g = L.g; R.ki = L.ki; R.xo = L.xo; R.qj = L.qj;
+  bt_dense_compute<NC>(R, lane, chk, q);
+}
 // chunks A and, if hasB, B: loads of both before the arithmetic of either
 template <int NC, bool FULL = false>
 __device__ __forceinline__ void bt_dense_pair(const int (&dA)[CH_STRIDE], const int (&dB)[CH_STRIDE], int chA, int chB, bool hasB, int lane,
@@ -1441,6 +1493,30 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
       int dsc[CH_STRIDE], dsb[CH_STRIDE];          // wave-uniform: descriptor words in SGPRs
 #pragma unroll
       for (int k = 0; k < CH_STRIDE; k++) dsc[k] = __builtin_amdgcn_readfirstlane(s_dsc[ch * CH_STRIDE + k]);
+      if (dsc[0] == 0 && a.bt_triple && !first && use_part && dsc[2] == BS && ch + 2 * BTWV < a.nchunks) {
+        // three full-width chunks with known per-row constants: all their loads before the arithmetic of the first
+        const int chb = ch + BTWV, chc = ch + 2 * BTWV;
+        int dsc2[CH_STRIDE];
+#pragma unroll
+        for (int k = 0; k < CH_STRIDE; k++) dsb[k] = __builtin_amdgcn_readfirstlane(s_dsc[chb * CH_STRIDE + k]);
+#pragma unroll
+        for (int k = 0; k < CH_STRIDE; k++) dsc2[k] = __builtin_amdgcn_readfirstlane(s_dsc[chc * CH_STRIDE + k]);
+        const int fa = __builtin_amdgcn_readfirstlane(s_cflag[ch]), fb = __builtin_amdgcn_readfirstlane(s_cflag[chb]),
+                  fc = __builtin_amdgcn_readfirstlane(s_cflag[chc]);
+        if (dsb[0] == 0 && dsc2[0] == 0 && dsb[2] == BS && dsc2[2] == BS && bt_lean_ok(fa, dsc[9] >= 0) &&
+            bt_lean_ok(fb, dsb[9] >= 0) && bt_lean_ok(fc, dsc2[9] >= 0)) {
+          BtLean<BS> LA, LB, LC;
+          bt_lean_load<BS>(dsc, fa, lane, bp, LA);
+          bt_lean_load<BS>(dsb, fb, lane, bp, LB);
+          bt_lean_load<BS>(dsc2, fc, lane, bp, LC);
+          bt_lean_compute<BS>(s_dsc, ch, lane, chk, bp, LA);
+          bt_lean_compute<BS>(s_dsc, chb, lane, chk, bp, LB);
+          bt_lean_compute<BS>(s_dsc, chc, lane, chk, bp, LC);
+          ch = chc;
+          BSTAMP(7)
+          continue;
+        }
+      }
       if (dsc[0] == 0) {
         const int ncols = dsc[2], chb = ch + BTWV, cha = ch;
         bool hasB = false;
@@ -1619,7 +1695,7 @@ int big_launch(const AdmmArgs &a, const int *setup_mask, int scaling, const int 
     ba.stamp = g_stamp; sco_debug_stamp_bt_ptr = g_stamp;
   }
 #endif
-  ba.bt_bs = 0; ba.bt_nb = 0; ba.bt_mid = 0; ba.bt_blk = nullptr; ba.bt_stride = 0; ba.nchunks = 0;
+  ba.bt_bs = 0; ba.bt_nb = 0; ba.bt_mid = 0; ba.bt_blk = nullptr; ba.bt_stride = 0; ba.nchunks = 0; ba.bt_triple = 0;
   ba.ch_desc = ba.it = ba.cent = nullptr; ba.npart = 0; ba.use_part = 0; ba.cflag = nullptr; ba.ccon = nullptr;
   ba.d = a.d; ba.Pp = Pp; ba.Pi = Pi;
   ba.row_elim = bd.row_elim; ba.row_epos = bd.row_epos; ba.er_ptr = bd.er_ptr; ba.er_row = bd.er_row;
@@ -1633,6 +1709,7 @@ int big_launch(const AdmmArgs &a, const int *setup_mask, int scaling, const int 
     ba.bt_bs = th->bs; ba.bt_nb = th->nb; ba.bt_mid = th->nb >= 4 ? th->nb / 2 : th->nb - 1; ba.bt_blk = td->blk; ba.bt_stride = th->blk_doubles;
     ba.ch_desc = td->ch_desc; ba.it = td->it; ba.cent = td->cent; ba.nchunks = th->nchunks;
     ba.npart = th->npart; ba.use_part = th->use_part ? 1 : 0;
+    { const char *te = getenv("SCO_QP_BT_TRIPLE"); ba.bt_triple = !(te && atoi(te) == 0); }
     ba.ws = td->ws; ba.ws_stride = th->ws_doubles;
     ba.cflag = td->cflag; ba.ccon = td->ccon;
   }

@@ -179,6 +179,25 @@ def test_12dof_50step_problem_against_stored_oracle_run(gpu):
     assert abs(res.max_violation[0] - float(r["p0_max_violation"])) < 1e-7
 
 
+def test_three_chunks_in_flight_on_the_structured_tier_change_no_bit(gpu, monkeypatch):
+    """r03: where three dense chunks of full width qualify (known per-row constants), the structured kernel issues the loads
+    of all three before the arithmetic of the first (csrc/sco_qp_big.hip, BtLean).  The arithmetic is the pairwise loop's:
+    SCO_QP_BT_TRIPLE=0 gives the same bits -- 12-DOF x 50 problems, solved in slices (park / resume) and in one piece."""
+    arrays, _ = af.make_batch(3, d=12, T=50, K=10, O=10)
+    out = {}
+    for triple in ("1", "0"):
+        monkeypatch.setenv("SCO_QP_BT_TRIPLE", triple)
+        for slice_ in (-1, 1500):
+            p = _lib.default_sqp_params(max_sqp_iters=2, admm_slice=slice_)
+            res = sb.solve_batch(arrays, params=p, qp_settings=_lib.default_qp_settings(max_iter=6000))
+            out[triple, slice_] = (res.x.copy(), [t.copy() for t in res.trace], res.admm_iters.copy())
+    ref = out["0", -1]
+    for key, (x, tr, it) in out.items():
+        assert np.array_equal(it, ref[2]), key
+        assert all(np.array_equal(a, b) for a, b in zip(tr, ref[1])), key
+        assert np.array_equal(x, ref[0]), key
+
+
 @pytest.mark.parametrize("shape,B", [((1, 2, 1, 1), 1), ((2, 3, 1, 1), 3), ((1, 40, 1, 2), 2), ((5, 2, 3, 1), 5)])
 def test_minimal_and_odd_shapes(gpu, shape, B):
     """Smallest legal descriptor (1 joint, 2 steps, 1 point, 1 obstacle, batch 1), odd batch sizes, a
