@@ -343,7 +343,8 @@ int sco_sqp_fetch_flags(sco_sqp *h, int *flags);
 /* Number of device rounds (pre -> QP setup -> ADMM launch -> post) of the last solve, the projection round
  * included; with time slicing one QP spans several rounds.  Default schedule: ONE group with round selection (a
  * batch larger than the CU count runs whole passes of the problems with most work in front of them); SCO_SQP_GROUPS=2..4
- * in the environment cuts the batch into stream groups whose rounds run side by side instead (no selection then).
+ * in the environment cuts the batch into stream groups whose rounds run side by side (since r03 each group selects its
+ * own whole passes; results do not depend on either).
  * Scheduling only, results unchanged.  `rounds` counts the group that needed most. */
 int sco_sqp_last_rounds(const sco_sqp *h, int *rounds);
 /* Round launches of the last solve summed over its stream groups (projection round excluded), and the number of

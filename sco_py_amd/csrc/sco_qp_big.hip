@@ -1308,6 +1308,7 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   double alpha = a.alpha, sigma = a.sigma, rho_arg = a.rho;
   int max_iter = a.max_iter, check = a.check;
   asm volatile("" : "+s"(alpha), "+s"(sigma), "+s"(rho_arg), "+s"(max_iter), "+s"(check));
+  // (BigArgs is the kernel's ONLY explicit parameter, passed by value: the argument segment starts with it)
   const BigArgs *akp = (const BigArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   // v shares the storage of t': the start point's t' is only read by the prologue below
   const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, use_part ? s_part : nullptr, alpha, sigma,

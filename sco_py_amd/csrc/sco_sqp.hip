@@ -1466,12 +1466,14 @@ static hipEvent_t next_event(sco_sqp *h, size_t &cursor) {
 // n_active starts the round at the number of live problems left out (sqp_post_kernel adds those that ran and go on).
 #define SEL_T 1024
 #define SEL_BUCKETS 1024
-__global__ __launch_bounds__(SEL_T) void sqp_select_kernel(SqpDev s, QpDev q1, int cus, int slice, int max_iter, int cap) {
+// (r03: the kernel works on the problems [s.b0, s.b0 + nb) of a stream group and fills that group's part of the list, so
+// selection and stream groups combine: SCO_SQP_GROUPS)
+__global__ __launch_bounds__(SEL_T) void sqp_select_kernel(SqpDev s, QpDev q1, int cus, int slice, int max_iter, int cap, int nb) {
   __shared__ int hist[SEL_BUCKETS];
   __shared__ int part[SEL_T], part2[SEL_T];
   __shared__ int s_active, s_thr, s_take;
-  const int tid = threadIdx.x, B = s.batch;
-  int *list = s.list_buf;
+  const int tid = threadIdx.x, B = nb, gb0 = s.b0;
+  int *list = s.list_buf + gb0;
   for (int k = tid; k < SEL_BUCKETS; k += SEL_T) hist[k] = 0;
   if (tid == 0) s_active = 0;
   __syncthreads();
@@ -1484,7 +1486,7 @@ __global__ __launch_bounds__(SEL_T) void sqp_select_kernel(SqpDev s, QpDev q1, i
     const int est = max(per_qp - done, 0) + (sc.qp_solves <= 1 ? per_qp : 0);
     return max(SEL_BUCKETS - 1 - est, 0);
   };
-  const int per = (B + SEL_T - 1) / SEL_T, b0 = min(B, tid * per), b1 = min(B, b0 + per);
+  const int per = (B + SEL_T - 1) / SEL_T, b0 = gb0 + min(B, tid * per), b1 = min(gb0 + B, b0 + per);
   int mine = 0;
   for (int b = b0; b < b1; b++) {
     const int k = key_of(b);
@@ -1638,9 +1640,9 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   // (profiles/r02_launches.txt: 737 ms per step against 630 ms of work).  Default: ROUND SELECTION -- with more active
   // problems than CUs a round runs a whole number of passes, the problems with most in front of them first
   // (sqp_select_kernel), and SQP_DEPTH rounds are enqueued ahead so the device never waits for the host.
-  // Alternative (SCO_SQP_GROUPS = 2..4, then no selection): the batch is cut into contiguous STREAM GROUPS that run
-  // their lock-step rounds independently on streams of their own, one group's launch filling the CUs another's
-  // leaves free.  (Measured on the 1024-problem 7x20 step: DESIGN.md 3.3.)
+  // Opt-in on top (SCO_SQP_GROUPS = 2..4): the batch is cut into contiguous STREAM GROUPS that run their rounds
+  // independently on streams of their own -- each with its own selection since r03 -- so that one group's launch fills the
+  // CUs the end of another's leaves free.  (Measured on the 1024-problem 7x20 step: DESIGN.md 3.3.)
   int G = 1, cus = 0;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
   {
@@ -1650,7 +1652,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
       G = std::max(1, std::min(std::min(want, SQP_MAX_GROUPS), s.batch / cus));
   }
   const char *sel_env = getenv("SCO_SQP_SELECT");
-  const bool select = G == 1 && slice_req > 0 && cus > 0 && s.batch > cus && sco_qp_supports_groups(h->qp1, &qsl) &&
+  const bool select = slice_req > 0 && cus > 0 && s.batch > cus && sco_qp_supports_groups(h->qp1, &qsl) &&
                       !(sel_env && sel_env[0] == '0');
   if (getenv("SCO_SQP_TRACE_ROUNDS")) fprintf(stderr, "sco_sqp_solve: %d CUs, %d stream group(s), round selection %s, slice %d\n", cus, G, select ? "on" : "off", slice_req);
   h->groups_used = G;
@@ -1685,7 +1687,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     if (select) {
       // compact launch: as many workgroups as the selection can let run, sized from the newest active count the host has
       nwg = std::max(1, r.last_active <= cus ? r.last_active : (r.last_active / cus) * cus);
-      hipLaunchKernelGGL(sqp_select_kernel, dim3(1), dim3(SEL_T), 0, r.st, sg, h->qp1->d, cus, slice_req, qsl.max_iter, nwg);
+      hipLaunchKernelGGL(sqp_select_kernel, dim3(1), dim3(SEL_T), 0, r.st, sg, h->qp1->d, cus, slice_req, qsl.max_iter, nwg, r.nb);
       SCO_HIP(hipGetLastError());
       sg.list = s.list_buf;
     }

@@ -498,7 +498,8 @@ def test_round_selection_and_stream_groups_change_the_schedule_not_the_results(g
         monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
     nb, dims = (700, (3, 6, 2, 2)) if tier == "row-local" else (300, (4, 8, 8, 3))
     arrays, probs = af.make_batch(nb, d=dims[0], T=dims[1], K=dims[2], O=dims[3])
-    schedules = [("0", "1", 400), ("1", "1", 400), ("1", "1", 175), ("0", "2", 400), ("0", "3", 175)]
+    # (selection, stream groups, slice); since r03 selection also runs inside every stream group
+    schedules = [("0", "1", 400), ("1", "1", 400), ("1", "1", 175), ("0", "2", 400), ("0", "3", 175), ("1", "2", 400), ("1", "2", 175)]
     outs = []
     with sb.TrajOptBatch(nb, *dims) as tb:
         tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
@@ -511,7 +512,7 @@ def test_round_selection_and_stream_groups_change_the_schedule_not_the_results(g
             r = tb.fetch(); r.trace = tb.trace(); r.timing = tb.last_timing()
             outs.append(r)
     # 700 problems on 256 CUs: at most two groups; 300: one
-    assert [r.timing["groups"] for r in outs] == ([1, 1, 1, 2, 2] if nb >= 512 else [1] * 5)
+    assert [r.timing["groups"] for r in outs] == ([1, 1, 1, 2, 2, 2, 2] if nb >= 512 else [1] * 7)
     if nb >= 512:
         assert outs[3].timing["launches"] > outs[0].timing["launches"] >= outs[0].timing["rounds"] - 1
     assert outs[1].timing["rounds"] >= outs[0].timing["rounds"]        # problems that sit rounds out need more of them
