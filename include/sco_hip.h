@@ -320,6 +320,11 @@ int sco_sqp_set_groups(sco_sqp *h, int n_groups, const unsigned int *block_mask)
 /* nonconverged[batch]: bit g set = group g is in prob.nonconverged_groups after the last solve
  * (violated and no longer improving when _min_merit_fn last returned, solver.py:209-235). */
 int sco_sqp_fetch_groups(sco_sqp *h, unsigned int *nonconverged);
+/* stalled[batch]: bit g set = group g ENDED the last minimisation (violated, its model predicts no progress and no group
+ * sharing a constraint with it progresses, solver.py:209-228).  A subset of sco_sqp_fetch_groups' mask; the reference's
+ * prob.nonconverged_groups list is these groups followed by all of that mask (solver.py:232-234), which is what the
+ * object-API path (sco_osqp/compile.py: write_back) rebuilds. */
+int sco_sqp_fetch_stalled_groups(sco_sqp *h, unsigned int *stalled);
 
 /* Run Solver.solve(prob, method="penalty_sqp") for every problem of the batch
  * (solver.py:30-105) starting from the loaded state; blocks until all are done. */

@@ -86,6 +86,7 @@ ABI = {
     "sco_sqp_load_ee_cost": (C.c_int, [C.c_void_p, _DP, _DP]),
     "sco_sqp_set_groups": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]),
     "sco_sqp_fetch_groups": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint)]),
+    "sco_sqp_fetch_stalled_groups": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint)]),
     "sco_sqp_fetch_flags": (C.c_int, [C.c_void_p, _IP]),
     "sco_sqp_last_rounds": (C.c_int, [C.c_void_p, _IP]),
     "sco_sqp_last_launches": (C.c_int, [C.c_void_p, _IP, _IP]),

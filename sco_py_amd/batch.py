@@ -207,12 +207,16 @@ class TrajOptBatch(object):
             admm.ctypes.data_as(C.POINTER(C.c_longlong)), _lib.dptr(merit), _lib.dptr(viol)))
         nc = np.zeros(B, dtype=np.uint32)
         _lib.check(_lib.load().sco_sqp_fetch_groups(self._h, nc.ctypes.data_as(C.POINTER(C.c_uint))))
+        st = np.zeros(B, dtype=np.uint32)
+        _lib.check(_lib.load().sco_sqp_fetch_stalled_groups(self._h, st.ctypes.data_as(C.POINTER(C.c_uint))))
         flags = np.zeros(B, dtype=np.int32)
         _lib.check(_lib.load().sco_sqp_fetch_flags(self._h, _lib.iptr(flags)))
         gids = getattr(self, "group_ids", ["all"])
         groups = [[g for k, g in enumerate(gids) if (int(m) >> k) & 1] for m in nc]
+        stalled = [[g for k, g in enumerate(gids) if (int(m) >> k) & 1] for m in st]
         return SimpleNamespace(x=x, success=success.astype(bool), sqp_iters=sqp_iters, qp_solves=qp_solves,
                                admm_iters=admm, merit=merit, max_violation=viol, nonconverged_groups=groups,
+                               stalled_groups=stalled,   # the groups that ended the minimisation (listed first by the reference)
                                flags=flags)      # bit flags SCO_SQP_FLAG_* (memo history full, capped, trace full)
 
     def trace(self, cap=64):

@@ -99,7 +99,8 @@ struct SqpDev {
   const unsigned int *gmask;      // [NB] groups of every constraint block
   const unsigned int *goverlap;   // [32] groups sharing a block with group g
   double *mvec;                   // [B][32] per-group violation at the convexification point
-  unsigned int *nonconv;          // [B] prob.nonconverged_groups
+  unsigned int *nonconv;          // [B] prob.nonconverged_groups: the violated groups under the y threshold (solver.py:232-234)
+  unsigned int *stalled;          // [B] the groups that ended the minimisation (solver.py:209-228); the reference lists them first
   const int *bpos;   // CSC positions are not needed for bounds: rows are contiguous
   // Q3 emulation: per timestep block, the points already seen (keys = rint(x * 1e6), the
   // reference's tuple(x.round(6))) with their f values, and the points already
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
     sc.state = ST_PROJECT; sc.k = 0; sc.sqp_iters = 0; sc.qp_solves = 0; sc.success = 0;
     sc.escalations = 0; sc.n_trace = 0; sc.spawned = 0; sc.admm_iters = 0; sc.flags = 0;
     sc.slack_cost = 1.0; sc.merit = 0.0; sc.merit_viol = 0.0;
-    s.active[b] = 1; s.nonconv[b] = 0u;
+    s.active[b] = 1; s.nonconv[b] = 0u; s.stalled[b] = 0u;
   }
   for (int t = tid; t < s.NB; t += SCO_BLOCK) { s.hn[(size_t)b * s.NB + t] = 0; s.cn[(size_t)b * s.NB + t] = 0; }
 }
@@ -974,7 +975,10 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
     // prob.nonconverged_groups is rewritten by every trust-region trial that gets past the
     // y-convergence test (solver.py:209, 233-235)
     if (kind != STEP_BAD && kind != STEP_YCONV)
+    {
       s.nonconv[b] = (kind == STEP_GROUP) ? (s.G > 0 ? g_report : 1u) : 0u;
+      s.stalled[b] = (kind == STEP_GROUP) ? (s.G > 0 ? g_stalled : 1u) : 0u;
+    }
     sc.qp_solves = qp_solves; sc.admm_iters += iters;
     if (capped) atomicOr(&sc.flags, SCO_SQP_FLAG_CAPPED);
     if (sc.n_trace >= s.trace_cap) atomicOr(&sc.flags, SCO_SQP_FLAG_TRACE_FULL);
@@ -1229,6 +1233,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   { unsigned int *p; if ((rc = sq_alloc(h, (size_t)32, &p))) return rc; s.goverlap = p; }
   if ((rc = sq_alloc(h, (size_t)B * 32, &s.mvec))) return rc;
   if ((rc = sq_alloc(h, (size_t)B, &s.nonconv))) return rc;
+  if ((rc = sq_alloc(h, (size_t)B, &s.stalled))) return rc;
   s.G = 0;
   { int *p; if ((rc = sq_alloc(h, (size_t)d, &p))) return rc; s.epos = p;
     SCO_HIP(hipMemcpy(p, epos.data(), d * sizeof(int), hipMemcpyHostToDevice)); }
@@ -1440,6 +1445,14 @@ extern "C" int sco_sqp_fetch_groups(sco_sqp *h, unsigned int *nonconverged) {
   if (!h->solved) { sco_set_error("sco_sqp_fetch_groups: call sco_sqp_solve first"); return SCO_ERR_STATE; }
   SCO_ON_DEVICE(h->device);
   SCO_HIP(hipMemcpy(nonconverged, h->d.nonconv, (size_t)h->d.batch * sizeof(unsigned int), hipMemcpyDeviceToHost));
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_fetch_stalled_groups(sco_sqp *h, unsigned int *stalled) {
+  if (!h || !stalled) return SCO_ERR_ARG;
+  if (!h->solved) { sco_set_error("sco_sqp_fetch_stalled_groups: call sco_sqp_solve first"); return SCO_ERR_STATE; }
+  SCO_ON_DEVICE(h->device);
+  SCO_HIP(hipMemcpy(stalled, h->d.stalled, (size_t)h->d.batch * sizeof(unsigned int), hipMemcpyDeviceToHost));
   return SCO_OK;
 }
 

@@ -78,12 +78,48 @@ class QPBatchServer(object):
 
 
 def solve_many(probs, solver_factory=None, method="penalty_sqp", **solve_kwargs):
-    """``[Solver().solve(p, method=..., **solve_kwargs) for p in probs]`` with the QP solves
-    of all problems batched on the GPU.  Returns (list of return values, server stats)."""
+    """``[Solver().solve(p, method=..., **solve_kwargs) for p in probs]`` for many problems at once.  Returns
+    (list of return values, stats).
+
+    Problems the device can evaluate itself (``compile.compile_prob``: every non-linear expression a
+    ``devexpr.DeviceExpr``) are bucketed by structure and each bucket runs as ONE batch of the device-resident loop
+    (``sco_sqp_*``): no Python inside the solve.  The rest keep the per-problem host loop in threads with their QP solves
+    batched on the GPU (below).  stats: ``device_problems`` / ``device_batches`` / ``compile_s`` / ``device_solve_s`` /
+    ``write_back_s`` for the first kind, ``device_launches`` / ``qps`` for the second."""
+    import time
     from .solver import Solver
+    from . import compile as sco_compile
     factory = solver_factory or Solver
-    server = QPBatchServer(len(probs))
+    if method != "penalty_sqp":
+        raise Exception("This method is not supported.")
     out = [None] * len(probs)
+    stats = dict(device_problems=0, device_batches=0, compile_s=0.0, device_solve_s=0.0, device_launches=0, qps=0)
+    lead = factory()
+    if solve_kwargs.get("tol") is not None:                 # Q8, as Solver.solve does it
+        lead.min_trust_region_size = lead.min_approx_improve = lead.cnt_tolerance = solve_kwargs["tol"]
+    host = list(range(len(probs)))
+    if lead.device_loop and lead._runs_reference_control_flow():
+        t0 = time.perf_counter()
+        buckets, host = {}, []
+        for k, p in enumerate(probs):
+            cp = sco_compile.compile_prob(p)
+            if cp is None:
+                host.append(k)
+            else:
+                buckets.setdefault(cp.key, []).append((k, cp))
+        stats["compile_s"] = time.perf_counter() - t0
+        kw = {k: v for k, v in solve_kwargs.items() if k not in ("tol", "verbose")}
+        for items in buckets.values():
+            t0 = time.perf_counter()
+            res = lead._solve_compiled([probs[k] for k, _ in items], [c for _, c in items], **kw)
+            stats["device_solve_s"] += time.perf_counter() - t0
+            for (k, _), r in zip(items, res):
+                out[k] = r
+            stats["device_problems"] += len(items); stats["device_batches"] += 1
+        stats["last_device"] = lead.last_device
+    if not host:
+        return out, stats
+    server = QPBatchServer(len(host))
     errors = [None] * len(probs)
 
     def run(k):
@@ -96,7 +132,7 @@ def solve_many(probs, solver_factory=None, method="penalty_sqp", **solve_kwargs)
             _local.server = None
             server.worker_done()
 
-    threads = [threading.Thread(target=run, args=(k,), daemon=True) for k in range(len(probs))]
+    threads = [threading.Thread(target=run, args=(k,), daemon=True) for k in host]
     for t in threads:
         t.start()
     for t in threads:
@@ -104,4 +140,5 @@ def solve_many(probs, solver_factory=None, method="penalty_sqp", **solve_kwargs)
     for e in errors:
         if e is not None:
             raise e
-    return out, dict(device_launches=server.launches, qps=server.qps)
+    stats["device_launches"] = server.launches; stats["qps"] = server.qps
+    return out, stats

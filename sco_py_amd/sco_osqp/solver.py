@@ -80,7 +80,8 @@ def classify_trial(trial, thr, group_index, group_overlap, group_order, predicat
             continue                         # a group sharing a constraint with it is still making progress
         stalled.append(gid)
     if stalled:
-        under = [g for k, g in enumerate(group_order) if violated[k] and per_group[k] < thr.min_approx_improve]
+        # the report uses the overridable predicate (solver.py:233), the stall test above the raw threshold (:213-221)
+        under = [g for k, g in enumerate(group_order) if violated[k] and y_converged(per_group[k])]
         return verdict(STEP_GROUP, stalled, stalled + under)
 
     if shrink(exact, ratio):
@@ -104,6 +105,11 @@ class Solver(object):
         self.initial_trust_region_size = 1
         self.initial_penalty_coeff = 1e3
         self.trace = []
+        # not in the reference: False keeps every solve on the host loop; last_path says where the last solve ran
+        # ("device": the resident loop, "host"); last_device has the device loop's round count and stage times
+        self.device_loop = True
+        self.last_path = None
+        self.last_device = None
 
     # ------------------------------------------------------------------ public entry
     def solve(self,
@@ -124,8 +130,57 @@ class Solver(object):
             self.min_trust_region_size = self.min_approx_improve = self.cnt_tolerance = tol
         if method != "penalty_sqp":
             raise Exception("This method is not supported.")
+        qp_kw = dict(osqp_eps_abs=osqp_eps_abs, osqp_eps_rel=osqp_eps_rel, osqp_max_iter=osqp_max_iter, rho=rho,
+                     adaptive_rho=adaptive_rho, sigma=sigma)
+        if self.device_loop and self._runs_reference_control_flow():
+            # a Prob whose non-linear expressions are device expressions runs the WHOLE solve in the device-resident
+            # loop (sco_sqp_*); anything else keeps the host loop below with one device QP per optimize
+            from . import compile as sco_compile
+            cp = sco_compile.compile_prob(prob)
+            if cp is not None:
+                return self._solve_compiled([prob], [cp], verbose=verbose, **qp_kw)[0]
+        self.last_path = "host"
         return self._penalty_sqp(prob, verbose=verbose, osqp_eps_abs=osqp_eps_abs, osqp_eps_rel=osqp_eps_rel,
                                  osqp_max_iter=osqp_max_iter, rho=rho, adaptive_rho=adaptive_rho, sigma=sigma)
+
+    # ------------------------------------------------------------------ device-resident loop
+    def _runs_reference_control_flow(self):
+        """The device loop implements the reference's decisions (csrc/sco_sqp.hip: sqp_post_kernel); a subclass that
+        overrides a predicate or a stage keeps the host loop, where its override is called."""
+        return all(getattr(type(self), name) is getattr(Solver, name) for name in (
+            "_penalty_sqp", "_min_merit_fn", "_bad_model", "_shrink_trust_region", "_x_converged", "_y_converged"))
+
+    def device_params(self):
+        """``sco_sqp_params`` from this instance's attributes (one-to-one, include/sco_hip.h)."""
+        from .. import _lib
+        return _lib.default_sqp_params(
+            improve_ratio_threshold=self.improve_ratio_threshold, min_trust_region_size=self.min_trust_region_size,
+            min_approx_improve=self.min_approx_improve, trust_shrink_ratio=self.trust_shrink_ratio,
+            trust_expand_ratio=self.trust_expand_ratio, cnt_tolerance=self.cnt_tolerance,
+            merit_coeff_increase_ratio=self.merit_coeff_increase_ratio,
+            initial_trust_region_size=self.initial_trust_region_size, initial_penalty_coeff=self.initial_penalty_coeff,
+            max_merit_coeff_increases=int(self.max_merit_coeff_increases))
+
+    def _solve_compiled(self, probs, cps, verbose=False, osqp_eps_abs=osqp_utils.DEFAULT_EPS_ABS,
+                        osqp_eps_rel=osqp_utils.DEFAULT_EPS_REL, osqp_max_iter=osqp_utils.DEFAULT_MAX_ITER,
+                        rho=osqp_utils.DEFAULT_RHO, adaptive_rho=osqp_utils.DEFAULT_ADAPTIVE_RHO,
+                        sigma=osqp_utils.DEFAULT_SIGMA, device=0):
+        """Compiled problems of ONE structure as one device batch (solver.py:30-253 per problem); results go back into
+        the Prob / Variable objects.  Returns the list of ``solve`` return values."""
+        from .. import _lib
+        from . import compile as sco_compile
+        qs = _lib.default_qp_settings(eps_abs=osqp_eps_abs, eps_rel=osqp_eps_rel, max_iter=int(osqp_max_iter), rho=rho,
+                                      adaptive_rho=1 if adaptive_rho else 0, sigma=sigma)
+        res = sco_compile.run_compiled(cps, self.device_params(), qs, device=device)
+        out = [sco_compile.write_back(p, c, res, b) for b, (p, c) in enumerate(zip(probs, cps))]
+        # same rows as the host loop's trace: (code, merit, model_merit, new_merit, trust, penalty)
+        self.trace = [tuple([int(r[0])] + [float(v) for v in r[1:6]]) for r in res.trace[-1]]
+        self.last_path = "device"
+        self.last_device = dict(res.timing, batch=len(probs), sqp_iters=res.sqp_iters.copy(), qp_solves=res.qp_solves.copy(),
+                                admm_iters=res.admm_iters.copy(), flags=res.flags.copy(), traces=res.trace)
+        if verbose:
+            print("device-resident penalty sqp: %d problem(s), %d rounds, %.3f ms" % (len(probs), res.timing["rounds"], res.timing["total_ms"]))
+        return out
 
     # ------------------------------------------------------------------ outer loop
     def _penalty_sqp(self, prob, verbose=False, **qp_kw):

@@ -9,9 +9,14 @@ import numpy as np
 from oracle import arm_family as af
 
 
-def build_prob(mods, pr, analytic_jac=False):
+def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
     """mods: namespace with Expr, AffExpr, QuadExpr, EqExpr, LEqExpr, BoundExpr,
-    Variable, OSQPVar, Prob.  pr: dict from oracle.arm_family.make_problem."""
+    Variable, OSQPVar, Prob.  pr: dict from oracle.arm_family.make_problem.
+    device_exprs (mirror API only): the non-linear expressions are sco_py_amd.devexpr classes -- the same functions as the
+    closures below, as Expr objects the device can evaluate itself, so that plain Solver().solve(prob) runs the resident loop."""
+    dx = None
+    if device_exprs:
+        from sco_py_amd import devexpr as dx
     d, T = pr["d"], pr["T"]
     n_x = d * T
     prob = mods.Prob()
@@ -76,6 +81,8 @@ def build_prob(mods, pr, analytic_jac=False):
                 def grad(x, pr=pr, rows=rows):
                     return pr["row_program"].jacobian(x.ravel(), pr["row_params"], rows)
                 e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
+                if dx is not None:
+                    e = dx.ProgramExpr(prog, pr["row_params"], rows=rows, analytic=analytic_jac)
                 prob.add_cnt_expr(mods.BoundExpr(cls(e, np.zeros((len(rows), 1))), sv), gids)
     if pr.get("quad_n_eq"):
         # quadratic rows with equality rows (r03): per timestep one LEqExpr and one EqExpr (val 0) on the same Variable
@@ -91,6 +98,8 @@ def build_prob(mods, pr, analytic_jac=False):
                 def grad(x, pr=pr, sl=sl):
                     return af.quad_rows_jac(x.ravel(), pr["quad_Q"][sl], pr["quad_a"][sl], pr["quad_c"][sl])
                 e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
+                if dx is not None:
+                    e = dx.QuadRowsExpr(pr["quad_Q"][sl], pr["quad_a"][sl], pr["quad_c"][sl], analytic=analytic_jac)
                 prob.add_cnt_expr(mods.BoundExpr(cls(e, np.zeros((len(range(R)[sl]), 1))), sv), gids)
         wide = True
     for t in range(0 if wide else T):
@@ -119,6 +128,11 @@ def build_prob(mods, pr, analytic_jac=False):
                 return af.arm_dist_jac(x.ravel(), pr["link_len"], pr["point_link"], pr["point_frac"],
                                        pr["obstacles"])
         e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
+        if dx is not None:
+            e = (dx.ProgramExpr(pr["row_program"], pr["row_params"], analytic=analytic_jac) if pr.get("row_program") is not None else
+                 dx.QuadRowsExpr(pr["quad_Q"], pr["quad_a"], pr["quad_c"], analytic=analytic_jac) if pr.get("quad_Q") is not None else
+                 dx.PointCirclesExpr(pr["obstacles"], analytic=analytic_jac) if pr.get("point") else
+                 dx.ArmCirclesExpr(pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"], analytic=analytic_jac))
         gids = pr["groups"][t] if pr.get("groups") is not None else None
         prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(e, np.zeros((R, 1))), sv), gids)
     if prog is not None and prog.objective:
@@ -126,14 +140,15 @@ def build_prob(mods, pr, analytic_jac=False):
         for t in range(T):
             def fo(x, pr=pr):
                 return np.array([[pr["row_program"].evaluate(x.ravel(), pr["row_params"], rows=[pr["row_program"].n_rows])[0]]])
-            prob.add_obj_expr(mods.BoundExpr(mods.Expr(fo), step_vars[t]))
+            prob.add_obj_expr(mods.BoundExpr(dx.ProgramObjExpr(prog, pr["row_params"]) if dx is not None else mods.Expr(fo), step_vars[t]))
     if pr.get("cost_weight") is not None:
         # non-quadratic objective terms, one Expr per timestep Variable: numeric gradient and Hessian, degree-2
         # convexification with the eigenvalue shift (expr.py:102-156; prob.py:88-104)
         for t in range(T):
             def fc(x, pr=pr):
                 return np.array([[af.ee_cost(x.ravel(), pr["link_len"], pr["cost_target"], pr["cost_weight"])]])
-            prob.add_obj_expr(mods.BoundExpr(mods.Expr(fc), step_vars[t]))
+            prob.add_obj_expr(mods.BoundExpr(dx.ArmEECostExpr(pr["link_len"], pr["cost_target"], pr["cost_weight"]) if dx is not None
+                                             else mods.Expr(fc), step_vars[t]))
     if reach:
         # end-effector target as a non-linear equality on the last timestep (abs penalty, prob.py:280-315)
         def fe(x, pr=pr):
@@ -142,6 +157,8 @@ def build_prob(mods, pr, analytic_jac=False):
         def ge(x, pr=pr):
             return af.ee_jac(x.ravel(), pr["link_len"])
         e = mods.Expr(fe, ge) if analytic_jac else mods.Expr(fe)
+        if dx is not None:
+            e = dx.ArmReachExpr(pr["link_len"], analytic=analytic_jac)
         gids = pr["groups"][T] if pr.get("groups") is not None else None
         prob.add_cnt_expr(mods.BoundExpr(mods.EqExpr(e, pr["target"].reshape(-1, 1)), step_vars[-1]), gids)
     return prob, traj, step_vars, atoms
