@@ -189,6 +189,63 @@ def _cpu_share():
     return None
 
 
+def build_arm_prob(pr):
+    """One problem record of the 7x20 workload as a ``Prob`` of the reference's object API (the construction a sco_py
+    caller writes: OSQPVar atoms, a trajectory Variable, QuadExpr objective, EqExpr pins, one LEqExpr block per timestep
+    -- tests/trajopt_build.py is the same code), with device expressions as the constraint bodies."""
+    from sco_py_amd import devexpr as dx, expr as ex
+    from sco_py_amd.sco_osqp import osqp_utils as ou, prob as pb, variable as vr
+    d, T = pr["d"], pr["T"]
+    n_x = d * T
+    prob = pb.Prob()
+    atoms = np.empty((n_x, 1), dtype=object)
+    for t in range(T):
+        for j in range(d):
+            atoms[t * d + j, 0] = ou.OSQPVar("q%03d_%02d" % (t, j))
+            prob.add_osqp_var(atoms[t * d + j, 0])
+    traj = vr.Variable(atoms, pr["x0"].reshape(n_x, 1))
+    prob.add_var(traj)
+    Q = np.zeros((n_x, n_x))
+    i = np.arange(n_x - d)
+    Q[i, i] += 2.0; Q[i + d, i + d] += 2.0; Q[i, i + d] -= 2.0; Q[i + d, i] -= 2.0
+    prob.add_obj_expr(ex.BoundExpr(ex.QuadExpr(Q, np.zeros((1, n_x)), np.zeros((1, 1))), traj))
+    pins = np.zeros((2 * d, n_x))
+    pins[np.arange(d), np.arange(d)] = 1.0; pins[d + np.arange(d), (T - 1) * d + np.arange(d)] = 1.0
+    prob.add_cnt_expr(ex.BoundExpr(ex.EqExpr(ex.AffExpr(pins, np.zeros((2 * d, 1))),
+                                             np.concatenate([pr["start"], pr["goal"]]).reshape(-1, 1)), traj))
+    R = pr["K"] * pr["O"]
+    for t in range(T):
+        sv = vr.Variable(atoms[t * d:(t + 1) * d, :], pr["x0"][t * d:(t + 1) * d].reshape(d, 1))
+        e = dx.ArmCirclesExpr(pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"])
+        prob.add_cnt_expr(ex.BoundExpr(ex.LEqExpr(e, np.zeros((R, 1))), sv))
+    return prob, traj
+
+
+def object_api_line(B, array_step_s):
+    """aux.object_api_1024: B Probs -> solve_many.  Reports the Python construction, the compile step, and the solve
+    (device solve + fetch: the part bench.py times as a step of the array API) separately."""
+    from sco_py_amd import workloads as af
+    from sco_py_amd.sco_osqp import batching
+    t0 = time.perf_counter()
+    built = [build_arm_prob(af.make_problem(i)) for i in range(B)]
+    build_s = time.perf_counter() - t0
+    probs = [b[0] for b in built]
+    t0 = time.perf_counter()
+    oks, stats = batching.solve_many(probs)
+    total_s = time.perf_counter() - t0
+    tm = stats["last_device"]
+    host_evals = sum(be.expr.expr.host_evals for p in probs for be in p._nonlin_cnt_exprs)
+    return {"workload": "the %d problems of the headline batch as %d Prob objects (Variable / BoundExpr / LEqExpr on device "
+                        "expressions), solve_many -> compile_prob -> one device batch; parity mode" % (B, B),
+            "build_probs_s": build_s, "compile_s": stats["compile_s"], "upload_s": tm["load_s"],
+            "solve_fetch_s": tm["solve_fetch_s"], "trace_s": tm["trace_s"], "solve_many_total_s": total_s,
+            "array_api_step_s": array_step_s, "solve_vs_array_api": tm["solve_fetch_s"] / array_step_s,
+            "sco_iters_per_s_solve": float(tm["sqp_iters"].sum()) / tm["solve_fetch_s"],
+            "sco_iters_per_s_incl_compile_and_write_back": float(tm["sqp_iters"].sum()) / total_s,
+            "device_problems": stats["device_problems"], "device_batches": stats["device_batches"],
+            "python_f_calls": int(host_evals), "success_fraction": float(np.mean(oks))}
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -221,6 +278,8 @@ def main():
     ap.add_argument("--aux-12x50", type=int, default=2048,
                     help="batch of the 12-DOF x 50 line reported under aux in a default 7x20 run (0 = skip)")
     ap.add_argument("--aux-b4096", type=int, default=1, help="also report a 4096-problem 7x20 step under aux (0 = skip)")
+    ap.add_argument("--aux-object-api", type=int, default=1,
+                    help="also solve the 1024 problems as 1024 Prob objects through solve_many, reported under aux (0 = skip)")
     ap.add_argument("--intended", action="store_true",
                     help="disable reference quirks Q1/Q2 (NOT the headline number)")
     ap.add_argument("--beyond", action="store_true",
@@ -399,6 +458,15 @@ def main():
         except Exception as e:                                  # pragma: no cover
             aux4096 = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    aux_obj = None
+    if world == 1 and not big and B == 1024 and not (args.intended or args.beyond) and args.aux_object_api:
+        # the reference's OBJECT API on the same 1024 problems: one Prob per problem built from Variable / BoundExpr
+        # objects (device expressions), all of them through solve_many -> compile_prob -> ONE device batch
+        try:
+            aux_obj = object_api_line(1024, r["elapsed"] / args.steps)
+        except Exception as e:                                  # pragma: no cover
+            aux_obj = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         dims = r["dims"]
         out = {
@@ -436,6 +504,8 @@ def main():
             out["aux"]["config4_12x50"] = aux12
         if aux4096 is not None:
             out["aux"]["batch_4096"] = aux4096
+        if aux_obj is not None:
+            out["aux"]["object_api_1024"] = aux_obj
         if world == 1 and args.cpu_problems > 0:
             v, dt, it = cpu_baseline(args.cpu_problems, 0, dims)
             out["cpu_baseline"] = {"value": v, "unit": "sco_iters/s", "cores": 1, "kind": "port",
