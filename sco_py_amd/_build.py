@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libsco_hip.so")
-SOURCES = ["sco_qp.hip", "sco_admm_fast.hip", "sco_admm_reg.hip", "sco_admm_rl.hip", "sco_qp_big.hip", "sco_sqp.hip", "qp_plan.cpp"]
+SOURCES = ["sco_qp.hip", "sco_admm_fast.hip", "sco_admm_reg.hip", "sco_admm_rl.hip", "sco_admm_wv.hip", "sco_qp_big.hip", "sco_sqp.hip", "qp_plan.cpp"]
 HEADERS = ["sco_internal.h", "qp_plan.h", os.path.join("..", "..", "include", "sco_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 

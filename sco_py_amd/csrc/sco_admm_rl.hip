@@ -505,6 +505,7 @@ struct RlArgs {
   int totAc, totAr[LNS_MAX];
   const double *As, *W, *qs, *kee_inv, *ls, *us, *rho, *cscale, *Ps, *D, *E;
   const int *w, *active;
+  const int *skip;   // or null: skip[b] != 0 = the wavefront tier solves this problem
   double *x, *y, *resid;
   int *status, *iters;
   int warm;          // start from the previous (unscaled) solution held in x / y instead of zero
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(LT) void qp_admm_rl_kernel(RlArgs a) {
   constexpr bool L8 = LAY != 0, AL = LAY == 2;
   static_assert(!L8 || (TR == AL_TR && TC == AL_TC && NS == 2), "8-column-group layout: 3 x 18 tiles, two row slots");
   const int b = a.list ? a.list[blockIdx.x + a.b0] : (int)blockIdx.x + a.b0, tid = threadIdx.x;
-  if (b < 0 || (a.active && !a.active[b])) return;
+  if (b < 0 || (a.active && !a.active[b]) || (a.skip && a.skip[b])) return;
   const int n = a.n, m = a.m, n_e = a.n_e, n_c = a.n_c;
 
   // row vectors are indexed by the planner's LDS position of a row (rl_plan_build), core vectors by core index;
@@ -1514,7 +1515,7 @@ int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t 
   ra.As = d.As; ra.W = d.W; ra.qs = d.qs; ra.kee_inv = d.kee_inv; ra.ls = d.ls; ra.us = d.us; ra.rho = d.rho;
   ra.cscale = d.cscale; ra.Ps = d.Ps; ra.D = d.D; ra.E = d.E; ra.w = d.w; ra.active = d.active;
   ra.x = d.x; ra.y = d.y; ra.resid = d.resid; ra.status = d.status; ra.iters = d.iters;
-  ra.warm = a.warm;
+  ra.warm = a.warm; ra.skip = a.skip;
   ra.slice = a.slice; ra.prog = d.prog;
   ra.ad_interval = a.adaptive ? a.ad_interval : 0; ra.ad_tol = a.ad_tol;
   ra.rho_b = d.rho_b; ra.rflag = d.rflag; ra.smask = d.smask; ra.nupd = d.nupd; ra.sx = d.sx; ra.sz = d.sz; ra.sy = d.sy; ra.st = d.st; ra.sg = d.sg;

@@ -99,6 +99,7 @@ struct AdmmArgs {
                 // parks with the new rho in d.rho_b[b] and d.smask[b] = d.rflag[b] = 1
   int ad_interval;
   double ad_tol;
+  const int *skip;   // or null: problems with skip[b] != 0 are left alone (the wavefront tier has taken them)
 };
 
 bool fast_plan_build(const QpPlan &pl, FastHost &fh);
@@ -142,6 +143,23 @@ bool rl_plan_build(const QpPlan &pl, RlHost &rh);
 int rl_upload(const RlHost &rh, std::vector<void *> &allocs, RlDev &rd);
 int rl_launch(const AdmmArgs &a, const RlHost &rh, const RlDev &rd, hipStream_t st);
 
+// ---- wavefront tier (sco_admm_wv.hip): one wavefront per problem, block-tridiagonal core solve, four problems per CU
+struct WvHost {
+  int bs = 0, nb = 0, mid = 0, lpb = 0, n_extra = 0;    // block order, blocks, middle block, lanes per block, second single rows
+  int BS = 8, NS = 1, NV = 1, NSTEP = 4;                 // instantiation: mat-vec width, hinge-row / variable slots per lane, sweep steps
+  int cst_slots = 0;
+  size_t g_doubles = 0, lds_doubles = 0, lds_bytes = 0;
+  std::vector<int> tab;                                  // lane tables (wv_tab_layout)
+};
+// G: [batch][g_doubles] factor (pivot inverses, couplings); cst: [batch][cst_slots][64] constants of the termination test;
+// wc: [batch] common weight of the hinge rows; ok: [batch] 1 = the problem's values have the penalty-QP structure (else the
+// row-local kernel solves it: rl_need = its setup mask); scr: [batch][m + n] delta_y / delta_x of the last checked iteration
+struct WvDev { const int *tab; double *G, *cst, *wc, *scr; int *ok, *rl_need; };
+bool wv_plan_build(const QpPlan &pl, WvHost &wh);
+int wv_upload(const WvHost &wh, int batch, int n, int m, std::vector<void *> &allocs, WvDev &wd);
+int wv_launch_factor(const AdmmArgs &a, const int *setup_mask, const WvHost &wh, const WvDev &wd, hipStream_t st);
+int wv_launch(const AdmmArgs &a, const WvHost &wh, const WvDev &wd, hipStream_t st);
+
 // ---- big tier (sco_qp_big.hip): everything in HBM/L2, 1024 threads per problem
 struct BigHost {
   std::vector<int> row_elim, row_epos, er_ptr, er_row, free_rows, pc_ptr, pc_pos, pc_core;
@@ -182,6 +200,9 @@ struct sco_qp {
   RlHost rl;
   RlDev rld{};
   bool use_rl = false;
+  WvHost wv;
+  WvDev wvd{};
+  bool use_wv = false;
   RegHost reg;
   RegDev regd{};
   bool use_reg = false;

@@ -950,6 +950,18 @@ static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const
     }
   }
   {
+    // wavefront tier (one wavefront per problem, block-tridiagonal core solve): patterns of trajectory penalty QPs; it
+    // needs the row-local tier beside it for problems whose values leave the penalty-QP structure, and for the opt-in
+    // extensions (warm start, adaptive rho), which stay on the row-local kernel
+    const char *no_wv = getenv("SCO_QP_NO_WV"), *yes_wv = getenv("SCO_QP_WV");
+    const bool want_wv = !(no_wv && no_wv[0] == '1') && (yes_wv && yes_wv[0] == '1');
+    if (qp->use_rl && !qp->factor_cholesky && want_wv && wv_plan_build(pl, qp->wv)) {
+      int r_ = wv_upload(qp->wv, batch, n, m, qp->allocs, qp->wvd);
+      if (r_) return r_;
+      qp->use_wv = true;
+    }
+  }
+  {
     const char *no_reg = getenv("SCO_QP_NO_REG");
     int CW = 0, RW = 0, PX = 0;
     if (!(no_reg && no_reg[0] == '1') && reg_caps_for(pl, &CW, &RW, &PX) && reg_plan_build(pl, CW, RW, PX, qp->reg)) {
@@ -1080,7 +1092,9 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
   SetupArgs sa{dsetup, qp->Pp_dev, qp->Pi_dev, st->rho, st->sigma, st->scaling, adaptive ? 1 : 0};
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
               st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0, slice,
-              adaptive ? 1 : 0, adaptive ? sco_qp_adaptive_interval(st) : 0, st->adaptive_rho_tolerance};
+              adaptive ? 1 : 0, adaptive ? sco_qp_adaptive_interval(st) : 0, st->adaptive_rho_tolerance, nullptr};
+  // the wavefront tier runs cold-start, fixed-rho solves (parity mode); the opt-in extensions keep the row-local kernel
+  const bool wv_now = qp->use_wv && !aa.warm && !adaptive && !st->warm_start;
   qp->solved_once = true;
   if (!grp) SCO_HIP(hipEventRecord(qp->ev[0], stream));
   if (adaptive && setup_mask != SCO_MASK_NONE) {
@@ -1102,6 +1116,12 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
     const size_t ntri = (size_t)d.n_c * (d.n_c + 1) / 2;
     hipLaunchKernelGGL(qp_setup_kernel, dim3(nwg), dim3(SCO_BLOCK), qp->lds_setup - ntri * sizeof(double), stream, sa);
     SCO_HIP(hipGetLastError());
+    if (wv_now) {
+      // twisted block factorisation + the value test; the dense inverse below then runs for the problems that failed it only
+      int r_ = wv_launch_factor(aa, dsetup.active, qp->wv, qp->wvd, stream);
+      if (r_) return r_;
+      dsetup.active = qp->wvd.rl_need;
+    }
     if (qp->factor_cholesky)
       hipLaunchKernelGGL(qp_factor_kernel, dim3(d.batch), dim3(SCO_FACTOR_BLOCK), (ntri + d.n_c) * sizeof(double), stream, dsetup);
     else {
@@ -1115,6 +1135,11 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
   if (!grp) SCO_HIP(hipEventRecord(qp->ev[1], stream));
   if (mid) SCO_HIP(hipEventRecord(mid, stream));
   if (kern == K_RL) {
+    if (wv_now) {
+      int r_ = wv_launch(aa, qp->wv, qp->wvd, stream);
+      if (r_) return r_;
+      aa.skip = qp->wvd.ok;                      // the row-local kernel takes what the wavefront tier has left
+    }
     int r_ = rl_launch(aa, qp->rl, qp->rld, stream);
     if (r_) return r_;
   } else if (kern == K_REG) {
@@ -1234,6 +1259,21 @@ extern "C" int sco_debug_rl_plan(int *info) {
   const bool ok = rl_plan_build(g_dbg_plan, rh);
   info[0] = ok ? 1 : 0; info[1] = rh.CW; info[2] = rh.TR; info[3] = rh.TC; info[4] = (int)rh.lds_bytes; info[5] = rh.merged ? 1 : 0; info[6] = rh.aligned ? 1 : rh.lay8 ? 2 : 0; info[7] = rh.NS;
   return SCO_OK;
+}
+// Host-only: would that pattern land on the wavefront tier?  info[0] fits, [1] block order, [2] blocks, [3] lanes per block,
+// [4] instantiation BS, [5] NS, [6] NV, [7] NSTEP, [8] LDS bytes, [9] second single rows
+extern "C" int sco_debug_wv_plan(int *info) {
+  WvHost wh;
+  const bool ok = wv_plan_build(g_dbg_plan, wh);
+  info[0] = ok ? 1 : 0; info[1] = wh.bs; info[2] = wh.nb; info[3] = wh.lpb; info[4] = wh.BS; info[5] = wh.NS; info[6] = wh.NV;
+  info[7] = wh.NSTEP; info[8] = (int)wh.lds_bytes; info[9] = wh.n_extra;
+  return SCO_OK;
+}
+// Which ADMM tiers a handle holds: bit 0 row-local, 1 register-offset, 2 sliced-ELL, 3 global memory, 4 its structured form,
+// 5 wavefront tier
+extern "C" int sco_debug_qp_tiers(const sco_qp *qp) {
+  if (!qp) return SCO_ERR_ARG;
+  return (qp->use_rl ? 1 : 0) | (qp->use_reg ? 2 : 0) | (qp->use_fast ? 4 : 0) | (qp->use_big ? 8 : 0) | (qp->use_bt ? 16 : 0) | (qp->use_wv ? 32 : 0);
 }
 extern "C" int sco_debug_plan_get(const char *name, int *out, int cap) {
   const QpPlan &p = g_dbg_plan;
