@@ -953,8 +953,8 @@ static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const
     // wavefront tier (one wavefront per problem, block-tridiagonal core solve): patterns of trajectory penalty QPs; it
     // needs the row-local tier beside it for problems whose values leave the penalty-QP structure, and for the opt-in
     // extensions (warm start, adaptive rho), which stay on the row-local kernel
-    const char *no_wv = getenv("SCO_QP_NO_WV"), *yes_wv = getenv("SCO_QP_WV");
-    const bool want_wv = !(no_wv && no_wv[0] == '1') && (yes_wv && yes_wv[0] == '1');
+    const char *no_wv = getenv("SCO_QP_NO_WV");
+    const bool want_wv = !(no_wv && no_wv[0] == '1');
     if (qp->use_rl && !qp->factor_cholesky && want_wv && wv_plan_build(pl, qp->wv)) {
       int r_ = wv_upload(qp->wv, batch, n, m, qp->allocs, qp->wvd);
       if (r_) return r_;
