@@ -179,7 +179,7 @@ bool wv_plan_build(const QpPlan &pl, WvHost &wh) {
   wh.lds_doubles = wh.g_doubles + 4 * (size_t)npos * 8 + (size_t)wh.NS * 512 + (size_t)npos * lpb * 8;
   wh.lds_bytes = wh.lds_doubles * sizeof(double);
   wh.cst_slots = 6 * wh.NS + 14 * wh.NV + 2;
-  return wh.lds_bytes <= (wh.NSTEP == 10 ? 40 : 64) * 1024;
+  return wh.lds_bytes <= 64 * 1024;     // (<= 40 KB: four problems per CU, the 7 x 20 shapes; more LDS = fewer per CU)
 }
 
 int wv_upload(const WvHost &wh, int batch, int n, int m, std::vector<void *> &allocs, WvDev &wd) {

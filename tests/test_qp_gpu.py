@@ -574,3 +574,66 @@ def test_split_and_unsplit_column_plans_give_the_same_answer(gpu, monkeypatch):
         alt = _check(probs)
         assert np.array_equal(base[2], alt[2]) and np.array_equal(base[3], alt[3])
         assert np.abs(base[1] - alt[1]).max() < 1e-10
+
+
+def _tiers(n, m, Pp, Pi, Ap, Ai):
+    import ctypes as C
+    lib = _lib.load()
+    lib.sco_debug_qp_tiers.restype = C.c_int; lib.sco_debug_qp_tiers.argtypes = [C.c_void_p]
+    qp = _lib.BatchedQP(1, n, m, Pp, Pi, Ap, Ai)
+    try:
+        return lib.sco_debug_qp_tiers(qp._h)
+    finally:
+        qp.close()
+
+
+@pytest.mark.parametrize("shape", [(6, 3, 4), (8, 2, 3), (9, 5, 6), (20, 7, 10), (12, 7, 10), (30, 4, 5)])
+def test_wavefront_tier_agrees_with_the_row_local_tier_and_the_oracle(gpu, monkeypatch, shape):
+    """r04: csrc/sco_admm_wv.hip -- one wavefront per problem, twisted block-tridiagonal core solve instead of the dense
+    inverse.  Same statuses and iteration counts as the row-local kernel and as the oracle, answers within 1e-10 of the
+    former; row weights, second pins, every instantiation (<7,4,3,10> at 7 x 20 and 7 x 12, <8,1,1,4>, <8,2,2,8>, <8,4,4,16>)."""
+    T, d, r = shape
+    rng = np.random.default_rng(100 + T)
+    probs = [penalty_qp(rng, T, d, r) for _ in range(6)]
+    m = len(probs[0][3])
+    w = np.ones((6, m), dtype=np.int32); w[:, d:d + T * r] = rng.integers(1, 4, size=(6, 1))
+    n, m, Pp, Pi, Ap, Ai, *_ = _stack(probs)
+    assert _tiers(n, m, Pp, Pi, Ap, Ai) & 32, "pattern did not land on the wavefront tier"
+    _, x_wv, st_wv, it_wv = _check(probs, w=w, check=range(3))
+    monkeypatch.setenv("SCO_QP_NO_WV", "1")
+    assert not _tiers(n, m, Pp, Pi, Ap, Ai) & 32
+    _, x_rl, st_rl, it_rl = _check(probs, w=w, check=[])
+    assert np.array_equal(st_wv, st_rl) and np.array_equal(it_wv, it_rl) and np.abs(x_wv - x_rl).max() < 1e-10
+
+
+def test_wavefront_tier_leaves_odd_value_structure_to_the_row_local_kernel(gpu, monkeypatch):
+    """The tier's kernel assumes the VALUES of a penalty QP (hinge rows l = -inf with one weight, slack rows [0, inf), box
+    rows on the base rho).  Problems of a batch that do not have them -- a two-sided hinge row, a slack with an upper bound,
+    a box so narrow that OSQP gives it the equality rho, unequal weights -- are found by qp_wv_factor_kernel and solved by
+    the row-local kernel in the same launch sequence: statuses, iteration counts and answers of the whole batch = the
+    oracle's and = a run with the tier switched off."""
+    rng = np.random.default_rng(77)
+    T, d, r = 6, 3, 4
+    probs = [list(penalty_qp(rng, T, d, r)) for _ in range(6)]
+    nx = T * d; m = len(probs[0][3])
+    probs[1][3] = probs[1][3].copy(); probs[1][3][d + 2] = -3.0                     # hinge row with a finite lower bound
+    probs[2][4] = probs[2][4].copy(); probs[2][4][d + T * r + nx + 1] = 5.0         # slack row with an upper bound
+    lo, hi = probs[3][3].copy(), probs[3][4].copy()
+    mid = 0.5 * (lo[d + T * r + 4] + hi[d + T * r + 4]); lo[d + T * r + 4] = mid - 2e-5; hi[d + T * r + 4] = mid + 2e-5
+    probs[3][3], probs[3][4] = lo, hi                                                # box narrower than 1e-4: rho_eq
+    probs = [tuple(p) for p in probs]
+    w = np.ones((6, m), dtype=np.int32); w[:, d:d + T * r] = 2; w[4, d + 1] = 3       # problem 4: unequal hinge weights
+    _, x_wv, st_wv, it_wv = _check(probs, w=w)
+    monkeypatch.setenv("SCO_QP_NO_WV", "1")
+    _, x_rl, st_rl, it_rl = _check(probs, w=w, check=[])
+    assert np.array_equal(st_wv, st_rl) and np.array_equal(it_wv, it_rl) and np.abs(x_wv - x_rl).max() < 1e-10
+
+
+def test_wavefront_tier_time_slices_and_max_iter(gpu):
+    """Parked and resumed solves (sco_qp_settings.max_iter cut into slices by the SQP loop is covered in test_sqp_gpu.py);
+    here: a solve that stops on max_iter between two termination checks, and one with check_termination off."""
+    rng = np.random.default_rng(5)
+    probs = [penalty_qp(rng, 20, 7, 10) for _ in range(4)]
+    for kw in (dict(max_iter=60), dict(max_iter=333), dict(max_iter=500, check_termination=0)):
+        st = _lib.default_qp_settings(**kw)
+        _check(probs, settings=st, **kw)

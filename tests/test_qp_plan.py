@@ -139,3 +139,35 @@ def test_which_device_families_land_on_the_row_local_tier(name, kw, cw):
     assert lib.sco_debug_rl_plan(ip(info)) == 0
     assert bool(info[0]) == fits, (name, info)
     assert info[1] == cw and info[2] == 5 and info[4] + 40 * 1024 <= 160 * 1024
+
+
+@pytest.mark.parametrize("name,kw,want", [
+    ("circles 7x20", {}, (1, 7, 20, 3, 7, 4, 3, 10)), ("circles 3x6", dict(d=3, T=6, K=2, O=2), (1, 3, 6, 8, 8, 1, 1, 4)),
+    ("objective terms", dict(ee_cost_weight=1.0), (1, 7, 20, 3, 7, 4, 3, 10)),
+    ("point robot", dict(d=2, T=8, O=3, point=True), (1, 2, 8, 8, 8, 1, 1, 4)),
+    ("7-DOF x 12", dict(T=12), (1, 7, 12, 5, 7, 4, 3, 10)), ("4-DOF x 24", dict(d=4, T=24, K=3, O=2), (1, 4, 24, 2, 8, 4, 4, 16)), ("5-DOF x 30: five row slots", dict(d=5, T=30), (0,)),
+    ("velocity limits", dict(vel_limit=0.3), (0,)), ("reach", dict(reach=True), (0,)), ("joint limits", dict(joint_limit=0.2), (0,)),
+    ("span-2 program", dict(d=2, T=8, K=1, program=True, variant="sweep"), (0,))])
+def test_which_penalty_qps_land_on_the_wavefront_tier(name, kw, want):
+    """Host-side plan of the wavefront tier (csrc/sco_admm_wv.hip: wv_plan_build): block-tridiagonal core with diagonal
+    couplings, every hinge row inside one timestep block with its own slack, at most two single rows per core variable.
+    info = fits, block order, blocks, lanes per block, instantiation <BS, NS, NV, NSTEP>.  Rows on two timesteps (velocity
+    limits, span-2 blocks), abs rows with a core slack (reach) and three single rows per variable (joint limits) stay on
+    the row-local tier."""
+    from oracle import arm_family as af
+    from oracle import sco_ref as sr
+    out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(0, **kw)), sr.SolverParams(max_qp_solves=2), record_qps=True)
+    q = out.qps[1]
+    P = sp.triu(sp.csc_matrix(q["P"] != 0), format="csc"); A = sp.csc_matrix(q["A"] != 0)
+    P.sort_indices(); A.sort_indices()
+    lib = _lib.load()
+    ip = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int))
+    Pp, Pi, Ap, Ai = (np.ascontiguousarray(a, dtype=np.int32) for a in (P.indptr, P.indices, A.indptr, A.indices))
+    sizes = np.zeros(16, dtype=np.int32); info = np.zeros(10, dtype=np.int32)
+    lib.sco_debug_plan_build.argtypes = [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4 + [C.c_int, C.POINTER(C.c_int)]
+    lib.sco_debug_wv_plan.argtypes = [C.POINTER(C.c_int)]
+    assert lib.sco_debug_plan_build(len(q["q"]), len(q["l"]), ip(Pp), ip(Pi), ip(Ap), ip(Ai), 1, ip(sizes)) == 0
+    assert lib.sco_debug_wv_plan(ip(info)) == 0
+    assert tuple(info[:len(want)]) == want, (name, info.tolist())
+    if want[0]:
+        assert info[8] <= (40 if info[2] == 20 else 64) * 1024        # LDS: four problems per CU at 7 x 20
