@@ -193,6 +193,8 @@ int wv_upload(const WvHost &wh, int batch, int n, int m, std::vector<void *> &al
   SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
   SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(int))); allocs.push_back(p); wd.rl_need = (int *)p;
   SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
+  SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(int))); allocs.push_back(p); wd.w_ready = (int *)p;
+  SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
   SCO_HIP(hipMalloc(&p, (size_t)batch * (size_t)(n + m) * sizeof(double))); allocs.push_back(p); wd.scr = (double *)p;
   return SCO_OK;
 }
@@ -206,12 +208,12 @@ struct WvArgs {
   int bs, nb, mid, lpb, n_extra, NS, NV, NSTEP, cst_slots; size_t g_doubles;
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   const int *tab;
-  double *G, *cst, *wc, *scr; int *ok, *rl_need;
+  double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready;
   const double *As, *Ps, *qs, *ls, *us, *rhov, *kee_inv, *cscale, *D, *E, *S;
   const int *w, *active, *setup_active;
   const int *Ap, *Ai, *Rp, *Rj, *Rpos, *Fp, *Fi, *Fpos;
   double *x, *y, *resid; int *status, *iters, *prog;
-  double *sx, *sz, *sy;
+  double *sx, *sz, *sy, *st, *sg;
   int ablate;        // diagnostic (SCO_WV_ABLATE): 1 = no sweeps, 2 = no row passes (timing only, results wrong)
 };
 
@@ -276,7 +278,8 @@ __global__ __launch_bounds__(WV_T) void qp_wv_factor_kernel(WvArgs a) {
     c[0] = xr >= 0 ? 1.0 / E[xr] : 0.0; c[64] = xr >= 0 ? E[xr] : 0.0;
   }
   bad = (int)wv_wmax((double)bad);
-  if (lane == 0) { a.ok[b] = !bad; a.rl_need[b] = bad; a.wc[b] = (double)wk; }
+  // (a failed value test: the dense inverse is formed right behind this kernel, so W will be ready)
+  if (lane == 0) { a.ok[b] = !bad; a.rl_need[b] = bad; a.w_ready[b] = bad; a.wc[b] = (double)wk; }
   if (bad) return;
   // ---- twisted block factorisation.  Lane (i, j) = (lane >> 3, lane & 7) holds entry (i, j) of the current 8 x 8 block
   // (entries beyond bs: identity).
@@ -799,21 +802,29 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   }
   if (!status && iter < a.max_iter) {
     // the slice is used up: park the solve (scaled x, z, y in natural order; t', g_e and the right-hand side are rebuilt
-    // from them by the next launch with the same formulas, i.e. bit for bit)
+    // from them by the next launch with the same formulas, i.e. bit for bit).  t' and g_e are written too, in the form
+    // the row-local kernel resumes from (sco_admm_rl.hip: t'_i = t_i - rw_i a_ie g_e): the SQP loop hands the tail of a
+    // step, when fewer problems are alive than this tier needs to fill the chip, to that kernel.
     double *sx = a.sx + (size_t)b * n, *sz = a.sz + (size_t)b * m, *sy = a.sy + (size_t)b * m;
+    double *stp = a.st + (size_t)b * m, *sgp = a.sg + (size_t)b * a.n_e;
     const int *tab = wv_opaque(tab0);
 #pragma unroll
     for (int q = 0; q < NS; q++) {
       const int h = tab[(oHROW + q) * 64 + lane], br = tab[(oHBROW + q) * 64 + lane], ev = tab[(oHEVAR + q) * 64 + lane];
-      if (h >= 0) { sz[h] = h_z[q]; sy[h] = h_y[q]; sz[br] = h_zb[q]; sy[br] = h_yb[q]; sx[ev] = h_xe[q]; }
+      if (h >= 0) {
+        sz[h] = h_z[q]; sy[h] = h_y[q]; sz[br] = h_zb[q]; sy[br] = h_yb[q]; sx[ev] = h_xe[q];
+        const double th = wc * (rho0 * h_z[q] - h_y[q]), tb = rho0 * h_zb[q] - h_yb[q];
+        stp[h] = th - (rw * h_ae[q]) * h_ge[q]; stp[br] = tb - (rho0 * h_ab[q]) * h_ge[q];
+        sgp[tab[(oHEIDX + q) * 64 + lane]] = h_ge[q];
+      }
     }
 #pragma unroll
     for (int v = 0; v < NV; v++) {
       const int var = tab[(oVVAR + v) * 64 + lane], r0 = tab[(oVROW + v) * 64 + lane];
       if (var >= 0) sx[var] = v_x[v];
-      if (r0 >= 0) { sz[r0] = v_z[v]; sy[r0] = v_y[v]; }
+      if (r0 >= 0) { sz[r0] = v_z[v]; sy[r0] = v_y[v]; stp[r0] = rho0 * v_z[v] - v_y[v]; }
     }
-    if (x_row >= 0) { sz[x_row] = x_z; sy[x_row] = x_y; }
+    if (x_row >= 0) { sz[x_row] = x_z; sy[x_row] = x_y; stp[x_row] = x_w * (x_rho * x_z - x_y); }
     if (lane == 0) { a.prog[b] = iter; a.status[b] = 0; a.iters[b] = iter; }
     return;
   }
@@ -855,13 +866,32 @@ static void wv_fill_args(const AdmmArgs &aa, const WvHost &wh, const WvDev &wd, 
   a.cst_slots = wh.cst_slots; a.g_doubles = wh.g_doubles;
   a.rho = aa.rho; a.sigma = aa.sigma; a.alpha = aa.alpha; a.eps_abs = aa.eps_abs; a.eps_rel = aa.eps_rel;
   a.eps_prim_inf = aa.eps_prim_inf; a.eps_dual_inf = aa.eps_dual_inf;
-  a.tab = wd.tab; a.G = wd.G; a.cst = wd.cst; a.wc = wd.wc; a.scr = wd.scr; a.ok = wd.ok; a.rl_need = wd.rl_need;
+  a.tab = wd.tab; a.G = wd.G; a.cst = wd.cst; a.wc = wd.wc; a.scr = wd.scr; a.ok = wd.ok; a.rl_need = wd.rl_need; a.w_ready = wd.w_ready;
   a.As = d.As; a.Ps = d.Ps; a.qs = d.qs; a.ls = d.ls; a.us = d.us; a.rhov = d.rho; a.kee_inv = d.kee_inv; a.cscale = d.cscale;
   a.D = d.D; a.E = d.E; a.S = d.W; a.w = d.w; a.active = d.active; a.setup_active = setup_mask;
   a.Ap = d.Ap; a.Ai = d.Ai; a.Rp = d.Rp; a.Rj = d.Rj; a.Rpos = d.Rpos; a.Fp = d.Fp; a.Fi = d.Fi; a.Fpos = d.Fpos;
   a.x = d.x; a.y = d.y; a.resid = d.resid; a.status = d.status; a.iters = d.iters; a.prog = d.prog;
-  a.sx = d.sx; a.sz = d.sz; a.sy = d.sy;
+  a.sx = d.sx; a.sz = d.sz; a.sy = d.sy; a.st = d.st; a.sg = d.sg;
   { const char *ab = getenv("SCO_WV_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+}
+
+// need[b] = the problem starts a QP, or it is active on a QP the wavefront tier factored (W buffer still holds S)
+__global__ void qp_wv_need_kernel(int b0, const int *list, int nb, const int *setup_mask, const int *active, int *w_ready, int *need) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  const int b = list ? list[g + b0] : g + b0;
+  if (b < 0) return;
+  const int nd = (setup_mask ? setup_mask[b] != 0 : 1) || ((!active || active[b]) && !w_ready[b]);
+  need[b] = nd;
+  if (nd) w_ready[b] = 1;
+}
+
+int wv_launch_need(const AdmmArgs &aa, const int *setup_mask, const WvDev &wd, hipStream_t st) {
+  const int nwg = aa.d.nb > 0 ? aa.d.nb : aa.d.batch;
+  hipLaunchKernelGGL(qp_wv_need_kernel, dim3((nwg + 255) / 256), dim3(256), 0, st, aa.d.b0, aa.d.list, nwg, setup_mask, aa.d.active,
+                     wd.w_ready, wd.rl_need);
+  SCO_HIP(hipGetLastError());
+  return SCO_OK;
 }
 
 int wv_launch_factor(const AdmmArgs &aa, const int *setup_mask, const WvHost &wh, const WvDev &wd, hipStream_t st) {

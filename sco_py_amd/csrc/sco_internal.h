@@ -154,11 +154,15 @@ struct WvHost {
 // G: [batch][g_doubles] factor (pivot inverses, couplings); cst: [batch][cst_slots][64] constants of the termination test;
 // wc: [batch] common weight of the hinge rows; ok: [batch] 1 = the problem's values have the penalty-QP structure (else the
 // row-local kernel solves it: rl_need = its setup mask); scr: [batch][m + n] delta_y / delta_x of the last checked iteration
-struct WvDev { const int *tab; double *G, *cst, *wc, *scr; int *ok, *rl_need; };
+// w_ready: [batch] 1 = the problem's W buffer holds the dense inverse (the row-local kernel can run it), 0 = it still
+// holds S (the wavefront tier factored this QP; qp_sweep_kernel has to run before the row-local kernel takes over)
+struct WvDev { const int *tab; double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready; };
 bool wv_plan_build(const QpPlan &pl, WvHost &wh);
 int wv_upload(const WvHost &wh, int batch, int n, int m, std::vector<void *> &allocs, WvDev &wd);
 int wv_launch_factor(const AdmmArgs &a, const int *setup_mask, const WvHost &wh, const WvDev &wd, hipStream_t st);
 int wv_launch(const AdmmArgs &a, const WvHost &wh, const WvDev &wd, hipStream_t st);
+// row-local round on a handle that also holds the wavefront tier: need[b] = setup_mask[b] or (active and W not ready)
+int wv_launch_need(const AdmmArgs &a, const int *setup_mask, const WvDev &wd, hipStream_t st);
 
 // ---- big tier (sco_qp_big.hip): everything in HBM/L2, 1024 threads per problem
 struct BigHost {
@@ -203,6 +207,7 @@ struct sco_qp {
   WvHost wv;
   WvDev wvd{};
   bool use_wv = false;
+  int cus = 0;                         // compute units of the device (tier choice by batch size)
   RegHost reg;
   RegDev regd{};
   bool use_reg = false;
@@ -238,9 +243,13 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
 #define SCO_MASK_NONE ((const int *)(uintptr_t)2)
 // `grp` (may be null): run only problems [b0, b0 + nb) and on grp->stream instead of the handle's own (stream groups of
 // the SQP loop; row-local tier with the Gauss-Jordan inversion only, see sco_qp_supports_groups)
-struct QpGroup { int b0, nb; hipStream_t stream; const int *list; };       // list: see QpDev (null = none)
+// tier: 0 = the handle decides (wavefront tier when the batch has at least SCO_WV_MIN_PER_CU problems per CU), 1 = row-local
+// kernel, 2 = wavefront tier (handles that hold it; others ignore the field)
+struct QpGroup { int b0, nb; hipStream_t stream; const int *list; int tier; };       // list: see QpDev (null = none)
 int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup_mask, const int *active_dev,
                          int slice, hipEvent_t mid, int *sliced, const QpGroup *grp = nullptr);
 bool sco_qp_supports_groups(const sco_qp *qp, const sco_qp_settings *st);
 int sco_qp_adaptive_interval(const sco_qp_settings *st);
+int sco_wv_min_live(int cus);      // fewest live problems for which a round runs on the wavefront tier
+bool sco_qp_has_wv(const sco_qp *qp, const sco_qp_settings *st);   // the handle holds the wavefront tier and these settings can use it
 bool sco_qp_can_adapt(const sco_qp *qp);   // false: this handle sits on the dense global-memory tier, which cannot park a solve

@@ -881,6 +881,7 @@ static int qp_create_impl(sco_qp *qp, int device, int batch, int n, int m, const
   int rc = qp_plan_build(n, m, Pp, Pi, Ap, Ai, (no_elim && no_elim[0] == '1') ? 0 : 1, qp->plan);
   if (rc != 0) { sco_set_error("sco_qp_create: malformed sparsity pattern"); return SCO_ERR_ARG; }
   const QpPlan &pl = qp->plan;
+  (void)hipDeviceGetAttribute(&qp->cus, hipDeviceAttributeMultiprocessorCount, device);
   qp->lds_setup = setup_lds_doubles(pl) * sizeof(double);
   qp->lds_admm = admm_lds_doubles(n, m, pl.nnzA, pl.n_e, pl.n_c, pl.ncpl) * sizeof(double) + (size_t)m * sizeof(int);
   const size_t lds_cap = 160 * 1024;
@@ -1037,6 +1038,13 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
   return sco_qp_launch_sliced(qp, st, active_dev, active_dev, 0, mid, nullptr);
 }
 
+// fewest problems of a launch for which the wavefront tier is the faster one (SCO_WV_MIN_PER_CU: problems per CU, default 3.3)
+int sco_wv_min_live(int cus) {
+  const char *e = getenv("SCO_WV_MIN_PER_CU");
+  const double per = e ? atof(e) : 3.3;
+  return (int)(per * (cus > 0 ? cus : 256));
+}
+
 int sco_qp_adaptive_interval(const sco_qp_settings *st) {
   if (st->adaptive_rho_interval > 0) {
     // park points sit on termination checks
@@ -1047,6 +1055,7 @@ int sco_qp_adaptive_interval(const sco_qp_settings *st) {
   return st->check_termination > 0 ? 4 * st->check_termination : 100;
 }
 
+bool sco_qp_has_wv(const sco_qp *qp, const sco_qp_settings *st) { return qp->use_wv && !st->warm_start && !st->adaptive_rho; }
 bool sco_qp_can_adapt(const sco_qp *qp) { return !(qp->use_big && !qp->use_bt); }
 
 // Launch windows and index lists (QpGroup) exist for the paths the bench workloads take: row-local ADMM kernel with
@@ -1093,8 +1102,13 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
   AdmmArgs aa{d, st->rho, st->sigma, st->alpha, st->eps_abs, st->eps_rel, st->eps_prim_inf, st->eps_dual_inf,
               st->max_iter, st->check_termination, (st->warm_start && qp->solved_once) ? 1 : 0, slice,
               adaptive ? 1 : 0, adaptive ? sco_qp_adaptive_interval(st) : 0, st->adaptive_rho_tolerance, nullptr};
-  // the wavefront tier runs cold-start, fixed-rho solves (parity mode); the opt-in extensions keep the row-local kernel
-  const bool wv_now = qp->use_wv && !aa.warm && !adaptive && !st->warm_start;
+  // The wavefront tier runs cold-start, fixed-rho solves (parity mode); the opt-in extensions keep the row-local kernel.
+  // It puts four problems on a CU at ~3.1 us per iteration each where the row-local kernel runs one at ~0.95 us: it is
+  // the faster way through a launch only with more than ~3.3 problems per CU to run (profiles/r04_wv.txt).  The SQP loop
+  // says per round which one it wants (QpGroup::tier, from its live count); a plain sco_qp_solve goes by the batch.
+  const bool wv_can = qp->use_wv && !aa.warm && !adaptive && !st->warm_start;
+  const int wv_min = sco_wv_min_live(qp->cus);
+  const bool wv_now = wv_can && (grp && grp->tier ? grp->tier == 2 : (grp ? grp->nb : d.batch) >= wv_min);
   qp->solved_once = true;
   if (!grp) SCO_HIP(hipEventRecord(qp->ev[0], stream));
   if (adaptive && setup_mask != SCO_MASK_NONE) {
@@ -1119,6 +1133,12 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
     if (wv_now) {
       // twisted block factorisation + the value test; the dense inverse below then runs for the problems that failed it only
       int r_ = wv_launch_factor(aa, dsetup.active, qp->wv, qp->wvd, stream);
+      if (r_) return r_;
+      dsetup.active = qp->wvd.rl_need;
+    } else if (qp->use_wv) {
+      // a row-local launch on a handle that also runs the wavefront tier: besides the problems that start a QP, the dense
+      // inverse is formed for the active ones whose QP was factored by that tier (their W buffer still holds S)
+      int r_ = wv_launch_need(aa, dsetup.active, qp->wvd, stream);
       if (r_) return r_;
       dsetup.active = qp->wvd.rl_need;
     }

@@ -130,6 +130,7 @@ struct sco_sqp {
   double last_ms[5] = {0, 0, 0, 0, 0};
   int rounds = 0;          // 1 (projection) + the rounds of the group that needed most
   int launches = 0;        // round launches over all stream groups
+  int wv_rounds = 0;       // of them on the wavefront tier
 };
 
 // --------------------------------------------------------------------------
@@ -1668,6 +1669,14 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   const bool select = slice_req > 0 && cus > 0 && s.batch > cus && sco_qp_supports_groups(h->qp1, &qsl) &&
                       !(sel_env && sel_env[0] == '0');
   if (getenv("SCO_SQP_TRACE_ROUNDS")) fprintf(stderr, "sco_sqp_solve: %d CUs, %d stream group(s), round selection %s, slice %d\n", cus, G, select ? "on" : "off", slice_req);
+  // Tier of a round (handles whose penalty QP has the wavefront tier, parity-mode settings): with at least wv_min live
+  // problems the round runs on the wavefront tier -- every live problem at once, four per CU -- below that on the row-local
+  // kernel, one problem per CU in whole passes.  The first is the higher THROUGHPUT while the batch is alive (1024 / 3.1 us
+  // against 256 / 0.95 us per iteration), the second the lower LATENCY for the tail of a step; a problem's QP changes kernel
+  // at a slice boundary (the parked state is common).  Both kernels agree to rounding (1e-14), not bit for bit: for batches
+  // that ever have wv_min live problems the last bits of a result depend on the schedule (SCO_WV_MIN_PER_CU=1e9: never).
+  const bool has_wv = select && sco_qp_has_wv(h->qp1, &qsl);
+  const int wv_min = sco_wv_min_live(cus);
   h->groups_used = G;
   for (int g = 1; g < G; g++)
     if (!h->gstream[g - 1]) SCO_HIP(hipStreamCreate(&h->gstream[g - 1]));
@@ -1690,6 +1699,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   auto gmark = [&](int g, int st) { hipEvent_t e = gevent(g); (void)hipEventRecord(e, grp[g].st); grp[g].stage.push_back(st); };
   std::vector<hipEvent_t> &done = h->done;          // per (group, slot): the round's read-back has landed
   while (done.size() < (size_t)G * SQP_DEPTH) { hipEvent_t e; SCO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); done.push_back(e); }
+  int wv_rounds = 0;
   auto enqueue_round = [&](int g) -> int {
     Group &r = grp[g];
     SqpDev sg = s; sg.b0 = r.b0; sg.n_active = s.n_active + g;
@@ -1697,10 +1707,13 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     if (!select) SCO_HIP(hipMemsetAsync(sg.n_active, 0, sizeof(int), r.st));
     sg.list = nullptr;
     int nwg = r.nb;                              // workgroups of this round's kernels
+    const bool wv_round = has_wv && r.last_active >= wv_min;
     if (select) {
       // compact launch: as many workgroups as the selection can let run, sized from the newest active count the host has
-      nwg = std::max(1, r.last_active <= cus ? r.last_active : (r.last_active / cus) * cus);
-      hipLaunchKernelGGL(sqp_select_kernel, dim3(1), dim3(SEL_T), 0, r.st, sg, h->qp1->d, cus, slice_req, qsl.max_iter, nwg, r.nb);
+      // (a pass of the chip = one problem per CU, four on the wavefront tier)
+      const int pass = wv_round ? 4 * cus : cus;
+      nwg = std::max(1, r.last_active <= pass ? r.last_active : (r.last_active / pass) * pass);
+      hipLaunchKernelGGL(sqp_select_kernel, dim3(1), dim3(SEL_T), 0, r.st, sg, h->qp1->d, pass, slice_req, qsl.max_iter, nwg, r.nb);
       SCO_HIP(hipGetLastError());
       sg.list = s.list_buf;
     }
@@ -1708,7 +1721,8 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     SCO_HIP(hipGetLastError());
     gmark(g, 0);
     hipEvent_t gm = gevent(g); r.stage.push_back(1);
-    const QpGroup win{r.b0, nwg, r.st, sg.list};
+    const QpGroup win{r.b0, nwg, r.st, sg.list, has_wv ? (wv_round ? 2 : 1) : 0};
+    if (wv_round) wv_rounds++;
     const int rc_ = sco_qp_launch_sliced(h->qp1, &qsl, s.newqp, s.active, slice_req, gm, nullptr, (G > 1 || select) ? &win : nullptr);
     if (rc_) return rc_;
     gmark(g, 2);
@@ -1761,6 +1775,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     h->rounds = 1 + total_rounds;
     h->launches = 0;
     for (int g = 0; g < G; g++) h->launches += grp[g].retired;
+    h->wv_rounds = wv_rounds;
   }
   if (capped) {
     // the launch cap ended the loop with problems still running (it is sized so that this cannot happen while every
@@ -1866,6 +1881,7 @@ extern "C" int sco_sqp_last_rounds(const sco_sqp *h, int *rounds) {
   return SCO_OK;
 }
 
+extern "C" int sco_debug_sqp_wv_rounds(const sco_sqp *h) { return h ? h->wv_rounds : -1; }
 extern "C" int sco_sqp_last_launches(const sco_sqp *h, int *launches, int *groups) {
   if (!h) return SCO_ERR_ARG;
   if (launches) *launches = h->launches;

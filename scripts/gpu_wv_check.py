@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import osqp_ref as o
 from sco_py_amd import _lib as L
 
-os.environ["SCO_QP_WV"] = "1"
+os.environ["SCO_WV_MIN_PER_CU"] = "0"     # every launch on the wavefront tier (default: > 3.3 problems per CU)
 lib = L.load()
 lib.sco_debug_qp_tiers.restype = C.c_int; lib.sco_debug_qp_tiers.argtypes = [C.c_void_p]
 

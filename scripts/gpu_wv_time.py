@@ -4,7 +4,7 @@ import numpy as np, scipy.sparse as sp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = [sys.argv[0], "noop"]
 from sco_py_amd import _lib as L
-os.environ["SCO_QP_WV"] = "1"
+os.environ["SCO_WV_MIN_PER_CU"] = "0"     # every launch on the wavefront tier (default: > 3.3 problems per CU)
 import importlib.util
 spec = importlib.util.spec_from_file_location("wvc", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_wv_check.py"))
 src = open(spec.origin).read().split("quick = len(sys.argv)")[0]

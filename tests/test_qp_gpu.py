@@ -592,6 +592,7 @@ def test_wavefront_tier_agrees_with_the_row_local_tier_and_the_oracle(gpu, monke
     """r04: csrc/sco_admm_wv.hip -- one wavefront per problem, twisted block-tridiagonal core solve instead of the dense
     inverse.  Same statuses and iteration counts as the row-local kernel and as the oracle, answers within 1e-10 of the
     former; row weights, second pins, every instantiation (<7,4,3,10> at 7 x 20 and 7 x 12, <8,1,1,4>, <8,2,2,8>, <8,4,4,16>)."""
+    monkeypatch.setenv("SCO_WV_MIN_PER_CU", "0")      # (by default a launch goes to this tier with > 3.3 problems per CU only)
     T, d, r = shape
     rng = np.random.default_rng(100 + T)
     probs = [penalty_qp(rng, T, d, r) for _ in range(6)]
@@ -612,6 +613,7 @@ def test_wavefront_tier_leaves_odd_value_structure_to_the_row_local_kernel(gpu, 
     a box so narrow that OSQP gives it the equality rho, unequal weights -- are found by qp_wv_factor_kernel and solved by
     the row-local kernel in the same launch sequence: statuses, iteration counts and answers of the whole batch = the
     oracle's and = a run with the tier switched off."""
+    monkeypatch.setenv("SCO_WV_MIN_PER_CU", "0")
     rng = np.random.default_rng(77)
     T, d, r = 6, 3, 4
     probs = [list(penalty_qp(rng, T, d, r)) for _ in range(6)]
@@ -629,9 +631,10 @@ def test_wavefront_tier_leaves_odd_value_structure_to_the_row_local_kernel(gpu, 
     assert np.array_equal(st_wv, st_rl) and np.array_equal(it_wv, it_rl) and np.abs(x_wv - x_rl).max() < 1e-10
 
 
-def test_wavefront_tier_time_slices_and_max_iter(gpu):
+def test_wavefront_tier_time_slices_and_max_iter(gpu, monkeypatch):
     """Parked and resumed solves (sco_qp_settings.max_iter cut into slices by the SQP loop is covered in test_sqp_gpu.py);
     here: a solve that stops on max_iter between two termination checks, and one with check_termination off."""
+    monkeypatch.setenv("SCO_WV_MIN_PER_CU", "0")
     rng = np.random.default_rng(5)
     probs = [penalty_qp(rng, 20, 7, 10) for _ in range(4)]
     for kw in (dict(max_iter=60), dict(max_iter=333), dict(max_iter=500, check_termination=0)):

@@ -1095,3 +1095,30 @@ def test_quadratic_rows_with_an_equality_row(gpu):
         assert bool(res.success[0]) == bool(g[prefix + "success"]), prefix
         nq = int(g[prefix + "n_qp"])
         assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix
+
+
+def test_wavefront_rounds_then_row_local_tail_agree_with_the_row_local_loop(gpu, monkeypatch):
+    """r04: with at least 3.3 live problems per CU a round of the device loop runs on the wavefront tier (four problems per
+    CU, csrc/sco_admm_wv.hip), below that on the row-local kernel; a QP changes kernel at a slice boundary through the
+    common parked state.  The two kernels agree to rounding, so against the all-row-local loop (SCO_QP_NO_WV=1) and the
+    oracle: same decisions, QP statuses and ADMM iteration counts, trajectories within 1e-9 (the north_star bar is 1e-6)."""
+    import ctypes as C
+    lib = _lib.load()
+    lib.sco_debug_sqp_wv_rounds.restype = C.c_int; lib.sco_debug_sqp_wv_rounds.argtypes = [C.c_void_p]
+    nb, dims = 1280, (3, 6, 2, 2)
+    arrays, probs = af.make_batch(nb, d=dims[0], T=dims[1], K=dims[2], O=dims[3])
+    outs, wvr = [], []
+    for no_wv in ("0", "1"):
+        monkeypatch.setenv("SCO_QP_NO_WV", no_wv)
+        with sb.TrajOptBatch(nb, *dims) as tb:
+            tb.load(arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"],
+                    arrays["point_frac"], arrays["obstacles"])
+            tb.solve(_lib.default_sqp_params(admm_slice=400))
+            r = tb.fetch(); r.trace = tb.trace(); r.timing = tb.last_timing()
+            outs.append(r); wvr.append(lib.sco_debug_sqp_wv_rounds(tb._h))
+    assert wvr[0] > 0 and wvr[1] == 0 and outs[0].timing["rounds"] > wvr[0]       # wavefront rounds first, then the tail
+    a, b = outs
+    assert np.array_equal(a.admm_iters, b.admm_iters) and np.array_equal(a.success, b.success) and np.array_equal(a.qp_solves, b.qp_solves)
+    assert all(np.array_equal(x[:, [0, 4, 5, 6, 7]], y[:, [0, 4, 5, 6, 7]]) for x, y in zip(a.trace, b.trace))
+    assert np.abs(a.x - b.x).max() < 1e-9
+    _compare(a, probs, range(0, nb, 160))
