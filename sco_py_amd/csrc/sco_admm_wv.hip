@@ -364,6 +364,12 @@ __device__ __forceinline__ double wv_matvec(double acc, double w, const WvRow<BS
   return acc + acc2;
 }
 
+// Hand-over of LDS data between lanes of the ONE wavefront of a workgroup: the LDS unit works through a wavefront's
+// instructions in issue order, so a read issued after a write sees it; all that is needed is that the compiler keeps the
+// program order (a wavefront-scope fence emits no instruction).  __syncthreads() would add s_waitcnt lgkmcnt(0) + s_barrier
+// four times per iteration.
+#define WV_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 // opaque copy of a pointer: loads through it cannot be hoisted out of the iteration loop (the constants of the termination
 // test and the lane tables are read on checked iterations only; hoisted, they would occupy ~170 registers for the whole solve)
 template <typename T>
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   const double *const md_g = lds + oG + NSTEP * 64 + k8 * 8;
   double *const md_v = lds + oR + NSTEP * 8 + k8;
   double *scr_dy = a.scr + (size_t)b * (n + m), *scr_dx = scr_dy + m;
-  __syncthreads();
+  WV_SYNC();
 
   // accumulators of the termination test that ride along in the checked step
   double c_ndy = 0.0, c_lhs = 0.0, c_ndx = 0.0, c_qdx = 0.0;
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       const double t0 = rho0 * v_z[v] - v_y[v];
       own[v] = v_a[v] * t0 + (sigma * v_x[v] - v_q[v]);
     }
-    __syncthreads();
+    WV_SYNC();
     // core right-hand side = own part + the extra row's + the block's partial column sums
     double rsum[NV];
 #pragma unroll
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       v_p[v][oR - oXT] = v_on[v] ? rsum[v] : 0.0;
       if (MODE == 2) v_p[v][oXC - oXT] = v_x[v];
     }
-    __syncthreads();
+    WV_SYNC();
   };
 
   // x~_C = S^-1 r by the twisted block factorisation: forward sweeps of both chains, the middle block, backward sweeps.
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       emk = lds[oEM + k8];
       sw_v[(NSTEP - 1) * 8 + (oXT - oR)] = vs[NSTEP - 1];
     }
-    __syncthreads();
+    WV_SYNC();
     if (sw_store) {
       double xn;
       const double vA = md_v[-8 + (oXT - oR)], vB = md_v[NSTEP * 8 + (oXT - oR)];
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       for (int s = 0; s < NSTEP; s++) sw_v[s * 8 + (oXT - oR)] = vs[s];
       if (srow == 0) md_v[oXT - oR] = xmid;
     }
-    __syncthreads();
+    WV_SYNC();
   };
 
   rows(std::integral_constant<int, 0>{});
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         w_pri = fmax(w_pri, ex * fabs(ax - x_z)); w_pn = fmax(w_pn, ex * fmax(fabs(x_z), fabs(ax)));
         if (x_row >= 0) x_p[oEX - oXT] = x_a * (x_w * x_y);
       }
-      __syncthreads();
+      WV_SYNC();
 #pragma unroll
       for (int v = 0; v < NV; v++) {
         const double *c = ck.vc[v];
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
           w_dn = fmax(w_dn, dj * fmax(fabs(v_q[v]), fmax(fabs(aty), fabs(px))));
         }
       }
-      __syncthreads();       // (the next pass over the rows rewrites the two buffers the test has borrowed)
+      WV_SYNC();       // (the next pass over the rows rewrites the two buffers the test has borrowed)
       w_pri = wv_wmax(w_pri); w_pn = wv_wmax(w_pn); w_dua = wv_wmax(w_dua); w_dn = wv_wmax(w_dn);
       const double ndy = wv_wmax(c_ndy), ndx = wv_wmax(c_ndx), lhs = wv_wsum(c_lhs), qdx = wv_wsum(c_qdx);
       pri = w_pri; dua = cinv * w_dua;
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       // arrays the checked step has filled
       const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
       if (!prim_ok && ndy > epi && lhs < -epi * ndy) {
-        __threadfence_block(); __syncthreads();
+        __threadfence_block(); WV_SYNC();
         double nat = 0.0;
         for (int j = lane; j < n; j += WV_T) {
           double aty = 0.0;
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         if (nat < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
       }
       if (!dual_ok && ndx > edi && qdx < -cscale * edi * ndx) {
-        __threadfence_block(); __syncthreads();
+        __threadfence_block(); WV_SYNC();
         const double *Psg = a.Ps + (size_t)b * a.nnzP;
         double npx = 0.0;
         for (int j = lane; j < n; j += WV_T) {

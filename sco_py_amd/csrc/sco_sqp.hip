@@ -1639,6 +1639,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   // default slice: 6250 iterations (7-DOF x 20: 964 ms per 1024-batch step against 1106 unsliced); with adaptive rho
   // the QPs are short and every rho change costs its problem a relaunch, so the slice is shorter (scripts/gpu_adaptive_slice_sweep.py)
   int slice_req = params->admm_slice < 0 ? 0 : (params->admm_slice > 0 ? params->admm_slice : (qs->adaptive_rho ? 2000 : 6250));
+  if (params->admm_slice == 0) { const char *se = getenv("SCO_SQP_SLICE"); if (se && atoi(se) > 0) slice_req = atoi(se); }   // tuning aid: the default slice
   if (params->admm_slice == 0) {
     // with at most one problem per CU there is nobody to hand a CU to: slicing would only add relaunches
     int cus = 0;
