@@ -44,10 +44,20 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // (a VALU write of the broadcast operand needs two wait states before a DPP instruction reads it: the first of a chain
 // carries them itself, inline assembly is opaque to the compiler's hazard recogniser.  Plain `asm`, not `asm volatile`:
 // a volatile statement is a scheduling barrier, and the loads of the next block step have to move above this one's chain)
-#define WV_FMAC_DPP0(acc, w, g) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(g))
 #define WV_FMAC_DPP(acc, w, g, k) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(g))
 
 __host__ __device__ __forceinline__ size_t wv_tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // packed lower, j <= i
+
+// LDS layouts chosen against bank conflicts (r04 PMC: 42 % of the LDS cycles of the first version were conflicts, the LDS
+// pipe of a CU with four of these wavefronts was busy 68 % of the time).  A 64-byte row per lane at a 64-byte lane stride
+// puts lanes i and i + 4 on the same banks for every 16-byte piece; instead the four pieces of a vector are stored
+// PIECE-MAJOR, 16 bytes per block (or per lane slot) inside a piece:
+//   block vectors (r, x~, x, extra)  index(pos, k) = (k >> 1) * 2 NPOS + 2 pos + (k & 1)
+//   partial column sums              index(j, slot) = j * 2 NSLOT + 2 slot              (slot = pos * lpb + part)
+//   rows of G, block pos             index(row i, col c) = 64 pos + 16 ((c >> 1) + shift & 3) + 2 i + (c & 1), shift = 1 for
+//                                    the blocks of chain B (both chains read their piece j in the same instruction)
+__host__ __device__ inline int wv_vidx(int npos, int pos, int k) { return (k >> 1) * 2 * npos + 2 * pos + (k & 1); }
+__host__ __device__ inline int wv_gidx(int nstep, int pos, int i, int c) { return 64 * pos + 16 * (((c >> 1) + (pos > nstep ? 1 : 0)) & 3) + 2 * i + (c & 1); }
 
 // int tables, [..][64] lane-minor; offsets in units of 64 ints
 struct WvTab {
@@ -64,11 +74,15 @@ __host__ __device__ inline WvTab wv_tab_layout(int NS, int NV) {
   t.total = o;
   return t;
 }
-// constants of the termination test, [slot][64] per problem: hinge slot q: 1/E_h, 1/E_b, 1/D_e, E_h, E_b, D_e;
-// variable slot v: 1/D_c, 1/E_0, D_c, E_0, P(c, c-) , P(c, c+), P(c, block)[8]; extra row: 1/E_x, E_x
-__host__ __device__ inline int wv_cst_h(int q) { return 6 * q; }
-__host__ __device__ inline int wv_cst_v(int NS, int v) { return 6 * NS + 14 * v; }
-__host__ __device__ inline int wv_cst_x(int NS, int NV) { return 6 * NS + 14 * NV; }
+// constants of the termination test, [slot][64] per problem: hinge slot q: 1/E_h, 1/E_b, 1/D_e; variable slot v: 1/D_c,
+// 1/E_0, P(c, c-), P(c, c+), P(c, c), then P(c, block)[8] (read only by problems whose P has entries off these three
+// diagonals: pflag); extra row: 1/E_x.  The scalings themselves (E, D) are formed from the reciprocals when the
+// certificates' norms need them: the fetch of these constants is what a checked iteration costs most
+// (every wavefront of the chip asks for them at the same time).
+__host__ __device__ inline int wv_cst_h(int q) { return 3 * q; }
+__host__ __device__ inline int wv_cst_v(int NS, int v) { return 3 * NS + 13 * v; }
+__host__ __device__ inline int wv_cst_x(int NS, int NV) { return 3 * NS + 13 * NV; }
+__device__ __forceinline__ double wv_recip(double x) { return x != 0.0 ? 1.0 / x : 0.0; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host plan
@@ -146,8 +160,8 @@ bool wv_plan_build(const QpPlan &pl, WvHost &wh) {
   auto at = [&](int off, int lane) -> int & { return wh.tab[(size_t)off * 64 + lane]; };
   for (int l = 0; l < 64; l++) {
     at(T.pos, l) = dummy;                                           // idle lanes sit on the all-zero dummy block
-    for (int v = 0; v < wh.NV; v++) { at(T.vpk + v, l) = dummy * 8 + (v & 7); at(T.vpkm + v, l) = dummy * 8; at(T.vpkp + v, l) = dummy * 8; }
-    at(T.xpk, l) = dummy * 8;
+    for (int v = 0; v < wh.NV; v++) { at(T.vpk + v, l) = wv_vidx(npos, dummy, v & 7); at(T.vpkm + v, l) = wv_vidx(npos, dummy, 0); at(T.vpkp + v, l) = wv_vidx(npos, dummy, 0); }
+    at(T.xpk, l) = wv_vidx(npos, dummy, 0);
   }
   int xl = 0;
   for (int t = 0; t < nb; t++) {
@@ -161,9 +175,9 @@ bool wv_plan_build(const QpPlan &pl, WvHost &wh) {
     }
     for (int k = 0; k < bs; k++) {
       const int l = base + k % lpb, v = k / lpb, c = t * bs + k, var = pl.core_var[c];
-      at(T.vvar + v, l) = var; at(T.vpk + v, l) = p * 8 + k;
-      at(T.vpkm + v, l) = t > 0 ? pos_of(t - 1) * 8 + k : dummy * 8;
-      at(T.vpkp + v, l) = t + 1 < nb ? pos_of(t + 1) * 8 + k : dummy * 8;
+      at(T.vvar + v, l) = var; at(T.vpk + v, l) = wv_vidx(npos, p, k);
+      at(T.vpkm + v, l) = t > 0 ? wv_vidx(npos, pos_of(t - 1), k) : wv_vidx(npos, dummy, 0);
+      at(T.vpkp + v, l) = t + 1 < nb ? wv_vidx(npos, pos_of(t + 1), k) : wv_vidx(npos, dummy, 0);
       // the variable's own slot takes its LAST single row: the reference appends the bound / trust-region rows behind all
       // constraint rows (osqp_utils.py:185-189), so that is the box row, which sits on the base rho; an earlier one (a pin:
       // equality, rho_eq) goes to the general extra-row lanes
@@ -171,14 +185,14 @@ bool wv_plan_build(const QpPlan &pl, WvHost &wh) {
       for (int k2 = 0; k2 < bs; k2++) at(T.vpd + v * 8 + k2, l) = ppos(var, pl.core_var[t * bs + k2]);
       at(T.vpm + v, l) = t > 0 ? ppos(var, pl.core_var[(t - 1) * bs + k]) : -1;
       at(T.vpp + v, l) = t + 1 < nb ? ppos(var, pl.core_var[(t + 1) * bs + k]) : -1;
-      if (single[c].size() == 2) { at(T.xrow, xl) = single[c][0]; at(T.xpos, xl) = apos(single[c][0], var); at(T.xpk, xl) = p * 8 + k; xl++; }
+      if (single[c].size() == 2) { at(T.xrow, xl) = single[c][0]; at(T.xpos, xl) = apos(single[c][0], var); at(T.xpk, xl) = wv_vidx(npos, p, k); xl++; }
     }
   }
   // LDS of the ADMM kernel (doubles): G, ef, en, em | r, x~, x, extra | Jacobian rows | partials
   wh.g_doubles = (size_t)npos * 64 + 2 * (size_t)npos * 8 + 8;
   wh.lds_doubles = wh.g_doubles + 4 * (size_t)npos * 8 + (size_t)wh.NS * 512 + (size_t)npos * lpb * 8;
   wh.lds_bytes = wh.lds_doubles * sizeof(double);
-  wh.cst_slots = 6 * wh.NS + 14 * wh.NV + 2;
+  wh.cst_slots = 3 * wh.NS + 13 * wh.NV + 1;
   return wh.lds_bytes <= 64 * 1024;     // (<= 40 KB: four problems per CU, the 7 x 20 shapes; more LDS = fewer per CU)
 }
 
@@ -192,6 +206,8 @@ int wv_upload(const WvHost &wh, int batch, int n, int m, std::vector<void *> &al
   SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(int))); allocs.push_back(p); wd.ok = (int *)p;
   SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
   SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(int))); allocs.push_back(p); wd.rl_need = (int *)p;
+  SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
+  SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(int))); allocs.push_back(p); wd.pflag = (int *)p;
   SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
   SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(int))); allocs.push_back(p); wd.w_ready = (int *)p;
   SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
@@ -208,25 +224,45 @@ struct WvArgs {
   int bs, nb, mid, lpb, n_extra, NS, NV, NSTEP, cst_slots; size_t g_doubles;
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   const int *tab;
-  double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready;
+  double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready, *pflag;
   const double *As, *Ps, *qs, *ls, *us, *rhov, *kee_inv, *cscale, *D, *E, *S;
   const int *w, *active, *setup_active;
   const int *Ap, *Ai, *Rp, *Rj, *Rpos, *Fp, *Fi, *Fpos;
   double *x, *y, *resid; int *status, *iters, *prog;
   double *sx, *sz, *sy, *st, *sg;
-  int ablate;        // diagnostic (SCO_WV_ABLATE): 1 = no sweeps, 2 = no row passes (timing only, results wrong)
+  int ablate;        // diagnostic (SCO_WV_ABLATE): 1 = no sweeps, 2 = no row passes, 16 = no termination test behind the checked iteration (timing only, results wrong)
 };
 
-__device__ __forceinline__ double wv_wmax(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+// Wavefront-wide max / sum in registers: two DPP quad steps, two DPP mirror steps inside a 16-lane row, then the row and
+// half swaps (v_permlane16_swap / v_permlane32_swap).  (__shfl_xor goes through ds_bpermute: an LDS round trip per step,
+// 48 of them per termination test.)  Every lane ends with the result.
+typedef unsigned int wv_u2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ double wv_dpp(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true));
+}
+template <bool IS_MAX>
+__device__ __forceinline__ double wv_wred(double v) {
+  auto op = [](double a, double b) { return IS_MAX ? fmax(a, b) : a + b; };
+  v = op(v, wv_dpp<0xb1>(v));       // quad_perm [1, 0, 3, 2]
+  v = op(v, wv_dpp<0x4e>(v));       // quad_perm [2, 3, 0, 1]
+  v = op(v, wv_dpp<0x141>(v));      // row_half_mirror
+  v = op(v, wv_dpp<0x140>(v));      // row_mirror
+  {
+    const wv_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const wv_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    v = op(__hiloint2double((int)hi.x, (int)lo.x), __hiloint2double((int)hi.y, (int)lo.y));
+  }
+  {
+    const wv_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const wv_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    v = op(__hiloint2double((int)hi.x, (int)lo.x), __hiloint2double((int)hi.y, (int)lo.y));
+  }
   return v;
 }
-__device__ __forceinline__ double wv_wsum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ double wv_wmax(double v) { return wv_wred<true>(v); }
+__device__ __forceinline__ double wv_wsum(double v) { return wv_wred<false>(v); }
 #define WV_BIG (SCO_INFTY * SCO_MIN_SCALING)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -245,7 +281,7 @@ __global__ __launch_bounds__(WV_T) void qp_wv_factor_kernel(WvArgs a) {
   const double *D = a.D + (size_t)b * n, *E = a.E + (size_t)b * m, *Ps = a.Ps + (size_t)b * a.nnzP;
   double *cst = a.cst + (size_t)b * a.cst_slots * 64;
   // ---- value structure of a penalty QP (else the row-local kernel takes the problem)
-  int bad = 0, wk = 0;
+  int bad = 0, wk = 0, offd = 0;      // offd: P has entries inside a block off its diagonal
   for (int q = 0; q < NS; q++) { const int h = tab[(T.hrow + q) * 64 + lane]; if (h >= 0) wk = max(wk, w[h]); }
   wk = (int)wv_wmax((double)wk);
   for (int q = 0; q < NS; q++) {
@@ -258,7 +294,6 @@ __global__ __launch_bounds__(WV_T) void qp_wv_factor_kernel(WvArgs a) {
     }
     double *c = cst + (size_t)wv_cst_h(q) * 64 + lane;
     c[0] = h >= 0 ? 1.0 / eh : 0.0; c[64] = h >= 0 ? 1.0 / eb : 0.0; c[128] = h >= 0 ? 1.0 / de : 0.0;
-    c[192] = eh; c[256] = eb; c[320] = de;
   }
   for (int v = 0; v < NV; v++) {
     const int var = tab[(T.vvar + v) * 64 + lane], r0 = tab[(T.vrow + v) * 64 + lane];
@@ -266,18 +301,25 @@ __global__ __launch_bounds__(WV_T) void qp_wv_factor_kernel(WvArgs a) {
     if (r0 >= 0 && (rho[r0] != a.rho || w[r0] != 1)) bad = 1;
     c[0] = var >= 0 ? 1.0 / D[var] : 0.0;
     c[64] = r0 >= 0 ? 1.0 / E[r0] : 0.0;
-    c[128] = var >= 0 ? D[var] : 0.0;
-    c[192] = r0 >= 0 ? E[r0] : 0.0;
     const int pm = tab[(T.vpm + v) * 64 + lane], pp = tab[(T.vpp + v) * 64 + lane];
-    c[4 * 64] = pm >= 0 ? Ps[pm] : 0.0; c[5 * 64] = pp >= 0 ? Ps[pp] : 0.0;
-    for (int k = 0; k < 8; k++) { const int pd = tab[(T.vpd + v * 8 + k) * 64 + lane]; c[(6 + k) * 64] = pd >= 0 ? Ps[pd] : 0.0; }
+    c[2 * 64] = pm >= 0 ? Ps[pm] : 0.0; c[3 * 64] = pp >= 0 ? Ps[pp] : 0.0;
+    const int kown = (tab[(T.vpk + v) * 64 + lane] / (2 * (2 * NSTEP + 2)) << 1) | (tab[(T.vpk + v) * 64 + lane] & 1);   // in-block index of the variable
+    double pdiag = 0.0;
+    for (int k = 0; k < 8; k++) {
+      const int pd = tab[(T.vpd + v * 8 + k) * 64 + lane];
+      const double pv = pd >= 0 ? Ps[pd] : 0.0;
+      c[(5 + k) * 64] = pv;
+      if (var >= 0 && k == kown) pdiag = pv; else if (var >= 0 && pv != 0.0) offd = 1;
+    }
+    c[4 * 64] = pdiag;
   }
   {
     const int xr = tab[T.xrow * 64 + lane];
     double *c = cst + (size_t)wv_cst_x(NS, NV) * 64 + lane;
-    c[0] = xr >= 0 ? 1.0 / E[xr] : 0.0; c[64] = xr >= 0 ? E[xr] : 0.0;
+    c[0] = xr >= 0 ? 1.0 / E[xr] : 0.0;
   }
-  bad = (int)wv_wmax((double)bad);
+  bad = (int)wv_wmax((double)bad); offd = (int)wv_wmax((double)offd);
+  if (lane == 0) a.pflag[b] = offd;
   // (a failed value test: the dense inverse is formed right behind this kernel, so W will be ready)
   if (lane == 0) { a.ok[b] = !bad; a.rl_need[b] = bad; a.w_ready[b] = bad; a.wc[b] = (double)wk; }
   if (bad) return;
@@ -319,7 +361,7 @@ __global__ __launch_bounds__(WV_T) void qp_wv_factor_kernel(WvArgs a) {
       const double ei = s > 0 ? Soff(tl, i) : 0.0, ej = s > 0 ? Soff(tl, j) : 0.0;
       const double M = Sblk(t) - ei * Gp * ej;
       Gp = invert(M);
-      G[(size_t)p * 64 + lane] = Gp;
+      G[wv_gidx(NSTEP, p, i, j)] = Gp;
       const int tn = chain ? t - 1 : t;           // link (tn, tn + 1) joins t with the next block towards the middle
       if (lane < 8) { ef[p * 8 + lane] = s > 0 ? Soff(tl, lane) : 0.0; en[p * 8 + lane] = Soff(tn, lane); }
     }
@@ -330,7 +372,7 @@ __global__ __launch_bounds__(WV_T) void qp_wv_factor_kernel(WvArgs a) {
   }
   {
     const double Gm = invert(Sblk(mid) - Gmid_corr);
-    G[(size_t)NSTEP * 64 + lane] = Gm;
+    G[wv_gidx(NSTEP, NSTEP, i, j)] = Gm;
     if (lane < 8) { ef[NSTEP * 8 + lane] = Soff(mid - 1, lane); em[lane] = Soff(mid, lane); }
   }
 }
@@ -344,11 +386,12 @@ __device__ __forceinline__ double wv_max(double a, double b) { double r; asm("v_
 // a row of G: BS doubles (the eighth of a 7-wide row is not loaded: its register would be free at once and the allocator
 // reuses it for the next load, which then has to wait for this one)
 template <int BS> struct WvRow { d2 a, b, c; d2 d; };
+// p: piece 0 of the lane's row (pieces 0 .. 2 follow at 16-double steps), pd: its piece 3 (wrapped for chain B)
 template <int BS>
-__device__ __forceinline__ WvRow<BS> wv_row(const double *p) {
-  WvRow<BS> r; const d2 *q = (const d2 *)p;
-  r.a = q[0]; r.b = q[1]; r.c = q[2];
-  if (BS > 7) r.d = q[3]; else { r.d.x = p[6]; r.d.y = 0.0; }
+__device__ __forceinline__ WvRow<BS> wv_row(const double *p, const double *pd) {
+  WvRow<BS> r;
+  r.a = *(const d2 *)p; r.b = *(const d2 *)(p + 16); r.c = *(const d2 *)(p + 32);
+  if (BS > 7) r.d = *(const d2 *)pd; else { r.d.x = pd[0]; r.d.y = 0.0; }
   return r;
 }
 
@@ -356,9 +399,14 @@ template <int BS>
 __device__ __forceinline__ double wv_matvec(double acc, double w, const WvRow<BS> &g) {
   const d2 g0 = g.a, g1 = g.b, g2 = g.c, g3 = g.d;
   // two accumulators: a dependent v_fmac_f64_dpp issues every 8.5 cycles, two interleaved chains every 6.5
-  // (scripts/microbench/wave_cost.hip)
+  // (scripts/microbench/wave_cost.hip).  The FIRST instruction of both chains sits in one asm statement behind the wait
+  // states: the two chains are independent, so as separate statements the scheduler was free to put the second chain's
+  // first broadcast directly behind the instruction that writes w (seen as wrong results of one build, r04).
   double acc2 = 0.0;
-  WV_FMAC_DPP0(acc, w, g0.x); WV_FMAC_DPP(acc2, w, g0.y, 1); WV_FMAC_DPP(acc, w, g1.x, 2); WV_FMAC_DPP(acc2, w, g1.y, 3);
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc), "+v"(acc2) : "v"(w), "v"(g0.x), "v"(g0.y));
+  WV_FMAC_DPP(acc, w, g1.x, 2); WV_FMAC_DPP(acc2, w, g1.y, 3);
   WV_FMAC_DPP(acc, w, g2.x, 4); WV_FMAC_DPP(acc2, w, g2.y, 5); WV_FMAC_DPP(acc, w, g3.x, 6);
   if (BS > 7) WV_FMAC_DPP(acc2, w, g3.y, 7);
   return acc + acc2;
@@ -410,8 +458,9 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   }
   // ---- lane roles (row layout): pointers into the vectors of the lane's block
   const int pos_r = tab0[oPOS * 64 + lane];
-  double *const xt_p = lds + oXT + pos_r * 8;                                   // x~ of the block (xc: + (oXC - oXT))
-  double *const part_p = lds + oPART + (pos_r * lpb + (lane & 15) % lpb) * 8;   // the lane's partial column sums
+  double *const xt_p = lds + oXT + pos_r * 2;                                   // x~ of the block, piece 0 (xc: + (oXC - oXT))
+  const int nslot2 = NPOS * lpb * 2;                                            // doubles of one piece of the partial sums
+  double *const part_p = lds + oPART + (pos_r * lpb + (lane & 15) % lpb) * 2;   // the lane's partial column sums, piece 0
   double *const jl_p = lds + oJ + lane * 2;                                     // Jacobian rows, lane-private
   // hinge slots: constants and state
   double h_ae[NS], h_ab[NS], h_u[NS], h_q[NS], h_kinv[NS], h_z[NS], h_y[NS], h_zb[NS], h_yb[NS], h_xe[NS], h_ge[NS];
@@ -436,12 +485,15 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   }
   // core-variable slots
   double *v_p[NV];                       // address of x~ of the variable (r, x, extra: fixed distances)
+  const double *v_pp[NV];                // its component in the first partial-sum slot of its block
   bool v_on[NV];
   double v_x[NV], v_q[NV], v_a[NV], v_l[NV], v_u[NV], v_z[NV], v_y[NV];
 #pragma unroll
   for (int v = 0; v < NV; v++) {
     const int var = tab0[(oVVAR + v) * 64 + lane], r0 = tab0[(oVROW + v) * 64 + lane];
-    v_on[v] = var >= 0; v_p[v] = lds + oXT + tab0[(oVPK + v) * 64 + lane];
+    const int vix = tab0[(oVPK + v) * 64 + lane], vk = ((vix / (2 * NPOS)) << 1) | (vix & 1), vpos = (vix % (2 * NPOS)) >> 1;
+    v_on[v] = var >= 0; v_p[v] = lds + oXT + vix;
+    v_pp[v] = lds + oPART + (vk >> 1) * nslot2 + vpos * lpb * 2 + (vk & 1);
     v_q[v] = var >= 0 ? qs[var] : 0.0; v_x[v] = var >= 0 && resume ? sxg[var] : 0.0;
     v_a[v] = r0 >= 0 ? As[tab0[(oVPOS + v) * 64 + lane]] : 0.0;
     v_l[v] = r0 >= 0 ? lsg[r0] : 0.0; v_u[v] = r0 >= 0 ? usg[r0] : 0.0;
@@ -456,10 +508,14 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   // sweep roles: DPP row 0 (and its copy, row 2) runs chain A, row 1 (and 3) chain B; lane k of a row holds component k
   const int srow = lane >> 4, k8 = lane & 7, chain = srow & 1;
   const bool sw_store = srow < 2 && (lane & 15) < 8;
-  const double *const sw_g = lds + oG + (chain ? NSTEP + 1 : 0) * 64 + k8 * 8;        // row k8 of the chain's first block
-  double *const sw_v = lds + oR + (chain ? NSTEP + 1 : 0) * 8 + k8;                    // r of the chain's first block
-  const double *const md_g = lds + oG + NSTEP * 64 + k8 * 8;
-  double *const md_v = lds + oR + NSTEP * 8 + k8;
+  const int pos0 = chain ? NSTEP + 1 : 0;
+  const double *const sw_g = lds + oG + pos0 * 64 + k8 * 2 + (chain ? 16 : 0);        // row k8 of the chain's first block, piece 0
+  const double *const sw_gd = lds + oG + pos0 * 64 + k8 * 2 + (chain ? 0 : 48);       // ... its piece 3
+  double *const sw_v = lds + oR + wv_vidx(NPOS, pos0, k8);                              // r of the chain's first block (next block: + 2)
+  const double *const sw_e = lds + oEF + pos0 * 8 + k8;                                // couplings of the chain's first block
+  const double *const md_g = lds + oG + NSTEP * 64 + k8 * 2;
+  double *const md_v = lds + oR + wv_vidx(NPOS, NSTEP, k8);
+  const double *const md_e = lds + oEF + NSTEP * 8 + k8;
   double *scr_dy = a.scr + (size_t)b * (n + m), *scr_dx = scr_dy + m;
   WV_SYNC();
 
@@ -468,7 +524,11 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   // Row / variable indices and scaling constants that only a checked iteration needs.  They are fetched from global memory
   // at the START of that iteration, in front of the sweeps, so that the round trip (L2 or HBM: 68 x 512 B per problem) runs
   // under the iteration's own arithmetic; kept for the whole solve they would cost ~170 registers.
-  struct { int h[NS], br[NS], ev[NS], r0[NV], var[NV], pkm[NV], pkp[NV]; double hc[NS][6], vc[NV][14], xc[2]; } ck;
+  struct { int h[NS], br[NS], ev[NS], r0[NV], var[NV], pkm[NV], pkp[NV]; double hc[NS][3], vc[NV][5], xc; } ck;
+  const int pdense = (a.ablate & 32) ? 1 : a.pflag[b];         // P has entries off the three diagonals the compact constants hold
+  // delta_y (clipped) / delta_x of the checked iteration: kept in registers; only when an infeasibility certificate has to be
+  // evaluated (rare) are they written to the scratch arrays its generic loops read
+  struct { double h[NS], b[NS], e[NS], r0[NV], var[NV], x; } dsv;
   auto load_chk = [&]() {
     const int *tab = wv_opaque(tab0);
     const double *c = wv_opaque(cstg0);
@@ -476,16 +536,16 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     for (int q = 0; q < NS; q++) {
       ck.h[q] = tab[(oHROW + q) * 64 + lane]; ck.br[q] = tab[(oHBROW + q) * 64 + lane]; ck.ev[q] = tab[(oHEVAR + q) * 64 + lane];
 #pragma unroll
-      for (int k = 0; k < 6; k++) ck.hc[q][k] = c[(wv_cst_h(q) + k) * 64];
+      for (int k = 0; k < 3; k++) ck.hc[q][k] = c[(wv_cst_h(q) + k) * 64];
     }
 #pragma unroll
     for (int v = 0; v < NV; v++) {
       ck.r0[v] = tab[(oVROW + v) * 64 + lane]; ck.var[v] = tab[(oVVAR + v) * 64 + lane];
       ck.pkm[v] = tab[(oVPKM + v) * 64 + lane]; ck.pkp[v] = tab[(oVPKP + v) * 64 + lane];
 #pragma unroll
-      for (int k = 0; k < 14; k++) ck.vc[v][k] = (k < 6 + BS) ? c[(wv_cst_v(NS, v) + k) * 64] : 0.0;
+      for (int k = 0; k < 5; k++) ck.vc[v][k] = c[(wv_cst_v(NS, v) + k) * 64];
     }
-    ck.xc[0] = c[wv_cst_x(NS, NV) * 64]; ck.xc[1] = c[(wv_cst_x(NS, NV) + 1) * 64];
+    ck.xc = c[wv_cst_x(NS, NV) * 64];
   };
 
   // One pass over the lane's rows and variables.  MODE 0: initialise (right-hand side of the first iteration from the
@@ -495,8 +555,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     // every LDS read of this phase is issued before its first store (the compiler keeps loads behind stores that may alias)
     double xt[8], xtx = 0.0, xtv[NV];
     if (MODE) {
-      const d2 *xp = (const d2 *)xt_p;
-      const d2 a0 = xp[0], a1 = xp[1], a2 = xp[2], a3 = xp[3];
+      const d2 a0 = *(const d2 *)xt_p, a1 = *(const d2 *)(xt_p + 2 * NPOS), a2 = *(const d2 *)(xt_p + 4 * NPOS), a3 = *(const d2 *)(xt_p + 6 * NPOS);
       xtx = x_p[0];
 #pragma unroll
       for (int v = 0; v < NV; v++) xtv[v] = v_p[v][0];
@@ -525,8 +584,8 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
           h_y[q] += dy; h_z[q] = zn;
           if (MODE == 2) {
             const double dc = fmax(dy, 0.0);              // clipped to the cone of the bounds (u finite, l = -inf)
-            c_ndy = fmax(c_ndy, ck.hc[q][3] * fabs(dc)); c_lhs += wc * (h_u[q] * dc);
-            if (ck.h[q] >= 0) scr_dy[ck.h[q]] = dc;
+            c_ndy = fmax(c_ndy, wv_recip(ck.hc[q][0]) * fabs(dc)); c_lhs += wc * (h_u[q] * dc);
+            dsv.h[q] = dc;
           }
         }
         // slack's bound row: [0, inf)
@@ -537,16 +596,16 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
           h_yb[q] += dy; h_zb[q] = zn;
           if (MODE == 2) {
             const double dc = fmin(dy, 0.0);
-            c_ndy = fmax(c_ndy, ck.hc[q][4] * fabs(dc));           // l = 0: nothing for u' dy+ + l' dy-
-            if (ck.br[q] >= 0) scr_dy[ck.br[q]] = dc;
+            c_ndy = fmax(c_ndy, wv_recip(ck.hc[q][1]) * fabs(dc));           // l = 0: nothing for u' dy+ + l' dy-
+            dsv.b[q] = dc;
           }
         }
         const double xo = h_xe[q], xn = alpha * xte + oma * xo;
         h_xe[q] = xn;
         if (MODE == 2) {
           const double dx = xn - xo;
-          c_ndx = fmax(c_ndx, ck.hc[q][5] * fabs(dx)); c_qdx += h_q[q] * dx;
-          if (ck.ev[q] >= 0) scr_dx[ck.ev[q]] = dx;
+          c_ndx = fmax(c_ndx, wv_recip(ck.hc[q][2]) * fabs(dx)); c_qdx += h_q[q] * dx;
+          dsv.e[q] = dx;
         }
       }
       const double th = wc * (rho0 * h_z[q] - h_y[q]);
@@ -559,10 +618,9 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       for (int k = 0; k < BS; k++) part[k] = __builtin_fma(J[k], tp, part[k]);
     }
     {
-      d2 *pp = (d2 *)part_p;
       d2 v0, v1, v2, v3;
       v0.x = part[0]; v0.y = part[1]; v1.x = part[2]; v1.y = part[3]; v2.x = part[4]; v2.y = part[5]; v3.x = part[6]; v3.y = BS > 7 ? part[7] : 0.0;
-      pp[0] = v0; pp[1] = v1; pp[2] = v2; pp[3] = v3;
+      *(d2 *)part_p = v0; *(d2 *)(part_p + nslot2) = v1; *(d2 *)(part_p + 2 * nslot2) = v2; *(d2 *)(part_p + 3 * nslot2) = v3;
     }
     // extra rows
     {
@@ -574,8 +632,8 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         x_y += dy; x_z = zn;
         if (MODE == 2) {
           const double d1 = x_u > WV_BIG ? fmin(dy, 0.0) : dy, dc = x_l < -WV_BIG ? fmax(d1, 0.0) : d1;
-          c_ndy = fmax(c_ndy, ck.xc[1] * fabs(dc)); c_lhs += x_w * (x_u * fmax(dc, 0.0) + x_l * fmin(dc, 0.0));
-          if (x_row >= 0) scr_dy[x_row] = dc;
+          c_ndy = fmax(c_ndy, wv_recip(ck.xc) * fabs(dc)); c_lhs += x_w * (x_u * fmax(dc, 0.0) + x_l * fmin(dc, 0.0));
+          dsv.x = dc;
         }
       }
       const double t = x_w * (x_rho * x_z - x_y);
@@ -596,9 +654,11 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         if (MODE == 2) {
           const double d1 = v_u[v] > WV_BIG ? fmin(dy, 0.0) : dy, dc = v_l[v] < -WV_BIG ? fmax(d1, 0.0) : d1;
           const int r0 = ck.r0[v], var = ck.var[v];
-          if (r0 >= 0) { c_ndy = fmax(c_ndy, ck.vc[v][3] * fabs(dc)); c_lhs += v_u[v] * fmax(dc, 0.0) + v_l[v] * fmin(dc, 0.0); scr_dy[r0] = dc; }
+          if (r0 >= 0) { c_ndy = fmax(c_ndy, wv_recip(ck.vc[v][1]) * fabs(dc)); c_lhs += v_u[v] * fmax(dc, 0.0) + v_l[v] * fmin(dc, 0.0); }
+          dsv.r0[v] = dc;
           const double dx = xn - xo;
-          if (var >= 0) { c_ndx = fmax(c_ndx, ck.vc[v][2] * fabs(dx)); c_qdx += v_q[v] * dx; scr_dx[var] = dx; }
+          if (var >= 0) { c_ndx = fmax(c_ndx, wv_recip(ck.vc[v][0]) * fabs(dx)); c_qdx += v_q[v] * dx; }
+          dsv.var[v] = dx;
         }
       }
       const double t0 = rho0 * v_z[v] - v_y[v];
@@ -609,14 +669,13 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     double rsum[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
-      const int pk = (int)(v_p[v] - (lds + oXT)), p = pk >> 3, k = pk & 7;
       double r = own[v] + v_p[v][oEX - oXT];
-      const double *pp = lds + oPART + p * lpb * 8 + k;
+      const double *pp = v_pp[v];
       if (LPB > 0) {
 #pragma unroll
-        for (int s2 = 0; s2 < LPB; s2++) r += pp[s2 * 8];
+        for (int s2 = 0; s2 < LPB; s2++) r += pp[s2 * 2];
       } else {
-        for (int s2 = 0; s2 < lpb; s2++) r += pp[s2 * 8];
+        for (int s2 = 0; s2 < lpb; s2++) r += pp[s2 * 2];
       }
       rsum[v] = r;
     }
@@ -636,15 +695,14 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     double vs[NSTEP];
     WvRow<BS> g; double rr = 0.0, ee = 0.0, emk = 0.0;
     if (sw_store) {
-      g = wv_row<BS>(sw_g);                       // row of G of the block being processed; the next block's is in flight
-      rr = sw_v[0]; ee = sw_v[oEF - oR];
+      g = wv_row<BS>(sw_g, sw_gd);                // row of G of the block being processed; the next block's is in flight
+      rr = sw_v[0]; ee = sw_e[0];
       double vprev = 0.0;
 #pragma unroll
       for (int s = 0; s < NSTEP; s++) {
         // prefetch: the chain's next block, or (last step) the middle block
-        const WvRow<BS> gn = wv_row<BS>(s + 1 < NSTEP ? sw_g + (s + 1) * 64 : md_g);
-        const double *vp = s + 1 < NSTEP ? sw_v + (s + 1) * 8 : md_v;
-        const double rn = vp[0], en_ = vp[oEF - oR];
+        const WvRow<BS> gn = s + 1 < NSTEP ? wv_row<BS>(sw_g + (s + 1) * 64, sw_gd + (s + 1) * 64) : wv_row<BS>(md_g, md_g + 48);
+        const double rn = s + 1 < NSTEP ? sw_v[(s + 1) * 2] : md_v[0], en_ = s + 1 < NSTEP ? sw_e[(s + 1) * 8] : md_e[0];
         const double w = __builtin_fma(-ee, vprev, rr);
         vprev = wv_matvec<BS>(0.0, w, g);
         vs[s] = vprev;
@@ -652,15 +710,15 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       }
       // the middle block needs the last vector of BOTH chains: through LDS (the x~ positions of those two blocks)
       emk = lds[oEM + k8];
-      sw_v[(NSTEP - 1) * 8 + (oXT - oR)] = vs[NSTEP - 1];
+      sw_v[(NSTEP - 1) * 2 + (oXT - oR)] = vs[NSTEP - 1];
     }
     WV_SYNC();
     if (sw_store) {
       double xn;
-      const double vA = md_v[-8 + (oXT - oR)], vB = md_v[NSTEP * 8 + (oXT - oR)];
+      const double vA = md_v[-2 + (oXT - oR)], vB = md_v[NSTEP * 2 + (oXT - oR)];
       // prefetch the chain's last block for the backward sweep
-      const WvRow<BS> gn = wv_row<BS>(sw_g + (NSTEP - 1) * 64);
-      const double en_ = sw_v[(NSTEP - 1) * 8 + (oEN - oR)];
+      const WvRow<BS> gn = wv_row<BS>(sw_g + (NSTEP - 1) * 64, sw_gd + (NSTEP - 1) * 64);
+      const double en_ = sw_e[(NSTEP - 1) * 8 + (oEN - oEF)];
       double w = __builtin_fma(-ee, vA, rr);
       w = __builtin_fma(-emk, vB, w);
       xn = wv_matvec<BS>(0.0, w, g);
@@ -669,14 +727,14 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
 #pragma unroll
       for (int s = NSTEP - 1; s >= 0; s--) {
         WvRow<BS> gn2 = g; double en2 = ee;
-        if (s > 0) { gn2 = wv_row<BS>(sw_g + (s - 1) * 64); en2 = sw_v[(s - 1) * 8 + (oEN - oR)]; }
+        if (s > 0) { gn2 = wv_row<BS>(sw_g + (s - 1) * 64, sw_gd + (s - 1) * 64); en2 = sw_e[(s - 1) * 8 + (oEN - oEF)]; }
         const double u = -(ee * xn);
         xn = wv_matvec<BS>(vs[s], u, g);
         vs[s] = xn;
         g = gn2; ee = en2;
       }
 #pragma unroll
-      for (int s = 0; s < NSTEP; s++) sw_v[s * 8 + (oXT - oR)] = vs[s];
+      for (int s = 0; s < NSTEP; s++) sw_v[s * 2 + (oXT - oR)] = vs[s];
       if (srow == 0) md_v[oXT - oR] = xmid;
     }
     WV_SYNC();
@@ -695,6 +753,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     c_ndy = 0.0; c_lhs = 0.0; c_ndx = 0.0; c_qdx = 0.0;
     load_chk();
     sweep(); rows(std::integral_constant<int, 2>{});
+    if (a.ablate & 16) continue;
     // ---- termination test (formulas of admm_check in sco_qp.hip) on the structured layout
     for (int approximate = 0; approximate < 2 && !status; approximate++) {
       if (approximate && iter < a.max_iter) break;
@@ -703,8 +762,8 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       double w_pri = 0.0, w_pn = 0.0, w_dua = 0.0, w_dn = 0.0;
       // rows of the hinge slots; partial sums of A' (w y) over the block's columns
       {
-        const d2 *xp = (const d2 *)(xt_p + (oXC - oXT));
-        const d2 a0 = xp[0], a1 = xp[1], a2 = xp[2], a3 = xp[3];
+        const double *xq = xt_p + (oXC - oXT);
+        const d2 a0 = *(const d2 *)xq, a1 = *(const d2 *)(xq + 2 * NPOS), a2 = *(const d2 *)(xq + 4 * NPOS), a3 = *(const d2 *)(xq + 6 * NPOS);
         const double xc[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
         double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -726,13 +785,12 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
 #pragma unroll
           for (int k = 0; k < BS; k++) part[k] = __builtin_fma(J[k], wy, part[k]);
         }
-        d2 *pp = (d2 *)part_p;
         d2 v0, v1, v2, v3;
         v0.x = part[0]; v0.y = part[1]; v1.x = part[2]; v1.y = part[3]; v2.x = part[4]; v2.y = part[5]; v3.x = part[6]; v3.y = BS > 7 ? part[7] : 0.0;
-        pp[0] = v0; pp[1] = v1; pp[2] = v2; pp[3] = v3;
+        *(d2 *)part_p = v0; *(d2 *)(part_p + nslot2) = v1; *(d2 *)(part_p + 2 * nslot2) = v2; *(d2 *)(part_p + 3 * nslot2) = v3;
       }
       {
-        const double xcv = x_p[oXC - oXT], ax = x_a * xcv, ex = ck.xc[0];
+        const double xcv = x_p[oXC - oXT], ax = x_a * xcv, ex = ck.xc;
         w_pri = fmax(w_pri, ex * fabs(ax - x_z)); w_pn = fmax(w_pn, ex * fmax(fabs(x_z), fabs(ax)));
         if (x_row >= 0) x_p[oEX - oXT] = x_a * (x_w * x_y);
       }
@@ -740,21 +798,26 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
 #pragma unroll
       for (int v = 0; v < NV; v++) {
         const double *c = ck.vc[v];
-        const int pk = (int)(v_p[v] - (lds + oXT)), p = pk >> 3, k = pk & 7;
+        const int vix = (int)(v_p[v] - (lds + oXT)), p = (vix % (2 * NPOS)) >> 1;
         const double dj = c[0], e0 = c[1];
         const double ax = v_a[v] * v_x[v];
         w_pri = fmax(w_pri, e0 * fabs(ax - v_z[v])); w_pn = fmax(w_pn, e0 * fmax(fabs(v_z[v]), fabs(ax)));
         double aty = v_a[v] * v_y[v] + v_p[v][oEX - oXT];
-        const double *pp = lds + oPART + p * lpb * 8 + k;
+        const double *pp = v_pp[v];
         if (LPB > 0) {
 #pragma unroll
-          for (int s2 = 0; s2 < LPB; s2++) aty += pp[s2 * 8];
+          for (int s2 = 0; s2 < LPB; s2++) aty += pp[s2 * 2];
         } else {
-          for (int s2 = 0; s2 < lpb; s2++) aty += pp[s2 * 8];
+          for (int s2 = 0; s2 < lpb; s2++) aty += pp[s2 * 2];
         }
-        double px = c[4] * lds[oXC + ck.pkm[v]] + c[5] * lds[oXC + ck.pkp[v]];
+        double px = c[2] * lds[oXC + ck.pkm[v]] + c[3] * lds[oXC + ck.pkp[v]];
+        if (pdense) {
+          const double *cd = wv_opaque(cstg0) + (size_t)(wv_cst_v(NS, v) + 5) * 64;
 #pragma unroll
-        for (int k2 = 0; k2 < BS; k2++) px = __builtin_fma(c[6 + k2], lds[oXC + p * 8 + k2], px);
+          for (int k2 = 0; k2 < BS; k2++) px = __builtin_fma(cd[k2 * 64], lds[oXC + wv_vidx(NPOS, p, k2)], px);
+        } else {
+          px = __builtin_fma(c[4], v_x[v], px);
+        }
         if (v_on[v]) {
           w_dua = fmax(w_dua, dj * fabs(v_q[v] + px + aty));
           w_dn = fmax(w_dn, dj * fmax(fabs(v_q[v]), fmax(fabs(aty), fabs(px))));
@@ -768,11 +831,26 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       const double eps_p = ea + er * w_pn, eps_d = ea + er * cinv * w_dn;
       const bool prim_ok = (m == 0) || (pri < eps_p), dual_ok = dua < eps_d;
       if (prim_ok && dual_ok) { status = approximate ? SCO_QP_SOLVED_INACCURATE : SCO_QP_SOLVED; break; }
-      // the two infeasibility certificates (rare): generic loops over the pattern, delta_y / delta_x from the scratch
-      // arrays the checked step has filled
+      // the two infeasibility certificates (rare): generic loops over the pattern; delta_y / delta_x go to the scratch
+      // arrays only now
       const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
+      auto spill_deltas = [&]() {
+#pragma unroll
+        for (int q = 0; q < NS; q++) {
+          if (ck.h[q] >= 0) scr_dy[ck.h[q]] = dsv.h[q];
+          if (ck.br[q] >= 0) scr_dy[ck.br[q]] = dsv.b[q];
+          if (ck.ev[q] >= 0) scr_dx[ck.ev[q]] = dsv.e[q];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          if (ck.r0[v] >= 0) scr_dy[ck.r0[v]] = dsv.r0[v];
+          if (ck.var[v] >= 0) scr_dx[ck.var[v]] = dsv.var[v];
+        }
+        if (x_row >= 0) scr_dy[x_row] = dsv.x;
+        __threadfence(); __syncthreads();          // global memory hand-over between lanes: a real fence
+      };
       if (!prim_ok && ndy > epi && lhs < -epi * ndy) {
-        __threadfence_block(); WV_SYNC();
+        spill_deltas();
         double nat = 0.0;
         for (int j = lane; j < n; j += WV_T) {
           double aty = 0.0;
@@ -783,7 +861,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         if (nat < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
       }
       if (!dual_ok && ndx > edi && qdx < -cscale * edi * ndx) {
-        __threadfence_block(); WV_SYNC();
+        spill_deltas();
         const double *Psg = a.Ps + (size_t)b * a.nnzP;
         double npx = 0.0;
         for (int j = lane; j < n; j += WV_T) {
@@ -872,7 +950,7 @@ static void wv_fill_args(const AdmmArgs &aa, const WvHost &wh, const WvDev &wd, 
   a.cst_slots = wh.cst_slots; a.g_doubles = wh.g_doubles;
   a.rho = aa.rho; a.sigma = aa.sigma; a.alpha = aa.alpha; a.eps_abs = aa.eps_abs; a.eps_rel = aa.eps_rel;
   a.eps_prim_inf = aa.eps_prim_inf; a.eps_dual_inf = aa.eps_dual_inf;
-  a.tab = wd.tab; a.G = wd.G; a.cst = wd.cst; a.wc = wd.wc; a.scr = wd.scr; a.ok = wd.ok; a.rl_need = wd.rl_need; a.w_ready = wd.w_ready;
+  a.tab = wd.tab; a.G = wd.G; a.cst = wd.cst; a.wc = wd.wc; a.scr = wd.scr; a.ok = wd.ok; a.rl_need = wd.rl_need; a.w_ready = wd.w_ready; a.pflag = wd.pflag;
   a.As = d.As; a.Ps = d.Ps; a.qs = d.qs; a.ls = d.ls; a.us = d.us; a.rhov = d.rho; a.kee_inv = d.kee_inv; a.cscale = d.cscale;
   a.D = d.D; a.E = d.E; a.S = d.W; a.w = d.w; a.active = d.active; a.setup_active = setup_mask;
   a.Ap = d.Ap; a.Ai = d.Ai; a.Rp = d.Rp; a.Rj = d.Rj; a.Rpos = d.Rpos; a.Fp = d.Fp; a.Fi = d.Fi; a.Fpos = d.Fpos;

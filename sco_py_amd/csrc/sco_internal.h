@@ -156,7 +156,7 @@ struct WvHost {
 // row-local kernel solves it: rl_need = its setup mask); scr: [batch][m + n] delta_y / delta_x of the last checked iteration
 // w_ready: [batch] 1 = the problem's W buffer holds the dense inverse (the row-local kernel can run it), 0 = it still
 // holds S (the wavefront tier factored this QP; qp_sweep_kernel has to run before the row-local kernel takes over)
-struct WvDev { const int *tab; double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready; };
+struct WvDev { const int *tab; double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready, *pflag; };
 bool wv_plan_build(const QpPlan &pl, WvHost &wh);
 int wv_upload(const WvHost &wh, int batch, int n, int m, std::vector<void *> &allocs, WvDev &wd);
 int wv_launch_factor(const AdmmArgs &a, const int *setup_mask, const WvHost &wh, const WvDev &wd, hipStream_t st);

@@ -27,11 +27,12 @@ def timeit(B, ablate, iters=20000):
     os.environ["SCO_WV_ABLATE"] = str(ablate)
     qp = L.BatchedQP(B, n, m, Pp, Pi, Ap, Ai)
     qp.load(Pval, q, Aval, l, u, None)
-    st = L.default_qp_settings(max_iter=iters, check_termination=0 if ablate else 25)
+    st = L.default_qp_settings(max_iter=iters, check_termination=0 if ablate in (1, 2, 3, 4) else 25)
     qp.solve(st); qp.solve(st)
     tm = qp.last_timing(); qp.close()
     return 1e3 * tm["admm_ms"] / iters
 
-for B in (64, 1024, 2048):
-    for ab, name in ((0, "full (with termination tests)"), (4, "full, no termination tests"), (1, "no sweeps"), (2, "no row passes"), (3, "neither")):
+for B in (64, 1024):
+    for ab, name in ((0, "full (with termination tests)"), (4, "full, no termination tests"), (8, "tests, constants not fetched"),
+                     (16, "checked iterations, no test pass"), (24, "checked iterations, no fetch, no pass"), (1, "no sweeps"), (2, "no row passes")):
         print("B=%5d %-32s %.3f us per iteration" % (B, name, timeit(B, ab)))

@@ -1122,3 +1122,26 @@ def test_wavefront_rounds_then_row_local_tail_agree_with_the_row_local_loop(gpu,
     assert all(np.array_equal(x[:, [0, 4, 5, 6, 7]], y[:, [0, 4, 5, 6, 7]]) for x, y in zip(a.trace, b.trace))
     assert np.abs(a.x - b.x).max() < 1e-9
     _compare(a, probs, range(0, nb, 160))
+
+
+@pytest.mark.parametrize("kw,params", [
+    (dict(d=3, T=6, K=2, O=2), {}), (dict(d=3, T=6, K=2, O=2), dict(compound_penalty=0, duplicate_rows=0, max_sqp_iters=20)),
+    (dict(), {}), (dict(d=2, T=8, O=3, point=True), {}), (dict(d=2, T=8, O=3, quadratic=True), {}),
+    (dict(d=2, T=8, K=1, program=True), {}), (dict(d=3, T=6, K=2, O=2, ee_cost_weight=0.5), {})],
+    ids=["3x6", "3x6 quirks off", "7x20", "point", "quadratic rows", "program rows", "objective terms"])
+def test_wavefront_tier_forced_through_the_device_loop(gpu, monkeypatch, kw, params):
+    """By default a round goes to the wavefront tier only with > 3.3 live problems per CU; SCO_WV_MIN_PER_CU=0 sends every
+    round of every batch there: decisions, QP statuses, iteration counts and trajectories of the flat oracle for the
+    families whose penalty QP the tier takes (dense P blocks of the objective terms included), time slices of 300."""
+    monkeypatch.setenv("SCO_WV_MIN_PER_CU", "0")
+    nb = 6 if not kw else 12
+    arrays, probs = af.make_batch(nb, **kw)
+    dp = _lib.default_sqp_params(admm_slice=300, **params)
+    op = sr.SolverParams(compound_penalty=False, duplicate_rows=False, max_qp_solves=20) if params else None
+    res = sb.solve_batch(arrays, params=dp)
+    if kw.get("ee_cost_weight") is None:
+        _compare(res, probs, range(0, nb, 2), op)
+    else:       # numeric Hessians: iteration counts of QPs that stop on max_iter may differ by one check (DESIGN 4)
+        for b in range(0, nb, 2):
+            ref = sr.penalty_sqp(sr.trajopt_flat(probs[b]), emulate_memo=True)
+            assert np.array_equal(res.trace[b][:, 0], ref.trace[:64, 0]) and np.abs(res.x[b] - ref.x).max() < TOL
