@@ -82,7 +82,8 @@ __host__ __device__ inline WvTab wv_tab_layout(int NS, int NV) {
 __host__ __device__ inline int wv_cst_h(int q) { return 3 * q; }
 __host__ __device__ inline int wv_cst_v(int NS, int v) { return 3 * NS + 13 * v; }
 __host__ __device__ inline int wv_cst_x(int NS, int NV) { return 3 * NS + 13 * NV; }
-__device__ __forceinline__ double wv_recip(double x) { return x != 0.0 ? 1.0 / x : 0.0; }
+// (v_rcp_f64, one instruction: these reciprocals only scale the norms of the infeasibility tests)
+__device__ __forceinline__ double wv_recip(double x) { return x != 0.0 ? __builtin_amdgcn_rcp(x) : 0.0; }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host plan
@@ -748,10 +749,13 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   while (!status && iter < stop) {
     int next = stop;
     if (a.check > 0) { next = (iter / a.check + 1) * a.check; if (next > stop) next = stop; }
-    while (iter + 1 < next) { iter++; if (!(a.ablate & 1)) sweep(); if (!(a.ablate & 2)) rows(std::integral_constant<int, 1>{}); }
+    while (iter + 2 < next) { iter++; if (!(a.ablate & 1)) sweep(); if (!(a.ablate & 2)) rows(std::integral_constant<int, 1>{}); }
+    // the checked iteration's constants are asked for one iteration early: their round trip (L2 / HBM, every wavefront of
+    // the chip at the same moment) then runs under two iterations' arithmetic
+    load_chk();
+    if (iter + 1 < next) { iter++; if (!(a.ablate & 1)) sweep(); if (!(a.ablate & 2)) rows(std::integral_constant<int, 1>{}); }
     iter++;
     c_ndy = 0.0; c_lhs = 0.0; c_ndx = 0.0; c_qdx = 0.0;
-    load_chk();
     sweep(); rows(std::integral_constant<int, 2>{});
     if (a.ablate & 16) continue;
     // ---- termination test (formulas of admm_check in sco_qp.hip) on the structured layout

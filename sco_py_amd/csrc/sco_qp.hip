@@ -1038,10 +1038,10 @@ int sco_qp_launch(sco_qp *qp, const sco_qp_settings *st, const int *active_dev, 
   return sco_qp_launch_sliced(qp, st, active_dev, active_dev, 0, mid, nullptr);
 }
 
-// fewest problems of a launch for which the wavefront tier is the faster one (SCO_WV_MIN_PER_CU: problems per CU, default 3.3)
+// fewest problems of a launch for which the wavefront tier is the faster one (SCO_WV_MIN_PER_CU: problems per CU, default 3.0)
 int sco_wv_min_live(int cus) {
   const char *e = getenv("SCO_WV_MIN_PER_CU");
-  const double per = e ? atof(e) : 3.3;
+  const double per = e ? atof(e) : 3.0;
   return (int)(per * (cus > 0 ? cus : 256));
 }
 
@@ -1104,7 +1104,7 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
               adaptive ? 1 : 0, adaptive ? sco_qp_adaptive_interval(st) : 0, st->adaptive_rho_tolerance, nullptr};
   // The wavefront tier runs cold-start, fixed-rho solves (parity mode); the opt-in extensions keep the row-local kernel.
   // It puts four problems on a CU at ~3.1 us per iteration each where the row-local kernel runs one at ~0.95 us: it is
-  // the faster way through a launch only with more than ~3.3 problems per CU to run (profiles/r04_wv.txt).  The SQP loop
+  // the faster way through a launch only with more than ~3 problems per CU to run (profiles/r04_wv.txt).  The SQP loop
   // says per round which one it wants (QpGroup::tier, from its live count); a plain sco_qp_solve goes by the batch.
   const bool wv_can = qp->use_wv && !aa.warm && !adaptive && !st->warm_start;
   const int wv_min = sco_wv_min_live(qp->cus);
