@@ -58,6 +58,19 @@ def onchip_model(d, T, K, O, projection=False):
     return flops, lds
 
 
+def wavefront_model(d, T, K, O):
+    """Counted flops of ONE ADMM iteration of one penalty QP on the wavefront tier (csrc/sco_admm_wv.hip): the
+    core solve is the twisted block-tridiagonal sweep -- every block but the middle one is visited twice (forward, backward),
+    a visit = a d x d mat-vec + d coupling multiply-adds -- instead of the dense n_c x n_c mat-vec of the row-local kernel;
+    A x~ and A' t' (one FMA per non-zero each), 12 per row and 4 per variable as in onchip_model."""
+    n_x, R = d * T, K * O
+    n = n_x + T * R
+    m = 2 * d + T * R + n
+    nnzA = 2 * d + T * R * (d + 1) + n
+    sweep = (2 * (T - 1) + 1) * (d * d + d)
+    return 2 * (sweep + 2 * nnzA) + 12 * m + 4 * n
+
+
 def kernel_src_sha():
     """Hash of every kernel source: a PMC measurement is only quoted for the kernels it was taken on."""
     import hashlib
@@ -272,6 +285,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=None, help="problems per GPU (default 1024; 256 for 12x50)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="STRONG scaling: this many problems in total, split over the GPUs (e.g. 8192 = BASELINE configs[3]); "
+                         "the default is weak scaling, --batch problems per GPU")
     ap.add_argument("--workload", choices=["7x20", "12x50"], default="7x20",
                     help="7x20 = BASELINE configs[2] (headline); 12x50 = configs[4] shape (structured global-memory tier)")
     ap.add_argument("--cpu-problems", type=int, default=16, help="size of the CPU-baseline sample (0 = skip)")
@@ -334,7 +350,7 @@ def main():
         """Load `B` problems per rank (resident in HBM before the clock starts), time `steps` complete sharded solves."""
         big = workload == "12x50"
         dims = dict(d=12, T=50, K=10, O=10) if big else dict(d=7, T=20, K=5, O=2)
-        total = B * world
+        total = args.global_batch if (args.global_batch and not big) else B * world
         lo, hi = sd.shard_range(total, rank, world)
         arrays, _ = af.make_batch(hi - lo, first=lo, **dims)
         params = _lib.default_sqp_params()
@@ -355,15 +371,21 @@ def main():
         sync()
         t0 = time.perf_counter()
         sco_iters = 0; admm_ms = 0.0; qp_launches = 0; groups = 1
+        wv = dict(ms=0.0, iters=0, launches=0, other_ms=0.0, other_launches=0)
+        my_iters = 0
         stage_ms = np.zeros(5)
         for _ in range(steps):
             res, allrec = sd.solve_sharded(tb, total, params, qs)   # solve the shard + RCCL all-gather of 24 B/problem (no-op at N = 1)
             sco_iters += int(allrec["sqp_iters"].sum())
+            my_iters += int(res.sqp_iters.sum())
             tm = tb.last_timing()                                  # HIP-event sums of the step just finished, taken on the library's stream
             stage_ms += [tm["convexify_ms"], tm["qp_setup_ms"], tm["admm_ms"], tm["decide_ms"], tm["total_ms"]]
             admm_ms += tm["admm_ms"]
             qp_launches += tm["launches"]                         # penalty-QP launches over all stream groups (the projection launch is tiny)
             groups = tm["groups"]
+            wv["ms"] += tm["wv_ms"]; wv["iters"] += tm["wv_iters"]; wv["launches"] += tm["wv_launches"]
+            wv["other_ms"] += tm["other_admm_ms"]; wv["other_launches"] += tm["other_launches"]
+        my_elapsed = time.perf_counter() - t0               # this rank's own clock, before the closing barrier
         sync()
         elapsed = time.perf_counter() - t0
         # bookkeeping outside the timed region: every step solves the same loaded problems and the solve is
@@ -373,9 +395,12 @@ def main():
         it_pen = steps * sum(int(t[1:, 7].sum()) for t in traces)
         qp_solves = steps * int(res.qp_solves.sum())
         tb.close()
+        # per-rank record of the step (north_star risk: data-dependent iteration counts -> unequal shards): own clock, own
+        # SCO iterations, own ADMM time; gathered like the result records (three doubles per rank), imbalance = max / mean
+        per_rank = sd.gather_rank_stats([my_elapsed, float(my_iters), admm_ms * 1e-3]) if world > 1 else np.array([[my_elapsed, float(my_iters), admm_ms * 1e-3]])
         if world > 1:
             elapsed = sd.max_over_ranks(elapsed)                  # device tensor under RCCL, host tensor under gloo
-        return dict(dims=dims, B=B, total=total, steps=steps, elapsed=elapsed, sco_iters=sco_iters, admm_ms=admm_ms,
+        return dict(dims=dims, B=B, total=total, steps=steps, elapsed=elapsed, sco_iters=sco_iters, admm_ms=admm_ms, wv=wv, per_rank=per_rank,
                     qp_launches=qp_launches, groups=groups, stage_ms=stage_ms / steps, it_proj=it_proj, it_pen=it_pen, qp_solves=qp_solves,
                     success=float(np.mean(allrec["success"] != 0)))
 
@@ -407,24 +432,55 @@ def main():
                             "(HIP events on the library stream)"}
         f_pen, l_pen = onchip_model(d["d"], d["T"], d["K"], d["O"])
         f_pro, l_pro = onchip_model(d["d"], d["T"], d["K"], d["O"], projection=True)
-        flops = r["it_pen"] * f_pen + r["it_proj"] * f_pro
-        lds = r["it_pen"] * l_pen + r["it_proj"] * l_pro
-        tj, src = measured_traffic("r03_traffic.json")
-        traffic = tj["hbm_bytes_per_step"] * r["steps"] / launches if tj and r["B"] == tj.get("batch") else None
-        return {"bound": "valu_f64", "kernel": "qp_admm_rl_kernel", "achieved": flops / secs / 1e12 if secs > 0 else 0.0,
-                "peak": F64_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / secs / F64_PEAK if secs > 0 else 0.0,
-                "traffic": traffic, "traffic_source": src,
-                "onchip": {"valu_frac": flops / secs / F64_PEAK if secs > 0 else 0.0,
-                           "lds_frac": lds / secs / LDS_PEAK if secs > 0 else 0.0,
-                           "flops_per_problem_iteration": f_pen, "lds_bytes_per_problem_iteration": l_pen,
+        f_wv = wavefront_model(d["d"], d["T"], d["K"], d["O"])
+        its_all = r["it_pen"] + r["it_proj"]
+        w = r["wv"]
+        # the step's ADMM launches by kernel: wavefront tier (rounds with >= ~3 live problems per CU) and the row-local
+        # kernel (the tail of the step, the projection QPs); each priced against its OWN HIP-event time and its own count
+        # of problem-iterations (the library counts the wavefront kernel's on the device)
+        its_wv, secs_wv = w["iters"], w["ms"] * 1e-3
+        its_rl, secs_rl = its_all - its_wv, w["other_ms"] * 1e-3
+        flops_rl = max(its_rl - r["it_proj"], 0) * f_pen + r["it_proj"] * f_pro
+        tiers = {
+            "wavefront": {"kernel": "qp_admm_wv_kernel<7,4,3,10,3>", "ms_per_step": w["ms"] / r["steps"], "launches_per_step": w["launches"] / r["steps"],
+                          "avg_launch_ms": w["ms"] / max(w["launches"], 1), "problem_iterations_per_step": its_wv / r["steps"],
+                          "problem_iterations_per_us_per_cu": its_wv / secs_wv / 1e6 / N_CU if secs_wv > 0 else None,
+                          "flops_per_problem_iteration": f_wv, "valu_frac": its_wv * f_wv / secs_wv / F64_PEAK if secs_wv > 0 else None},
+            "row_local": {"kernel": "qp_admm_rl_kernel<5,9,12,false,2,0>", "ms_per_step": w["other_ms"] / r["steps"],
+                          "launches_per_step": w["other_launches"] / r["steps"], "avg_launch_ms": w["other_ms"] / max(w["other_launches"], 1),
+                          "problem_iterations_per_step": its_rl / r["steps"],
+                          "problem_iterations_per_us_per_cu": its_rl / secs_rl / 1e6 / N_CU if secs_rl > 0 else None,
+                          "flops_per_problem_iteration": f_pen, "valu_frac": flops_rl / secs_rl / F64_PEAK if secs_rl > 0 else None},
+        }
+        use_wv = secs_wv >= secs_rl
+        dom = tiers["wavefront" if use_wv else "row_local"]
+        flops = its_wv * f_wv if use_wv else flops_rl
+        dsecs = secs_wv if use_wv else secs_rl
+        dlaunches = max(w["launches"] if use_wv else w["other_launches"], 1)
+        tj, src = measured_traffic("r04_traffic.json")
+        key = "wavefront" if use_wv else "row_local"
+        traffic = None
+        if tj and r["B"] == tj.get("batch") and key in tj.get("hbm_bytes_per_launch", {}):
+            traffic = tj["hbm_bytes_per_launch"][key]
+        return {"bound": "valu_f64", "kernel": dom["kernel"], "achieved": flops / dsecs / 1e12 if dsecs > 0 else 0.0,
+                "peak": F64_PEAK / 1e12, "unit": "TFLOP/s", "frac": flops / dsecs / F64_PEAK if dsecs > 0 else 0.0,
+                "traffic": traffic, "traffic_source": "PMC passes stored under " + src if tj else src,
+                "problem_iterations_per_us_per_cu": {"this_run_all_admm_launches": its_all / secs / 1e6 / N_CU if secs > 0 else None,
+                                                     "r03_row_local_only": 1.05},
+                "frac_at_the_r03_flop_count": its_all * f_pen / secs / F64_PEAK if secs > 0 else None,
+                "tiers": tiers,
+                "onchip": {"valu_frac": flops / dsecs / F64_PEAK if dsecs > 0 else 0.0,
+                           "flops_per_problem_iteration": dom["flops_per_problem_iteration"],
                            "clock_ghz_assumed": CLOCK_HZ / 1e9, "clock_ghz_measured": (tj or {}).get("clock_ghz_measured"), "cus": N_CU},
                 "hbm_measured": {"bytes_per_launch": traffic,
-                                 "frac_of_8TBps": traffic * launches / secs / HBM_PEAK if traffic and secs > 0 else None},
+                                 "frac_of_8TBps": traffic * dlaunches / dsecs / HBM_PEAK if traffic and dsecs > 0 else None},
                 "hbm_equivalent": hbm_eq,
-                "note": "bound = the f64 VECTOR ALU (the kernel holds no MFMA instruction).  f64 peak of MI355X: 64 FMA/clk/CU on the vector ALU = its dense f64 MFMA rate (78.6 TFLOP/s at 2.4 GHz); "
-                        "the kernel has no GEMM-shaped work (one dense 140 x 140 mat-vec per problem-iteration with a different "
-                        "matrix per problem), so its flops issue on the vector ALU and are priced against that peak.  Iterates live "
-                        "in LDS / registers for a whole solve: HBM sees the problem once per launch (hbm_measured, PMC)"}
+                "note": "bound = the f64 VECTOR ALU (no MFMA in either ADMM kernel).  r04 changed the algebra of the kernel that runs "
+                        "most of the step: a twisted block-tridiagonal sweep (20.2 k counted flops per problem-iteration) instead "
+                        "of the dense 140 x 140 inverse (55.0 k), one wavefront per problem and four problems per CU -- so frac "
+                        "(counted flops / peak) FELL while problem-iterations per second rose; compare problem_iterations_per_us_per_cu "
+                        "and frac_at_the_r03_flop_count (what the same launches would score at the old flop count).  Iterates live in "
+                        "registers / LDS for a whole launch: HBM sees the problem once per launch (hbm_measured, PMC)"}
 
     big = args.workload == "12x50"
     B = args.batch if args.batch is not None else (256 if big else 1024)
@@ -475,7 +531,7 @@ def main():
             "unit": "sco_iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * r["elapsed"] / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if (args.global_batch and not big) else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("batch=%d independent 12-DOF x 50-timestep planar-arm trajopt problems per GPU "
                                     "(n=5600, m=10624 + duplicated penalty rows, 5000 nonlinear rows), penalty SQP with "
@@ -495,6 +551,10 @@ def main():
                     "success_fraction": r["success"],
                     "sco_iters_per_step": r["sco_iters"] / args.steps,          # over ALL ranks (from the gathered records)
                     "backend": (dist.get_backend() if world > 1 else None),
+                    # per rank: own clock of the timed region (s), own SCO iterations, own ADMM device time (s)
+                    "per_rank": {"elapsed_s": r["per_rank"][:, 0].round(6).tolist(), "sco_iters": r["per_rank"][:, 1].astype(int).tolist(),
+                                 "admm_s": r["per_rank"][:, 2].round(6).tolist(),
+                                 "imbalance_max_over_mean": float(r["per_rank"][:, 0].max() / max(r["per_rank"][:, 0].mean(), 1e-12))},
                     "admm_launches_per_step": r["qp_launches"] / args.steps,
                     "stream_groups": r["groups"],
                     "kernel_src_sha": kernel_src_sha()},

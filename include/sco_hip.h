@@ -356,6 +356,13 @@ int sco_sqp_last_rounds(const sco_sqp *h, int *rounds);
  * groups it used (either pointer may be null). */
 int sco_sqp_last_launches(const sco_sqp *h, int *launches, int *groups);
 
+/* The ADMM launches of the last solve by kernel tier (diagnostics; bench.py prices each kernel against its own time):
+ * index 0 = the wavefront tier (csrc/sco_admm_wv.hip: one wavefront per problem, rounds with >= ~3 live problems per CU),
+ * 1 = the other ADMM kernels (row-local kernel ...: the tail of a step, small batches).  ms: HIP-event time of those launches
+ * (ms[0] + ms[1] = ms[2] of sco_sqp_last_timing); iters[0]: problem-iterations the wavefront kernel ran, iters[1] = -1 (the
+ * rest of sco_sqp_fetch's admm_iters sum, the projection QPs included); launches: rounds on either. */
+int sco_sqp_last_tiers(const sco_sqp *h, double ms[2], long long iters[2], int launches[2]);
+
 /* Per-problem decision trace of the last solve, for stage-wise parity checks:
  * trace[batch][cap][8] = {kind, merit, model_merit, new_merit, trust, penalty,
  * qp_status, qp_iters}; n_entries[batch].  kind: 0 projection QP, 1 accepted step,

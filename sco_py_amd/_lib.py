@@ -90,6 +90,7 @@ ABI = {
     "sco_sqp_fetch_flags": (C.c_int, [C.c_void_p, _IP]),
     "sco_sqp_last_rounds": (C.c_int, [C.c_void_p, _IP]),
     "sco_sqp_last_launches": (C.c_int, [C.c_void_p, _IP, _IP]),
+    "sco_sqp_last_tiers": (C.c_int, [C.c_void_p, _DP, _LP, _IP]),
     "sco_sqp_solve": (C.c_int, [C.c_void_p, C.POINTER(SqpParams), C.POINTER(QpSettings)]),
     "sco_sqp_fetch": (C.c_int, [C.c_void_p, _DP, _IP, _IP, _IP, _LP, _DP, _DP]),
     "sco_sqp_trace": (C.c_int, [C.c_void_p, C.c_int, _DP, _IP]),

@@ -233,9 +233,14 @@ class TrajOptBatch(object):
         _lib.check(_lib.load().sco_sqp_last_rounds(self._h, C.byref(rounds)))
         launches, groups = C.c_int(0), C.c_int(0)
         _lib.check(_lib.load().sco_sqp_last_launches(self._h, C.byref(launches), C.byref(groups)))
+        tms = np.zeros(2); tit = np.zeros(2, dtype=np.int64); tl = np.zeros(2, dtype=np.int32)
+        _lib.check(_lib.load().sco_sqp_last_tiers(self._h, _lib.dptr(tms), tit.ctypes.data_as(C.POINTER(C.c_longlong)), _lib.iptr(tl)))
         return dict(convexify_ms=float(ms[0]), qp_setup_ms=float(ms[1]), admm_ms=float(ms[2]),
                     decide_ms=float(ms[3]), total_ms=float(ms[4]), rounds=int(rounds.value),
-                    launches=int(launches.value), groups=int(groups.value))
+                    launches=int(launches.value), groups=int(groups.value),
+                    # ADMM launches by kernel tier: wavefront tier (rounds with >= ~3 live problems per CU) / the rest
+                    wv_ms=float(tms[0]), wv_iters=int(tit[0]), wv_launches=int(tl[0]), other_admm_ms=float(tms[1]),
+                    other_launches=int(tl[1]))
 
 
 def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_jac=False, prox_count=2):

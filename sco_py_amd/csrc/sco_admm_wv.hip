@@ -208,6 +208,8 @@ int wv_upload(const WvHost &wh, int batch, int n, int m, std::vector<void *> &al
   SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
   SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(int))); allocs.push_back(p); wd.rl_need = (int *)p;
   SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
+  SCO_HIP(hipMalloc(&p, sizeof(unsigned long long))); allocs.push_back(p); wd.it_count = (unsigned long long *)p;
+  SCO_HIP(hipMemset(p, 0, sizeof(unsigned long long)));
   SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(int))); allocs.push_back(p); wd.pflag = (int *)p;
   SCO_HIP(hipMemset(p, 0, (size_t)batch * sizeof(int)));
   SCO_HIP(hipMalloc(&p, (size_t)batch * sizeof(int))); allocs.push_back(p); wd.w_ready = (int *)p;
@@ -225,7 +227,7 @@ struct WvArgs {
   int bs, nb, mid, lpb, n_extra, NS, NV, NSTEP, cst_slots; size_t g_doubles;
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
   const int *tab;
-  double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready, *pflag;
+  double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready, *pflag; unsigned long long *it_count;
   const double *As, *Ps, *qs, *ls, *us, *rhov, *kee_inv, *cscale, *D, *E, *S;
   const int *w, *active, *setup_active;
   const int *Ap, *Ai, *Rp, *Rj, *Rpos, *Fp, *Fi, *Fpos;
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       if (r0 >= 0) { sz[r0] = v_z[v]; sy[r0] = v_y[v]; stp[r0] = rho0 * v_z[v] - v_y[v]; }
     }
     if (x_row >= 0) { sz[x_row] = x_z; sy[x_row] = x_y; stp[x_row] = x_w * (x_rho * x_z - x_y); }
-    if (lane == 0) { a.prog[b] = iter; a.status[b] = 0; a.iters[b] = iter; }
+    if (lane == 0) { a.prog[b] = iter; a.status[b] = 0; a.iters[b] = iter; atomicAdd(a.it_count, (unsigned long long)(iter - it0)); }
     return;
   }
   if (a.slice > 0 && lane == 0) a.prog[b] = 0;
@@ -939,7 +941,10 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       if (r0 >= 0) yo[r0] = cinv * Eg[r0] * v_y[v];
     }
     if (x_row >= 0) yo[x_row] = cinv * Eg[x_row] * x_y * x_w;
-    if (lane == 0) { a.status[b] = status; a.iters[b] = iter; a.resid[2 * (size_t)b] = pri; a.resid[2 * (size_t)b + 1] = dua; }
+    if (lane == 0) {
+      a.status[b] = status; a.iters[b] = iter; a.resid[2 * (size_t)b] = pri; a.resid[2 * (size_t)b + 1] = dua;
+      atomicAdd(a.it_count, (unsigned long long)(iter - it0));
+    }
   }
 }
 
@@ -954,7 +959,7 @@ static void wv_fill_args(const AdmmArgs &aa, const WvHost &wh, const WvDev &wd, 
   a.cst_slots = wh.cst_slots; a.g_doubles = wh.g_doubles;
   a.rho = aa.rho; a.sigma = aa.sigma; a.alpha = aa.alpha; a.eps_abs = aa.eps_abs; a.eps_rel = aa.eps_rel;
   a.eps_prim_inf = aa.eps_prim_inf; a.eps_dual_inf = aa.eps_dual_inf;
-  a.tab = wd.tab; a.G = wd.G; a.cst = wd.cst; a.wc = wd.wc; a.scr = wd.scr; a.ok = wd.ok; a.rl_need = wd.rl_need; a.w_ready = wd.w_ready; a.pflag = wd.pflag;
+  a.tab = wd.tab; a.G = wd.G; a.cst = wd.cst; a.wc = wd.wc; a.scr = wd.scr; a.ok = wd.ok; a.rl_need = wd.rl_need; a.w_ready = wd.w_ready; a.pflag = wd.pflag; a.it_count = wd.it_count;
   a.As = d.As; a.Ps = d.Ps; a.qs = d.qs; a.ls = d.ls; a.us = d.us; a.rhov = d.rho; a.kee_inv = d.kee_inv; a.cscale = d.cscale;
   a.D = d.D; a.E = d.E; a.S = d.W; a.w = d.w; a.active = d.active; a.setup_active = setup_mask;
   a.Ap = d.Ap; a.Ai = d.Ai; a.Rp = d.Rp; a.Rj = d.Rj; a.Rpos = d.Rpos; a.Fp = d.Fp; a.Fi = d.Fi; a.Fpos = d.Fpos;

@@ -156,7 +156,8 @@ struct WvHost {
 // row-local kernel solves it: rl_need = its setup mask); scr: [batch][m + n] delta_y / delta_x of the last checked iteration
 // w_ready: [batch] 1 = the problem's W buffer holds the dense inverse (the row-local kernel can run it), 0 = it still
 // holds S (the wavefront tier factored this QP; qp_sweep_kernel has to run before the row-local kernel takes over)
-struct WvDev { const int *tab; double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready, *pflag; };
+// it_count: [1] ADMM iterations the tier's kernel has run since the last reset (diagnostics: per-tier rates of bench.py)
+struct WvDev { const int *tab; double *G, *cst, *wc, *scr; int *ok, *rl_need, *w_ready, *pflag; unsigned long long *it_count; };
 bool wv_plan_build(const QpPlan &pl, WvHost &wh);
 int wv_upload(const WvHost &wh, int batch, int n, int m, std::vector<void *> &allocs, WvDev &wd);
 int wv_launch_factor(const AdmmArgs &a, const int *setup_mask, const WvHost &wh, const WvDev &wd, hipStream_t st);
@@ -251,5 +252,7 @@ int sco_qp_launch_sliced(sco_qp *qp, const sco_qp_settings *st, const int *setup
 bool sco_qp_supports_groups(const sco_qp *qp, const sco_qp_settings *st);
 int sco_qp_adaptive_interval(const sco_qp_settings *st);
 int sco_wv_min_live(int cus);      // fewest live problems for which a round runs on the wavefront tier
-bool sco_qp_has_wv(const sco_qp *qp, const sco_qp_settings *st);   // the handle holds the wavefront tier and these settings can use it
+bool sco_qp_has_wv(const sco_qp *qp, const sco_qp_settings *st);
+int sco_qp_wv_iters(const sco_qp *qp, unsigned long long *out);      // iterations run by the wavefront kernel since the reset
+void sco_qp_wv_iters_reset(sco_qp *qp, hipStream_t st);   // the handle holds the wavefront tier and these settings can use it
 bool sco_qp_can_adapt(const sco_qp *qp);   // false: this handle sits on the dense global-memory tier, which cannot park a solve

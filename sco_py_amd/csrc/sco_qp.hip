@@ -1055,6 +1055,13 @@ int sco_qp_adaptive_interval(const sco_qp_settings *st) {
   return st->check_termination > 0 ? 4 * st->check_termination : 100;
 }
 
+int sco_qp_wv_iters(const sco_qp *qp, unsigned long long *out) {
+  *out = 0;
+  if (!qp->use_wv) return SCO_OK;
+  SCO_HIP(hipMemcpy(out, qp->wvd.it_count, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return SCO_OK;
+}
+void sco_qp_wv_iters_reset(sco_qp *qp, hipStream_t st) { if (qp->use_wv) (void)hipMemsetAsync(qp->wvd.it_count, 0, sizeof(unsigned long long), st); }
 bool sco_qp_has_wv(const sco_qp *qp, const sco_qp_settings *st) { return qp->use_wv && !st->warm_start && !st->adaptive_rho; }
 bool sco_qp_can_adapt(const sco_qp *qp) { return !(qp->use_big && !qp->use_bt); }
 

@@ -131,6 +131,7 @@ struct sco_sqp {
   int rounds = 0;          // 1 (projection) + the rounds of the group that needed most
   int launches = 0;        // round launches over all stream groups
   int wv_rounds = 0;       // of them on the wavefront tier
+  double wv_ms = 0.0;      // ADMM time of those rounds (part of last_ms[2])
 };
 
 // --------------------------------------------------------------------------
@@ -1646,6 +1647,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && s.batch <= cus) slice_req = 0;
   }
   SCO_HIP(hipMemsetAsync(h->qp1->d.prog, 0, (size_t)s.batch * sizeof(int), h->stream));
+  sco_qp_wv_iters_reset(h->qp1, h->stream);
   long long slices_per_qp = slice_req > 0 ? (qsl.max_iter + slice_req - 1) / slice_req : 1;
   if (qsl.adaptive_rho) slices_per_qp += qsl.max_iter / sco_qp_adaptive_interval(&qsl) + 1;    // a launch per rho change at most
   // (a round with selection runs at least half of the active problems, hence the factor 2)
@@ -1726,7 +1728,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     if (wv_round) wv_rounds++;
     const int rc_ = sco_qp_launch_sliced(h->qp1, &qsl, s.newqp, s.active, slice_req, gm, nullptr, (G > 1 || select) ? &win : nullptr);
     if (rc_) return rc_;
-    gmark(g, 2);
+    gmark(g, wv_round ? 5 : 2);
     hipLaunchKernelGGL(sqp_post_kernel, dim3(nwg), block, 0, r.st, sg, h->qp1->d, p);
     SCO_HIP(hipGetLastError());
     gmark(g, 3);
@@ -1790,7 +1792,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   // stage: the ADMM launch if any group is inside one, else QP setup, else convexify, else the decisions -- the ADMM
   // figure is then the wall time during which at least one ADMM launch was resident or queued behind another group's,
   // and the stages add up to the wall time of the call.
-  double ms[5] = {0, 0, 0, 0, 0};
+  double ms[5] = {0, 0, 0, 0, 0}, wv_ms = 0.0;
   for (size_t i = 1; i < ec; i++) {
     float t = 0; (void)hipEventElapsedTime(&t, h->events[i - 1], h->events[i]);
     if (stage[i] >= 0) ms[stage[i]] += t;
@@ -1800,7 +1802,8 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     Group &r = grp[0];
     for (size_t i = 1; i < r.ec; i++) {
       float t = 0; (void)hipEventElapsedTime(&t, h->gevents[0][i - 1], h->gevents[0][i]);
-      if (r.stage[i] >= 0) ms[r.stage[i]] += t;
+      if (r.stage[i] == 5) { ms[2] += t; wv_ms += t; }
+      else if (r.stage[i] >= 0) ms[r.stage[i]] += t;
       ms[4] += t;
     }
   } else {
@@ -1811,7 +1814,9 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
       double prev = 0.0;
       for (size_t i = 0; i < r.ec; i++) {
         float t = 0; (void)hipEventElapsedTime(&t, h->events[0], h->gevents[g][i]);
-        if (i > 0 && r.stage[i] >= 0 && t > prev) { edges.push_back({prev, r.stage[i], 1}); edges.push_back({(double)t, r.stage[i], -1}); }
+        const int stg = r.stage[i] == 5 ? 2 : r.stage[i];
+        if (i > 0 && r.stage[i] == 5) wv_ms += t - prev;
+        if (i > 0 && stg >= 0 && t > prev) { edges.push_back({prev, stg, 1}); edges.push_back({(double)t, stg, -1}); }
         prev = t;
       }
     }
@@ -1827,6 +1832,7 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
     }
   }
   memcpy(h->last_ms, ms, sizeof ms);
+  h->wv_ms = wv_ms;
   h->solved = true;
   return SCO_OK;
 }
@@ -1883,6 +1889,16 @@ extern "C" int sco_sqp_last_rounds(const sco_sqp *h, int *rounds) {
 }
 
 extern "C" int sco_debug_sqp_wv_rounds(const sco_sqp *h) { return h ? h->wv_rounds : -1; }
+extern "C" int sco_sqp_last_tiers(const sco_sqp *h, double ms[2], long long iters[2], int launches[2]) {
+  if (!h || !ms || !iters || !launches) return SCO_ERR_ARG;
+  SCO_ON_DEVICE(h->device);
+  unsigned long long wv_it = 0;
+  if (sco_qp_wv_iters(h->qp1, &wv_it)) return SCO_ERR_DEVICE;
+  ms[0] = h->wv_ms; ms[1] = h->last_ms[2] - h->wv_ms;
+  iters[0] = (long long)wv_it; iters[1] = -1;          // the other kernels': total (sco_sqp_fetch: admm_iters) minus these
+  launches[0] = h->wv_rounds; launches[1] = h->launches - h->wv_rounds;
+  return SCO_OK;
+}
 extern "C" int sco_sqp_last_launches(const sco_sqp *h, int *launches, int *groups) {
   if (!h) return SCO_ERR_ARG;
   if (launches) *launches = h->launches;

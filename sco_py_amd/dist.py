@@ -47,6 +47,21 @@ def max_over_ranks(value):
     return float(t.item())
 
 
+def gather_rank_stats(values):
+    """All-gather a short vector of floats per rank (bench.py: a rank's own clock, SCO iterations, ADMM time): returns a
+    (world, len(values)) array on every rank -- what tells a slow shard from a slow collective when scaling falls short of
+    linear (data-dependent iteration counts are the one risk).  Outside the timed region."""
+    import torch
+    import torch.distributed as dist
+    v = np.asarray(values, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()):
+        return v[None, :]
+    t = torch.tensor(v, dtype=torch.float64, device=collective_device())
+    out = torch.empty(dist.get_world_size() * v.shape[0], dtype=torch.float64, device=t.device)      # flat: gloo wants it so
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy().reshape(dist.get_world_size(), v.shape[0])
+
+
 def gather_results(local, total, device=None, force_collective=False):
     """All-gather the per-problem result records of every rank.
 

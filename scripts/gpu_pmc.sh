@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-problems 0 --aux-12x50 0 --aux-b4096 0 ${PMC_BENCH_ARGS:-} > $R/gpurun_out/pmc_$name.json 2> $R/gpurun_out/pmc_$name.err || { tail -5 $R/gpurun_out/pmc_$name.err; return 1; }
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -o pmc -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-problems 0 --aux-12x50 0 --aux-b4096 0 --aux-object-api 0 ${PMC_BENCH_ARGS:-} > $R/gpurun_out/pmc_$name.json 2> $R/gpurun_out/pmc_$name.err || { tail -5 $R/gpurun_out/pmc_$name.err; return 1; }
 }
 run FETCH_SIZE FETCH_SIZE
 run WRITE_SIZE WRITE_SIZE

@@ -21,6 +21,11 @@ def test_shard_ranges_partition_the_batch():
         sd.shard_range(8, 2, 2)
 
 
+def test_rank_stats_without_a_process_group():
+    st = sd.gather_rank_stats([1.5, 7.0, 0.5])
+    assert st.shape == (1, 3) and st[0].tolist() == [1.5, 7.0, 0.5]
+
+
 def test_single_process_gather_is_identity():
     rec = sd.pack_results([1.0, 2.0], [0.0, 0.5], [True, False], [3, 4])
     assert sd.gather_results(rec, 2) is rec and rec.dtype.itemsize == 24
@@ -35,6 +40,10 @@ def _worker(rank, world, port, total, q):
     rec = sd.pack_results(idx * 1.5, idx * 0.25, idx % 2 == 0, idx + 10)
     out = sd.gather_results(rec, total)
     assert sd.collective_device() == "cpu" and sd.max_over_ranks(1.0 + rank) == float(world)      # the clock of bench.py
+    # bench.py's per-rank record (own clock, SCO iterations, ADMM time): every rank sees every rank's three numbers
+    stats = sd.gather_rank_stats([0.5 + rank, 100.0 * (rank + 1), 0.25 * (rank + 1)])
+    assert stats.shape == (world, 3) and stats[:, 0].tolist() == [0.5 + r for r in range(world)]
+    assert stats[:, 1].tolist() == [100.0 * (r + 1) for r in range(world)]
     q.put((rank, out.tobytes()))
     dist.barrier()
     dist.destroy_process_group()

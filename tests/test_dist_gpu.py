@@ -36,13 +36,31 @@ def _single_rank_iters(total, world):
     return out
 
 
-def _bench_two_ranks(mode, batch):
+def _run_group(cmd, env, timeout=600):
+    """Run a child that starts rank processes of its own (bench.py -> torch.distributed.run -> ranks) in a NEW SESSION: on a
+    timeout the whole process group is killed -- the grandchildren have initialised the GPU and would otherwise keep
+    device 0 for the rest of the test session -- and the test fails."""
+    import signal
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.communicate()
+        pytest.fail("child process group timed out and was killed: %r" % (cmd,))
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+
+
+def _bench_two_ranks(mode, batch, extra=()):
     env = dict(os.environ)
     env["SCO_BENCH_REHEARSE"] = mode
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", str(batch),
-           "--cpu-problems", "0", "--aux-12x50", "0", "--aux-b4096", "0"]
-    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+           "--cpu-problems", "0", "--aux-12x50", "0", "--aux-b4096", "0", "--aux-object-api", "0"] + list(extra)
+    return _run_group(cmd, env)
 
 
 def _json_line(stdout):
@@ -58,6 +76,21 @@ def test_bench_with_two_ranks_on_one_device_gloo(gpu):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2048 and out["scaling"] == "weak"
     assert out["aux"]["backend"] == "gloo" and out["value"] > 0 and out["roofline"]["frac"] > 0
     assert out["aux"]["sco_iters_per_step"] == _single_rank_iters(2048, 2)
+    # what makes a first real multi-GPU run explain itself: every rank's own clock, SCO iterations and ADMM time
+    pr = out["aux"]["per_rank"]
+    assert len(pr["elapsed_s"]) == len(pr["sco_iters"]) == len(pr["admm_s"]) == 2
+    assert sum(pr["sco_iters"]) == out["aux"]["sco_iters_per_step"] and all(0 < a <= e for a, e in zip(pr["admm_s"], pr["elapsed_s"]))
+    assert 1.0 <= pr["imbalance_max_over_mean"] < 2.0 and max(pr["elapsed_s"]) <= out["ms_per_step"] * 1e-3 + 1e-3
+
+
+def test_bench_strong_scaling_mode_splits_one_global_batch(gpu):
+    """--global-batch N: N problems in total over the ranks (BASELINE configs[3] is 8192 over 8 GPUs); here 600 over two ranks
+    on one device: the gathered SCO iterations are those of the two shards [0, 300), [300, 600)."""
+    p = _bench_two_ranks("1", 1024, extra=["--global-batch", "600"])
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    out = _json_line(p.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 600 and out["scaling"] == "strong"
+    assert out["aux"]["sco_iters_per_step"] == _single_rank_iters(600, 2) and len(out["aux"]["per_rank"]["sco_iters"]) == 2
 
 
 def test_bench_with_two_ranks_on_one_device_rccl_branch(gpu):
@@ -83,8 +116,7 @@ def test_rccl_calls_of_the_sharded_path_in_a_group_of_one_rank(gpu):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     port = 29500 + (os.getpid() % 400)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank.py"), str(port)], env=env, cwd=ROOT,
-                       capture_output=True, text=True, timeout=600)
+    p = _run_group([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank.py"), str(port)], env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
     out = _json_line(p.stdout)
     assert out["backend"] == "nccl" and out["device"] == "cuda" and out["world"] == 1
