@@ -270,7 +270,8 @@ typedef struct sco_trajopt_desc {
                         (prob.py:381-404); 0 is read as 1.  With span > 1 this is the count of an atom that ONE
                         block Variable covers; an atom covered by k blocks counts prox_count - 1 + k */
   int span;          /* SCO_FAM_STATE_PROGRAM: timesteps per constraint block, 1 or 2 (0 is read as 1) */
-  int n_eq_rows;     /* SCO_FAM_STATE_PROGRAM: how many of the n_obstacles rows of a block (the last ones) are equalities */
+  int n_eq_rows;     /* SCO_FAM_STATE_PROGRAM and SCO_FAM_STATE_QUADRATIC: how many of the n_obstacles rows of a block (the last
+                        ones) are equalities */
 } sco_trajopt_desc;
 
 typedef struct sco_sqp sco_sqp;

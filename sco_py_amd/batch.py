@@ -82,6 +82,9 @@ class TrajOptBatch(object):
         self.n_eq = prog.n_eq if prog is not None else (int(n_eq_rows) if self.quadratic else 0)
         if n_eq_rows and not (self.quadratic or prog is not None):
             raise ValueError("equality rows inside a block exist for the quadratic-row and program families")
+        if prog is not None and n_eq_rows and int(n_eq_rows) != prog.n_eq:
+            raise ValueError("n_eq_rows = %d, but the compiled program has %d equality rows (the program says how many of a "
+                             "block's rows are equalities; leave n_eq_rows out)" % (int(n_eq_rows), prog.n_eq))
         self.obj_program = bool(prog is not None and prog.objective)
         self.n_blocks = self.T - self.span + 1
         desc = _lib.TrajoptDesc(self.B, self.d, self.T, self.K, self.O,

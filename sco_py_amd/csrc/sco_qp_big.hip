@@ -11,6 +11,8 @@
 //   * dense (qp_setup_big_kernel's Cholesky + qp_admm_big_kernel): explicit inverse W
 //     of the core streamed from L2 every iteration (n_c^2 * 8 = 2.9 MB at 12 x 50);
 //     the fall-back for cores that are not banded and the cross-check of the above.
+#include <type_traits>
+
 #include "sco_internal.h"
 
 #include <algorithm>
@@ -1308,7 +1310,9 @@ __global__ __launch_bounds__(BTT) void qp_admm_bt_kernel(BigArgs a) {
   double alpha = a.alpha, sigma = a.sigma, rho_arg = a.rho;
   int max_iter = a.max_iter, check = a.check;
   asm volatile("" : "+s"(alpha), "+s"(sigma), "+s"(rho_arg), "+s"(max_iter), "+s"(check));
-  // (BigArgs is the kernel's ONLY explicit parameter, passed by value: the argument segment starts with it)
+  // (BigArgs is the kernel's ONLY explicit parameter, passed by value: the argument segment starts with it.  A second
+  // parameter, or one in front of it, would make this view read something else -- the static_assert behind the kernel
+  // pins the signature at compile time.)
   const BigArgs *akp = (const BigArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   // v shares the storage of t': the start point's t' is only read by the prologue below
   const BtPtrs bp{As, rho, ls, us, kinv, qs, w, x, y, z, sdy, sdx, ge, prod, s_xc, use_part ? s_part : nullptr, alpha, sigma,
@@ -1684,6 +1688,11 @@ static int bt_launch_bs(const BigArgs &bs, const BigArgs &ba, int batch, size_t 
   SCO_HIP(hipGetLastError());
   return SCO_OK;
 }
+
+// qp_admm_bt_kernel re-reads its arguments through the kernel-argument segment pointer (see there): that is only right
+// while BigArgs is its one and only parameter
+static_assert(std::is_same<decltype(&qp_admm_bt_kernel<12>), void (*)(BigArgs)>::value,
+              "qp_admm_bt_kernel must take exactly one parameter, BigArgs by value: it views the kernel-argument segment as a BigArgs");
 
 int big_launch(const AdmmArgs &a, const int *setup_mask, int scaling, const int *Pp, const int *Pi, const BigHost &bh,
                const BigDev &bd, const BtHost *th, const BtDev *td, hipStream_t st, hipEvent_t ev_mid, hipEvent_t mid2) {

@@ -1396,6 +1396,11 @@ extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, c
   // size frees the old ones first
   const size_t need[4] = {(size_t)2 * n_words * sizeof(int), ((size_t)R + 1) * sizeof(int), (size_t)std::max(n_consts, 1) * sizeof(double),
                           std::max<size_t>((size_t)s.batch * n_params, 1) * sizeof(double)};
+  // From here until every buffer is in place and filled the handle has NO program: a failed hipMalloc / hipMemcpy below
+  // returns early, and the kernels of a later sco_sqp_solve must not read freed or half-written buffers (solve refuses
+  // while prog_loaded is false).
+  h->prog_loaded = false; h->solved = false;
+  s.pw = nullptr; s.pptr = nullptr; s.pconst = nullptr; s.ppar = nullptr; s.n_par = 0;
   for (int k = 0; k < 4; k++)
     if (h->prog_bytes[k] != need[k]) {
       if (h->prog_buf[k]) { (void)hipFree(h->prog_buf[k]); h->prog_buf[k] = nullptr; h->prog_bytes[k] = 0; }

@@ -171,12 +171,13 @@ def compile_rows(rows, eq_rows=(), objective=None, span=1):
     timestep (span 1 only); ``span``: timesteps per constraint block (X(i) addresses i < span * dof)."""
     if span not in (1, 2) or (objective is not None and span != 1):
         raise ValueError("span is 1 or 2; an objective term needs span 1")
+    rows, eq_rows = list(rows), list(eq_rows)          # (generators are welcome: they are walked once, here)
     words, row_ptr, consts = [], [0], []
-    for r in list(rows) + list(eq_rows) + ([objective] if objective is not None else []):
+    for r in rows + eq_rows + ([objective] if objective is not None else []):
         Node.lift(r).emit(words, consts)
         words.append((OP_END, 0))
         row_ptr.append(len(words))
-    prog = Program(words, row_ptr, consts, n_eq=len(list(eq_rows)), span=span, objective=objective is not None)
+    prog = Program(words, row_ptr, consts, n_eq=len(eq_rows), span=span, objective=objective is not None)
     for r in range(len(prog.row_ptr) - 1):            # the same checks the C side makes, with Python errors
         sp = 0
         for op, arg in prog.words[prog.row_ptr[r]:prog.row_ptr[r + 1] - 1]:

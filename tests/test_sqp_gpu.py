@@ -1145,3 +1145,30 @@ def test_wavefront_tier_forced_through_the_device_loop(gpu, monkeypatch, kw, par
         for b in range(0, nb, 2):
             ref = sr.penalty_sqp(sr.trajopt_flat(probs[b]), emulate_memo=True)
             assert np.array_equal(res.trace[b][:, 0], ref.trace[:64, 0]) and np.abs(res.x[b] - ref.x).max() < TOL
+
+
+def test_program_reload_with_another_size_and_the_n_eq_rows_check(gpu):
+    """sco_sqp_load_program may be called again with a program of ANOTHER size (buffers are reallocated; r03 advisor: between
+    the free and the last upload the handle has no program -- a solve is refused, not run on freed buffers); the result is
+    that of a fresh handle.  TrajOptBatch refuses an n_eq_rows that contradicts the compiled program."""
+    from sco_py_amd.rowexpr import X, P, sqrt, compile_rows
+    d, T, B = 2, 8, 4
+    arrays, _ = af.make_batch(B, d=d, T=T, K=1, program=True)
+    short = compile_rows([P(2) - sqrt((X(0) - P(0)) ** 2 + (X(1) - P(1)) ** 2 + 1e-12)] * 4)        # 4 rows again, fewer words
+    assert len(short.words) != len(arrays["row_program"].words)
+    par = arrays["row_params"][:, :3].copy()
+    outs = []
+    with sb.TrajOptBatch(B, d, T, 1, 4, program=arrays["row_program"]) as tb:
+        args = (arrays["x0"], arrays["start"], arrays["goal"], arrays["link_len"], arrays["point_link"], arrays["point_frac"], arrays["obstacles"])
+        tb.load(*args, row_program=arrays["row_program"], row_params=arrays["row_params"])
+        tb.solve(); first = tb.fetch()
+        tb.load(*args, row_program=short, row_params=par)              # another word count: reallocation
+        tb.solve(); outs.append(tb.fetch())
+        tb.load(*args, row_program=arrays["row_program"], row_params=arrays["row_params"])
+        tb.solve(); again = tb.fetch()
+    with sb.TrajOptBatch(B, d, T, 1, 4, program=short) as tb2:
+        tb2.load(*args, row_program=short, row_params=par)
+        tb2.solve(); outs.append(tb2.fetch())
+    assert np.array_equal(outs[0].x, outs[1].x) and np.array_equal(first.x, again.x) and not np.array_equal(first.x, outs[0].x)
+    with pytest.raises(ValueError):
+        sb.TrajOptBatch(B, d, T, 1, 4, program=arrays["row_program"], n_eq_rows=2)
