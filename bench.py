@@ -495,8 +495,9 @@ def main():
             r12 = run("12x50", args.aux_12x50, 1, 0)
             rf12 = roofline(r12, True)
             aux12 = {"workload": "batch=%d x 12-DOF x 50-timestep (n=5600, m=10624, 5000 nonlinear rows) per GPU, parity mode, 1 step; "
-                                 "structured global-memory ADMM tier on the f64 vector ALU (no MFMA: the one GEMM-shaped stage, the block "
-                                 "normal matrices of the QP setup, is 0.3 %% of this step -- measured, profiles/r03_n1_mfma.txt)" % args.aux_12x50,
+                                 "structured global-memory ADMM tier on the f64 vector ALU; the one GEMM-shaped stage of the path, the block "
+                                 "normal matrices J' R J of the QP setup (100 x 12 per block), runs on v_mfma_f64_16x16x4 since r04, "
+                                 "bit-identically (qp_setup stage -21 %%, 0.3 %% of this step: profiles/r04_n1_mfma.txt)" % args.aux_12x50,
                      "sco_iters_per_s": r12["sco_iters"] / r12["elapsed"], "ms_per_step": 1e3 * r12["elapsed"],
                      "admm_problem_iterations_per_s": (r12["it_proj"] + r12["it_pen"]) / (r12["admm_ms"] * 1e-3),
                      "roofline": {k: rf12[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}}
@@ -535,8 +536,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("batch=%d independent 12-DOF x 50-timestep planar-arm trajopt problems per GPU "
                                     "(n=5600, m=10624 + duplicated penalty rows, 5000 nonlinear rows), penalty SQP with "
-                                    "reference defaults; structured global-memory ADMM tier, f64 vector ALU (no MFMA: "
-                                    "profiles/r03_n1_mfma.txt, DESIGN.md 5)" % B) if big else
+                                    "reference defaults; structured global-memory ADMM tier, f64 vector ALU; block normal "
+                                    "matrices of the QP setup on v_mfma_f64_16x16x4 (profiles/r04_n1_mfma.txt, DESIGN.md 5)" % B) if big else
                                    ("batch=%d independent 7-DOF x 20-timestep planar-arm trajopt problems per GPU "
                                     "(n=340, m=554 + duplicated penalty rows, 200 nonlinear rows), penalty SQP with "
                                     "reference defaults" % B),

@@ -181,10 +181,17 @@ struct BtHost {
   std::vector<int> cent;          // [n_c padded][4] column contributions: >= 0 partial index, <= -2 product position, -1 none
   size_t blk_doubles = 0, ws_doubles = 0, lds_bytes = 0;
   std::vector<int> ch_desc, it;     // it: 8 ints per chunk slot (e, j, r0, r1, ep0, ep1, core idx, core pos)
+  // r04 (N1): block normal matrices on the matrix cores.  For blocks of order >= 12 whose hinge rows are dense, the sum over
+  // those rows inside every diagonal-block entry of S is formed by v_mfma_f64_16x16x4 (one wavefront per block) between the
+  // terms that come before them in the entry's list and the ones after: mf_id [nb][256] entry id of tile position (i, j),
+  // i >= j (-1: none); mf_h0 / mf_h1 [nS] the run of hinge-row terms inside the entry's A' R A list (h0 = h1: none)
+  bool use_mfma = false;
+  int mf_why = 0;                 // 0 used, 1 switched off, 2 block order outside 12 .. 16, 3 hinge terms not one run, 4 rows differ between entries, 5 hole in a block, 6 no hinge rows
+  std::vector<int> mf_id, mf_h0, mf_h1;
 };
 // park_part: [batch][npart] of a parked solve; cflag: [batch][nchunks] flags of the per-row constants that are known values
 // for all rows of a dense chunk, ccon: [batch] the common row weight they refer to (written by qp_setup_big_kernel)
-struct BtDev { const int *ch_desc, *it, *cent; double *blk, *ws, *park_part; int *cflag; double *ccon; };
+struct BtDev { const int *ch_desc, *it, *cent; double *blk, *ws, *park_part; int *cflag; double *ccon; const int *mf_id, *mf_h0, *mf_h1; };
 bool bt_plan_build(const QpPlan &pl, const BigHost &bh, BtHost &th);
 int bt_upload(const BtHost &th, int batch, std::vector<void *> &allocs, BtDev &td);
 // th/td null = dense route

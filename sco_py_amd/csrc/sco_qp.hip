@@ -1296,11 +1296,20 @@ extern "C" int sco_debug_wv_plan(int *info) {
   info[7] = wh.NSTEP; info[8] = (int)wh.lds_bytes; info[9] = wh.n_extra;
   return SCO_OK;
 }
+// Host-only: the structured global-memory plan of that pattern.  info[0] fits, [1] block order, [2] blocks, [3] block normal
+// matrices on the matrix cores, [4] why not (BtHost::mf_why), [5] LDS bytes
+extern "C" int sco_debug_bt_plan(int *info) {
+  BigHost bh; BtHost th;
+  const bool ok = g_dbg_plan.n_c <= 1024 && big_plan_build(g_dbg_plan, bh) && bt_plan_build(g_dbg_plan, bh, th);
+  info[0] = ok ? 1 : 0; info[1] = th.bs; info[2] = th.nb; info[3] = th.use_mfma ? 1 : 0; info[4] = th.mf_why; info[5] = (int)th.lds_bytes;
+  return SCO_OK;
+}
 // Which ADMM tiers a handle holds: bit 0 row-local, 1 register-offset, 2 sliced-ELL, 3 global memory, 4 its structured form,
-// 5 wavefront tier
+// 5 wavefront tier, 6 the structured form builds its block normal matrices on the matrix cores (MFMA)
 extern "C" int sco_debug_qp_tiers(const sco_qp *qp) {
   if (!qp) return SCO_ERR_ARG;
-  return (qp->use_rl ? 1 : 0) | (qp->use_reg ? 2 : 0) | (qp->use_fast ? 4 : 0) | (qp->use_big ? 8 : 0) | (qp->use_bt ? 16 : 0) | (qp->use_wv ? 32 : 0);
+  return (qp->use_rl ? 1 : 0) | (qp->use_reg ? 2 : 0) | (qp->use_fast ? 4 : 0) | (qp->use_big ? 8 : 0) | (qp->use_bt ? 16 : 0) | (qp->use_wv ? 32 : 0) |
+         ((qp->use_bt && qp->bt.use_mfma) ? 64 : 0);
 }
 extern "C" int sco_debug_plan_get(const char *name, int *out, int cap) {
   const QpPlan &p = g_dbg_plan;

@@ -640,3 +640,34 @@ def test_wavefront_tier_time_slices_and_max_iter(gpu, monkeypatch):
     for kw in (dict(max_iter=60), dict(max_iter=333), dict(max_iter=500, check_termination=0)):
         st = _lib.default_qp_settings(**kw)
         _check(probs, settings=st, **kw)
+
+
+@pytest.mark.parametrize("shape", [(6, 12, 20), (5, 12, 9), (4, 16, 33)])
+def test_block_normal_matrices_on_the_matrix_cores_change_no_bit(gpu, monkeypatch, shape):
+    """r04 (north_star: "MFMA used only for the dense batched Jacobian x step contraction"): on the structured global-memory
+    tier the hinge-row part J' R J of every diagonal block of S is formed by v_mfma_f64_16x16x4 for blocks of order 12 .. 16
+    (BASELINE configs[4] is 100 x 12 per block), started from the terms the vector path adds first and followed by the ones it
+    adds afterwards, the Schur terms included -- the same additions in the same order.  Against SCO_QP_NO_MFMA=1: identical
+    bits in x and y, identical iteration counts; row counts that are no multiple of four, row weights."""
+    import ctypes as C
+    T, d, r = shape
+    monkeypatch.setenv("SCO_QP_FORCE_BIG", "1")
+    rng = np.random.default_rng(31 + d)
+    probs = [penalty_qp(rng, T, d, r) for _ in range(3)]
+    m = len(probs[0][3])
+    w = np.ones((3, m), dtype=np.int32); w[:, d:d + T * r] = rng.integers(1, 4, size=(3, 1))
+    n, m, Pp, Pi, Ap, Ai, Pval, q, Aval, l, u = _stack(probs)
+    outs = []
+    for no in ("0", "1"):
+        monkeypatch.setenv("SCO_QP_NO_MFMA", no)
+        assert bool(_tiers(n, m, Pp, Pi, Ap, Ai) & 64) == (no == "0")
+        qp = _lib.BatchedQP(3, n, m, Pp, Pi, Ap, Ai)
+        try:
+            qp.load(Pval, q, Aval, l, u, w)
+            outs.append(qp.solve())
+        finally:
+            qp.close()
+    (x0, y0, s0, i0, _), (x1, y1, s1, i1, _) = outs
+    assert np.array_equal(x0, x1) and np.array_equal(y0, y1) and np.array_equal(i0, i1) and np.array_equal(s0, s1)
+    ref = o.solve(*probs[0], w=w[0])
+    assert s0[0] == ref.info.status_val and i0[0] == ref.info.iter and np.abs(x0[0] - ref.x).max() < TOL

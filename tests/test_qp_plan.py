@@ -171,3 +171,39 @@ def test_which_penalty_qps_land_on_the_wavefront_tier(name, kw, want):
     assert tuple(info[:len(want)]) == want, (name, info.tolist())
     if want[0]:
         assert info[8] <= (40 if info[2] == 20 else 64) * 1024        # LDS: four problems per CU at 7 x 20
+
+
+@pytest.mark.parametrize("name,kw,want", [
+    ("12-DOF x 50 x 100 hinge rows (the shape of BASELINE configs[4])", (50, 12, 100), (1, 12, 50, 1, 0)),
+    ("12 x 8 x 20", (8, 12, 20), (1, 12, 8, 1, 0)),
+    ("12-DOF x 8 arm with the pattern taken from the values: a link's rows stop at its joint", dict(d=12, T=8, K=10, O=10), (1, 12, 8, 0, 4)),
+    ("16 x 4, 33 rows", (4, 16, 33), (1, 16, 4, 1, 0)),
+    ("14 x 5: blocks of 16 cut the time steps", (5, 14, 9), (1, 16, 5, 0, 4)),
+    ("7-DOF x 20: block order below 12", dict(d=7, T=20), (1, 8, 18, 0, 2)),
+])
+def test_which_structured_plans_form_their_blocks_on_the_matrix_cores(name, kw, want, monkeypatch):
+    """r04 (N1): the structured global-memory plan forms the hinge-row part of its diagonal blocks with
+    v_mfma_f64_16x16x4 when the block order is 12 .. 16 and every entry of a block sums over the same run of hinge rows
+    (csrc/sco_qp_big.hip bt_plan_build); SCO_QP_NO_MFMA=1 switches it off.  info: fits, block order, blocks, MFMA, why not."""
+    if isinstance(kw, dict):
+        from oracle import arm_family as af
+        from oracle import sco_ref as sr
+        out = sr.penalty_sqp(sr.trajopt_flat(af.make_problem(0, **kw)), sr.SolverParams(max_qp_solves=2), record_qps=True)
+        q = out.qps[1]; Pm, Am, n, m = q["P"], q["A"], len(q["q"]), len(q["l"])
+    else:
+        from test_qp_gpu import penalty_qp
+        Pm, qv, Am, lv, uv = penalty_qp(np.random.default_rng(0), *kw); n, m = len(qv), len(lv)
+    P = sp.triu(sp.csc_matrix(Pm != 0), format="csc"); A = sp.csc_matrix(Am != 0)
+    P.sort_indices(); A.sort_indices()
+    lib = _lib.load()
+    ip = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int))
+    Pp, Pi, Ap, Ai = (np.ascontiguousarray(a, dtype=np.int32) for a in (P.indptr, P.indices, A.indptr, A.indices))
+    sizes = np.zeros(16, dtype=np.int32); info = np.zeros(8, dtype=np.int32)
+    lib.sco_debug_plan_build.argtypes = [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4 + [C.c_int, C.POINTER(C.c_int)]
+    lib.sco_debug_bt_plan.argtypes = [C.POINTER(C.c_int)]
+    assert lib.sco_debug_plan_build(n, m, ip(Pp), ip(Pi), ip(Ap), ip(Ai), 1, ip(sizes)) == 0
+    assert lib.sco_debug_bt_plan(ip(info)) == 0
+    assert tuple(info[:5]) == want, (name, info.tolist())
+    if want[3]:
+        monkeypatch.setenv("SCO_QP_NO_MFMA", "1")
+        assert lib.sco_debug_bt_plan(ip(info)) == 0 and tuple(info[:5]) == want[:3] + (0, 1)
