@@ -39,7 +39,9 @@
  * sequence, iteration counts and sub-tolerance digits cannot be checked here
  * (library absent).  The SOLUTION is pinned by the reference's own analytic
  * known-answer tests at this boundary (tests/sco_osqp/test_variable.py:39-96,
- * test_prob.py:48-430, test_solver.py:91-169), see tests/test_oracle_kat.py.
+ * test_prob.py:48-430, test_solver.py:91-169), see tests/test_oracle_osqp.py and
+ * tests/golden/kat_results.json (tests/test_golden.py).  Where two float64 routes disagree on an iteration count, the x87
+ * extended-precision build of this very file (oracle/osqp_ref_ld.c) is the referee: tests/test_adjudicate.py.
  *
  * Linear system: the quasi-definite KKT matrix
  *     [ P + sigma I      A'      ]

@@ -19,6 +19,8 @@ import scipy.sparse as sp
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_osqp_ref.so")
 _SRC = os.path.join(_HERE, "osqp_ref.c")
+_SO_LD = os.path.join(_HERE, "_osqp_ref_ld.so")          # the same file compiled in x87 extended precision (osqp_ref_ld.c)
+_SRC_LD = os.path.join(_HERE, "osqp_ref_ld.c")
 
 
 class Settings(C.Structure):
@@ -65,6 +67,27 @@ def lib():
     return _lib
 
 
+_lib_ld = None
+
+
+def build_extended(force=False):
+    """Compile osqp_ref_ld.c: osqp_ref.c with `double` -> `long double` behind the same double ABI (gcc, host only)."""
+    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_SRC_LD))
+    if force or not os.path.exists(_SO_LD) or os.path.getmtime(_SO_LD) < newest:
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", _SO_LD, _SRC_LD, "-lm"], cwd=_HERE)
+    return _SO_LD
+
+
+def lib_extended():
+    global _lib_ld
+    if _lib_ld is None:
+        build_extended()
+        _lib_ld = C.CDLL(_SO_LD)
+        _lib_ld.osqp_ref_default_settings.argtypes = [C.POINTER(Settings)]
+        _lib_ld.osqp_ref_solve.restype = C.c_int
+    return _lib_ld
+
+
 def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int))
 
@@ -83,7 +106,7 @@ def default_settings(**kw):
     return s
 
 
-def solve(P, q, A, l, u, w=None, trace_cap=0, **settings):
+def solve(P, q, A, l, u, w=None, trace_cap=0, extended=False, **settings):
     """Solve  min 1/2 x'Px + q'x  s.t.  l <= Ax <= u  the way OSQP 0.6 would.
 
     P: (n, n) dense or sparse; only its upper triangle is read (the reference
@@ -91,6 +114,8 @@ def solve(P, q, A, l, u, w=None, trace_cap=0, **settings):
     A: (m, n) dense or sparse.  w: optional integer row multiplicities.
     Returns a namespace with x, y, info.status_val, info.iter, ... mirroring the
     fields the reference reads (prob.py:197, 202; osqp_utils.py:218).
+    extended=True runs the x87 long double build of the same code (osqp_ref_ld.c): where the algorithm stops once rounding
+    noise is 2048 x smaller -- the referee between two float64 routes that disagree on an iteration count.
     """
     q = np.ascontiguousarray(q, dtype=np.float64).ravel()
     n = q.shape[0]
@@ -112,7 +137,7 @@ def solve(P, q, A, l, u, w=None, trace_cap=0, **settings):
         wv = np.ascontiguousarray(w, dtype=np.int32).ravel()
         assert wv.shape == (m,)
     trace = np.zeros((max(trace_cap, 1), 4)); tl = C.c_int(0)
-    rc = lib().osqp_ref_solve(
+    rc = (lib_extended() if extended else lib()).osqp_ref_solve(
         C.c_int(n), C.c_int(m), _ip(Pp), _ip(Pi), _dp(Px), _dp(q), _ip(Ap), _ip(Ai), _dp(Ax),
         _dp(l), _dp(u), _ip(wv) if wv is not None else None, C.byref(st),
         _dp(x), _dp(y), C.byref(info), _dp(trace), C.c_int(trace_cap), C.byref(tl))

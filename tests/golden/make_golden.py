@@ -24,6 +24,7 @@ Outputs (tests/golden/):
   quirks.npz           Q1/Q2/Q14 demonstrations (q and A shapes over three update_obj calls)
 """
 import json
+import math
 import os
 import sys
 import types
@@ -41,6 +42,12 @@ from oracle import osqp_ref                  # noqa: E402
 from sco_py_amd import numdiff               # noqa: E402
 
 QP_LOG = []
+CANON_NX = [None]      # run_trajopt sets the number of trajectory columns: the stand-in then SOLVES every QP in the canonical
+                       # column / row order (tests/trajopt_build.py canonical_qp) and hands the answer back in the reference's.
+                       # The reference orders the slack columns of a QP by iterating a Python set of objects, an
+                       # order that changes from process to process; an ADMM run on permuted columns rounds differently (1e-8
+                       # over a run that stops on max_iter), so without this the fixtures did not regenerate bit-identically
+                       # (VERDICT r03 1c).  The QP the reference assembled is unchanged -- only the order it is solved in.
 
 
 def install_standins():
@@ -74,8 +81,17 @@ def install_standins():
         def solve(self):
             a = self.args
             kw = a["kw"]
-            res = osqp_ref.solve(a["P"], a["q"], a["A"], a["l"], a["u"], rho=kw["rho"], sigma=kw["sigma"],
-                                 eps_abs=kw["eps_abs"], eps_rel=kw["eps_rel"], max_iter=int(kw["max_iter"]))
+            st = dict(rho=kw["rho"], sigma=kw["sigma"], eps_abs=kw["eps_abs"], eps_rel=kw["eps_rel"], max_iter=int(kw["max_iter"]))
+            if CANON_NX[0] is not None and np.asarray(a["q"]).shape[0] > CANON_NX[0]:
+                import trajopt_build as tb
+                Pd, Ad = sp.csc_matrix(a["P"]).toarray(), sp.csc_matrix(a["A"]).toarray()
+                P2, q2, A2, l2, u2, perm, rows = tb.canonical_qp(Pd, np.array(a["q"]), Ad, np.array(a["l"]), np.array(a["u"]),
+                                                                 CANON_NX[0], with_rows=True)
+                res = osqp_ref.solve(P2, q2, A2, l2, u2, **st)
+                x = np.empty_like(res.x); x[perm] = res.x; res.x = x
+                y = np.empty_like(res.y); y[rows] = res.y; res.y = y
+            else:
+                res = osqp_ref.solve(a["P"], a["q"], a["A"], a["l"], a["u"], **st)
             QP_LOG.append(dict(P=sp.csc_matrix(a["P"]).toarray(), q=np.array(a["q"]),
                                A=sp.csc_matrix(a["A"]).toarray(), l=np.array(a["l"]), u=np.array(a["u"]),
                                x=res.x.copy(), status=res.info.status_val, iters=res.info.iter,
@@ -111,18 +127,19 @@ def run_reference_tests():
 def run_trajopt(mods, pr, analytic_jac=False, solver_attrs=None):
     import trajopt_build as tb
     del QP_LOG[:]
+    CANON_NX[0] = pr["d"] * pr["T"]
     prob, traj, step_vars, atoms = tb.build_prob(mods, pr, analytic_jac=analytic_jac)
     merit_log = []
     gv, gav = prob.get_value, prob.get_approx_value
 
     def get_value(pc, vectorize=False):
         v = gv(pc, vectorize)
-        merit_log.append((0.0, float(vectorize), float(pc), float(np.sum(v))))
+        merit_log.append((0.0, float(vectorize), float(pc), math.fsum(np.ravel(v))))       # exactly rounded: no order (Q10)
         return v
 
     def get_approx_value(pc, vectorize=False):
         v = gav(pc, vectorize)
-        merit_log.append((1.0, float(vectorize), float(pc), float(np.sum(v))))
+        merit_log.append((1.0, float(vectorize), float(pc), math.fsum(np.ravel(v))))
         return v
 
     prob.get_value, prob.get_approx_value = get_value, get_approx_value

@@ -164,13 +164,13 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
     return prob, traj, step_vars, atoms
 
 
-def canonical_qp(P, q, A, l, u, n_x):
+def canonical_qp(P, q, A, l, u, n_x, with_rows=False):
     """Bring a QP assembled in the reference's (partly arbitrary) order
     into the canonical order used by the oracle and the device path:
       columns  x in name order (already so), then slack columns ordered by the
                first row they appear in (ties: the -1 column before the +1 column);
       rows     constraint rows as given, then the n bound rows in column order.
-    P, A dense arrays.  Returns (P, q, A, l, u, column permutation)."""
+    P, A dense arrays.  Returns (P, q, A, l, u, column permutation[, row permutation])."""
     n = q.shape[0]
     m_c = A.shape[0] - n
     slack = list(range(n_x, n))
@@ -190,4 +190,6 @@ def canonical_qp(P, q, A, l, u, n_x):
     brow = A2[m_c:, :]
     order = np.argsort(np.argmax(brow != 0, axis=1), kind="stable")
     rows = np.concatenate([np.arange(m_c), m_c + order])
+    if with_rows:
+        return P2, q2, A2[rows, :], l[rows], u[rows], perm, rows
     return P2, q2, A2[rows, :], l[rows], u[rows], perm
