@@ -37,6 +37,9 @@
 #include "sco_internal.h"
 
 #define WV_T 64
+#ifndef WV_PD
+#define WV_PD 3       // block steps between the LDS reads of a sweep step and its arithmetic
+#endif
 #define WV_MAXNS 4
 #define WV_MAXNV 4
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -233,7 +236,7 @@ struct WvArgs {
   const int *Ap, *Ai, *Rp, *Rj, *Rpos, *Fp, *Fi, *Fpos;
   double *x, *y, *resid; int *status, *iters, *prog;
   double *sx, *sz, *sy, *st, *sg;
-  int ablate;        // diagnostic (SCO_WV_ABLATE): 1 = no sweeps, 2 = no row passes, 16 = no termination test behind the checked iteration (timing only, results wrong)
+  int ablate;        // diagnostic (SCO_WV_ABLATE): 1 = no sweeps, 2 = no row passes, 16 = no termination test behind the checked iteration, 64 = no infeasibility certificates (timing only, results wrong)
 };
 
 // Wavefront-wide max / sum in registers: two DPP quad steps, two DPP mirror steps inside a 16-lane row, then the row and
@@ -519,7 +522,6 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   const double *const md_g = lds + oG + NSTEP * 64 + k8 * 2;
   double *const md_v = lds + oR + wv_vidx(NPOS, NSTEP, k8);
   const double *const md_e = lds + oEF + NSTEP * 8 + k8;
-  double *scr_dy = a.scr + (size_t)b * (n + m), *scr_dx = scr_dy + m;
   WV_SYNC();
 
   // accumulators of the termination test that ride along in the checked step
@@ -527,17 +529,16 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   // Row / variable indices and scaling constants that only a checked iteration needs.  They are fetched from global memory
   // at the START of that iteration, in front of the sweeps, so that the round trip (L2 or HBM: 68 x 512 B per problem) runs
   // under the iteration's own arithmetic; kept for the whole solve they would cost ~170 registers.
-  struct { int h[NS], br[NS], ev[NS], r0[NV], var[NV], pkm[NV], pkp[NV]; double hc[NS][3], vc[NV][5], xc; } ck;
+  struct { int h[NS], r0[NV], var[NV], pkm[NV], pkp[NV]; double hc[NS][3], vc[NV][5], xc; } ck;
   const int pdense = (a.ablate & 32) ? 1 : a.pflag[b];         // P has entries off the three diagonals the compact constants hold
-  // delta_y (clipped) / delta_x of the checked iteration: kept in registers; only when an infeasibility certificate has to be
-  // evaluated (rare) are they written to the scratch arrays its generic loops read
+  // delta_y (clipped) / delta_x of the checked iteration: kept in registers for the infeasibility certificates
   struct { double h[NS], b[NS], e[NS], r0[NV], var[NV], x; } dsv;
   auto load_chk = [&]() {
     const int *tab = wv_opaque(tab0);
     const double *c = wv_opaque(cstg0);
 #pragma unroll
     for (int q = 0; q < NS; q++) {
-      ck.h[q] = tab[(oHROW + q) * 64 + lane]; ck.br[q] = tab[(oHBROW + q) * 64 + lane]; ck.ev[q] = tab[(oHEVAR + q) * 64 + lane];
+      ck.h[q] = tab[(oHROW + q) * 64 + lane];
 #pragma unroll
       for (int k = 0; k < 3; k++) ck.hc[q][k] = c[(wv_cst_h(q) + k) * 64];
     }
@@ -694,22 +695,29 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   // Nothing is stored inside the sweeps: the NSTEP intermediate vectors of a chain stay in registers.
   auto sweep = [&]() {
     // only the 16 lanes that hold a component of one of the two chains take part: the others would fetch the same rows of
-    // G again (four wavefronts share a CU's LDS pipe)
+    // G again (four wavefronts share a CU's LDS pipe).
+    // A block step is ~60 cycles of arithmetic (seven dependent v_fmac_f64_dpp in two chains, one fma, one add) and an LDS
+    // read comes back after ~130 (scripts/microbench/wave_cost.hip): the rows of G, the right-hand sides and the couplings
+    // are asked for WV_PD block steps ahead (r04: one step ahead left the sweeps waiting for LDS, 176 cycles per step).
+    constexpr int PD = WV_PD < NSTEP ? WV_PD : NSTEP;
     double vs[NSTEP];
-    WvRow<BS> g; double rr = 0.0, ee = 0.0, emk = 0.0;
+    WvRow<BS> gq[PD]; double rq[PD], eq[PD];
+    double emk = 0.0;
     if (sw_store) {
-      g = wv_row<BS>(sw_g, sw_gd);                // row of G of the block being processed; the next block's is in flight
-      rr = sw_v[0]; ee = sw_e[0];
+      auto fetch_fwd = [&](int st, WvRow<BS> &g, double &r, double &e) {      // block st of the chain; st = NSTEP: the middle block
+        if (st < NSTEP) { g = wv_row<BS>(sw_g + st * 64, sw_gd + st * 64); r = sw_v[st * 2]; e = sw_e[st * 8]; }
+        else if (st == NSTEP) { g = wv_row<BS>(md_g, md_g + 48); r = md_v[0]; e = md_e[0]; }
+      };
+#pragma unroll
+      for (int i = 0; i < PD; i++) fetch_fwd(i, gq[i], rq[i], eq[i]);
       double vprev = 0.0;
 #pragma unroll
-      for (int s = 0; s < NSTEP; s++) {
-        // prefetch: the chain's next block, or (last step) the middle block
-        const WvRow<BS> gn = s + 1 < NSTEP ? wv_row<BS>(sw_g + (s + 1) * 64, sw_gd + (s + 1) * 64) : wv_row<BS>(md_g, md_g + 48);
-        const double rn = s + 1 < NSTEP ? sw_v[(s + 1) * 2] : md_v[0], en_ = s + 1 < NSTEP ? sw_e[(s + 1) * 8] : md_e[0];
+      for (int st = 0; st < NSTEP; st++) {
+        const WvRow<BS> g = gq[st % PD]; const double rr = rq[st % PD], ee = eq[st % PD];
+        fetch_fwd(st + PD, gq[st % PD], rq[st % PD], eq[st % PD]);
         const double w = __builtin_fma(-ee, vprev, rr);
         vprev = wv_matvec<BS>(0.0, w, g);
-        vs[s] = vprev;
-        g = gn; rr = rn; ee = en_;
+        vs[st] = vprev;
       }
       // the middle block needs the last vector of BOTH chains: through LDS (the x~ positions of those two blocks)
       emk = lds[oEM + k8];
@@ -717,27 +725,31 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     }
     WV_SYNC();
     if (sw_store) {
-      double xn;
+      // (slot NSTEP % PD of the ring holds the middle block: fetched PD steps before the end of the forward sweep)
+      const WvRow<BS> gm = gq[NSTEP % PD]; const double rm = rq[NSTEP % PD], em_ = eq[NSTEP % PD];
       const double vA = md_v[-2 + (oXT - oR)], vB = md_v[NSTEP * 2 + (oXT - oR)];
-      // prefetch the chain's last block for the backward sweep
-      const WvRow<BS> gn = wv_row<BS>(sw_g + (NSTEP - 1) * 64, sw_gd + (NSTEP - 1) * 64);
-      const double en_ = sw_e[(NSTEP - 1) * 8 + (oEN - oEF)];
-      double w = __builtin_fma(-ee, vA, rr);
+      // backward sweep: block st of the chain and its coupling towards the middle, again PD steps ahead
+      WvRow<BS> gb[PD]; double eb[PD];
+      auto fetch_bwd = [&](int st, WvRow<BS> &g, double &e) {
+        if (st >= 0) { g = wv_row<BS>(sw_g + st * 64, sw_gd + st * 64); e = sw_e[st * 8 + (oEN - oEF)]; }
+      };
+#pragma unroll
+      for (int i = 0; i < PD; i++) fetch_bwd(NSTEP - 1 - i, gb[i], eb[i]);
+      double w = __builtin_fma(-em_, vA, rm);
       w = __builtin_fma(-emk, vB, w);
-      xn = wv_matvec<BS>(0.0, w, g);
-      g = gn; ee = en_;
+      double xn = wv_matvec<BS>(0.0, w, gm);
       const double xmid = xn;
 #pragma unroll
-      for (int s = NSTEP - 1; s >= 0; s--) {
-        WvRow<BS> gn2 = g; double en2 = ee;
-        if (s > 0) { gn2 = wv_row<BS>(sw_g + (s - 1) * 64, sw_gd + (s - 1) * 64); en2 = sw_e[(s - 1) * 8 + (oEN - oEF)]; }
+      for (int st = NSTEP - 1; st >= 0; st--) {
+        const int slot = (NSTEP - 1 - st) % PD;
+        const WvRow<BS> g = gb[slot]; const double ee = eb[slot];
+        fetch_bwd(st - PD, gb[slot], eb[slot]);
         const double u = -(ee * xn);
-        xn = wv_matvec<BS>(vs[s], u, g);
-        vs[s] = xn;
-        g = gn2; ee = en2;
+        xn = wv_matvec<BS>(vs[st], u, g);
+        vs[st] = xn;
       }
 #pragma unroll
-      for (int s = 0; s < NSTEP; s++) sw_v[s * 2 + (oXT - oR)] = vs[s];
+      for (int st = 0; st < NSTEP; st++) sw_v[st * 2 + (oXT - oR)] = vs[st];
       if (srow == 0) md_v[oXT - oR] = xmid;
     }
     WV_SYNC();
@@ -837,56 +849,103 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       const double eps_p = ea + er * w_pn, eps_d = ea + er * cinv * w_dn;
       const bool prim_ok = (m == 0) || (pri < eps_p), dual_ok = dua < eps_d;
       if (prim_ok && dual_ok) { status = approximate ? SCO_QP_SOLVED_INACCURATE : SCO_QP_SOLVED; break; }
-      // the two infeasibility certificates (rare): generic loops over the pattern; delta_y / delta_x go to the scratch
-      // arrays only now
-      const double *Dg = a.D + (size_t)b * n, *Eg = a.E + (size_t)b * m;
-      auto spill_deltas = [&]() {
+      // The two infeasibility certificates, on the structured layout as well (r04: stiff penalty QPs -- the compounded
+      // penalty of quirk Q1 -- meet their cheap preconditions at most checks; as generic loops over the CSC pattern in
+      // global memory they cost 8 % of the solve, scripts/gpu_wv_time.py).  Same quantities as admm_check in sco_qp.hip:
+      //   primal:  || D^-1 A' (w dy) ||inf < eps_prim_inf || E dy ||inf                  (dy clipped to the cone of the bounds)
+      //   dual:    || D^-1 P dx ||inf < c eps_dual_inf || D dx ||inf  and no row of E^-1 A dx leaves its finite bounds' cone
+      // delta_y / delta_x of the checked iteration are in registers (dsv); column sums go through the two buffers the
+      // test above has borrowed already.
+      if ((a.ablate & 64) == 0 && !prim_ok && ndy > epi && lhs < -epi * ndy) {
+        double nat = 0.0;
+        {
+          double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < NS; q++) {
-          if (ck.h[q] >= 0) scr_dy[ck.h[q]] = dsv.h[q];
-          if (ck.br[q] >= 0) scr_dy[ck.br[q]] = dsv.b[q];
-          if (ck.ev[q] >= 0) scr_dx[ck.ev[q]] = dsv.e[q];
+          for (int q = 0; q < NS; q++) {
+            const d2 *jp = (const d2 *)(jl_p + q * 512);
+            const d2 j0 = jp[0], j1 = jp[64], j2 = jp[128], j3 = jp[192];
+            const double J[8] = {j0.x, j0.y, j1.x, j1.y, j2.x, j2.y, j3.x, j3.y};
+            const double wd = wc * dsv.h[q];
+            nat = fmax(nat, ck.hc[q][2] * fabs(h_ae[q] * wd + h_ab[q] * dsv.b[q]));      // the slack's column
+#pragma unroll
+            for (int k = 0; k < BS; k++) part[k] = __builtin_fma(J[k], wd, part[k]);
+          }
+          d2 v0, v1, v2, v3;
+          v0.x = part[0]; v0.y = part[1]; v1.x = part[2]; v1.y = part[3]; v2.x = part[4]; v2.y = part[5]; v3.x = part[6]; v3.y = BS > 7 ? part[7] : 0.0;
+          *(d2 *)part_p = v0; *(d2 *)(part_p + nslot2) = v1; *(d2 *)(part_p + 2 * nslot2) = v2; *(d2 *)(part_p + 3 * nslot2) = v3;
         }
+        if (x_row >= 0) x_p[oEX - oXT] = x_a * (x_w * dsv.x);
+        WV_SYNC();
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          if (ck.r0[v] >= 0) scr_dy[ck.r0[v]] = dsv.r0[v];
-          if (ck.var[v] >= 0) scr_dx[ck.var[v]] = dsv.var[v];
+          double aty = v_a[v] * dsv.r0[v] + v_p[v][oEX - oXT];
+          const double *pp = v_pp[v];
+          if (LPB > 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < LPB; s2++) aty += pp[s2 * 2];
+          } else {
+            for (int s2 = 0; s2 < lpb; s2++) aty += pp[s2 * 2];
+          }
+          if (v_on[v]) nat = fmax(nat, ck.vc[v][0] * fabs(aty));
         }
-        if (x_row >= 0) scr_dy[x_row] = dsv.x;
-        __threadfence(); __syncthreads();          // global memory hand-over between lanes: a real fence
-      };
-      if (!prim_ok && ndy > epi && lhs < -epi * ndy) {
-        spill_deltas();
-        double nat = 0.0;
-        for (int j = lane; j < n; j += WV_T) {
-          double aty = 0.0;
-          for (int t = a.Ap[j]; t < a.Ap[j + 1]; t++) { const int i = a.Ai[t]; aty += As[t] * scr_dy[i] * (double)a.w[(size_t)b * m + i]; }
-          nat = fmax(nat, fabs(aty / Dg[j]));
-        }
+        WV_SYNC();
         nat = wv_wmax(nat);
         if (nat < epi * ndy) { status = approximate ? SCO_QP_PRIMAL_INFEASIBLE_INACCURATE : SCO_QP_PRIMAL_INFEASIBLE; break; }
       }
-      if (!dual_ok && ndx > edi && qdx < -cscale * edi * ndx) {
-        spill_deltas();
-        const double *Psg = a.Ps + (size_t)b * a.nnzP;
+      if ((a.ablate & 64) == 0 && !dual_ok && ndx > edi && qdx < -cscale * edi * ndx) {
+        // delta_x of the core variables takes the place of x in its block vector (the next checked pass rewrites it)
+#pragma unroll
+        for (int v = 0; v < NV; v++) v_p[v][oXC - oXT] = dsv.var[v];
+        WV_SYNC();
         double npx = 0.0;
-        for (int j = lane; j < n; j += WV_T) {
-          double px = 0.0;
-          for (int t = a.Fp[j]; t < a.Fp[j + 1]; t++) px += Psg[a.Fpos[t]] * scr_dx[a.Fi[t]];
-          npx = fmax(npx, fabs(px / Dg[j]));
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double *c = ck.vc[v];
+          const int vix = (int)(v_p[v] - (lds + oXT)), p = (vix % (2 * NPOS)) >> 1;
+          double px = c[2] * lds[oXC + ck.pkm[v]] + c[3] * lds[oXC + ck.pkp[v]];
+          if (pdense) {
+            const double *cd = wv_opaque(cstg0) + (size_t)(wv_cst_v(NS, v) + 5) * 64;
+#pragma unroll
+            for (int k2 = 0; k2 < BS; k2++) px = __builtin_fma(cd[k2 * 64], lds[oXC + wv_vidx(NPOS, p, k2)], px);
+          } else {
+            px = __builtin_fma(c[4], dsv.var[v], px);
+          }
+          if (v_on[v]) npx = fmax(npx, c[0] * fabs(px));
         }
         npx = wv_wmax(npx);
         if (npx < cscale * edi * ndx) {
+          const double thr = edi * ndx;
           double badv = 0.0;
-          for (int i = lane; i < m; i += WV_T) {
-            double adx = 0.0;
-            for (int t = a.Rp[i]; t < a.Rp[i + 1]; t++) adx += As[a.Rpos[t]] * scr_dx[a.Rj[t]];
-            adx /= Eg[i];
-            if ((usg[i] < WV_BIG && adx > edi * ndx) || (lsg[i] > -WV_BIG && adx < -edi * ndx)) badv = 1.0;
+          const double *xq = xt_p + (oXC - oXT);
+          const d2 a0 = *(const d2 *)xq, a1 = *(const d2 *)(xq + 2 * NPOS), a2 = *(const d2 *)(xq + 4 * NPOS), a3 = *(const d2 *)(xq + 6 * NPOS);
+          const double dxb[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
+#pragma unroll
+          for (int q = 0; q < NS; q++) {
+            const d2 *jp = (const d2 *)(jl_p + q * 512);
+            const d2 j0 = jp[0], j1 = jp[64], j2 = jp[128], j3 = jp[192];
+            const double J[8] = {j0.x, j0.y, j1.x, j1.y, j2.x, j2.y, j3.x, j3.y};
+            double s2 = J[0] * dxb[0];
+#pragma unroll
+            for (int k = 1; k < BS; k++) s2 = __builtin_fma(J[k], dxb[k], s2);
+            const double adh = ck.hc[q][0] * (s2 + h_ae[q] * dsv.e[q]), adb = ck.hc[q][1] * (h_ab[q] * dsv.e[q]);
+            if (ck.h[q] >= 0 && ((h_u[q] < WV_BIG && adh > thr) || adb < -thr)) badv = 1.0;     // hinge: l = -inf; its slack's bound row: [0, inf)
+          }
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            const double adx = ck.vc[v][1] * (v_a[v] * dsv.var[v]);
+            if (ck.r0[v] >= 0 && ((v_u[v] < WV_BIG && adx > thr) || (v_l[v] > -WV_BIG && adx < -thr))) badv = 1.0;
+          }
+          if (x_row >= 0) {
+            const double adx = ck.xc * (x_a * x_p[oXC - oXT]);
+            if ((x_u < WV_BIG && adx > thr) || (x_l > -WV_BIG && adx < -thr)) badv = 1.0;
           }
           badv = wv_wmax(badv);
           if (badv == 0.0) { status = approximate ? SCO_QP_DUAL_INFEASIBLE_INACCURATE : SCO_QP_DUAL_INFEASIBLE; break; }
         }
+        WV_SYNC();
+#pragma unroll
+        for (int v = 0; v < NV; v++) v_p[v][oXC - oXT] = v_x[v];       // x back in its place (the test at max_iter runs twice)
+        WV_SYNC();
       }
     }
   }

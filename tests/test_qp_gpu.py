@@ -631,6 +631,41 @@ def test_wavefront_tier_leaves_odd_value_structure_to_the_row_local_kernel(gpu, 
     assert np.array_equal(st_wv, st_rl) and np.array_equal(it_wv, it_rl) and np.abs(x_wv - x_rl).max() < 1e-10
 
 
+@pytest.mark.parametrize("shape", [(6, 3, 4), (20, 7, 10)])
+def test_wavefront_tier_infeasibility_certificates(gpu, monkeypatch, shape):
+    """r04: the two infeasibility certificates of the wavefront tier run on its structured layout (A' (w dy), P dx and A dx
+    from the lane's rows and the block vectors in LDS, no generic loop over the pattern).  A pin outside its variable's box
+    (primal infeasible) and a cost that pushes every joint down a direction P does not see with the boxes open below (dual
+    infeasible), between ordinary problems: statuses and iteration counts = the oracle's and = the row-local kernel's."""
+    monkeypatch.setenv("SCO_WV_MIN_PER_CU", "0")
+    T, d, r = shape
+    rng = np.random.default_rng(300 + T)
+    probs = [list(penalty_qp(rng, T, d, r)) for _ in range(6)]
+    nx = T * d; box0 = d + T * r
+    for k in (2, 3):                                            # pin of joint k - 2 four above the box of its variable
+        lo, hi = probs[k][3].copy(), probs[k][4].copy()
+        lo[k - 2] = hi[k - 2] = hi[box0 + k - 2] + 4.0
+        probs[k][3], probs[k][4] = lo, hi
+    for k in (4, 5):
+        q, lo, hi = probs[k][1].copy(), probs[k][3].copy(), probs[k][4].copy()
+        lo[:d] = -np.inf; hi[:d] = np.inf                        # no pins
+        lo[box0:box0 + nx] = -np.inf                             # boxes open below
+        q[:nx] = 1000.0
+        probs[k][1], probs[k][3], probs[k][4] = q, lo, hi
+    probs = [tuple(p) for p in probs]
+    n, m, Pp, Pi, Ap, Ai, *_ = _stack(probs)
+    assert _tiers(n, m, Pp, Pi, Ap, Ai) & 32
+    # (one 7 x 20 case creeps down its ray until max_iter, in the oracle too: status and count are compared, its x of order 1e5 not)
+    _, x_wv, st_wv, it_wv = _check(probs, check=[0, 1, 2, 3, 5])
+    ref4 = o.solve(*probs[4])
+    assert (st_wv[4], it_wv[4]) == (ref4.info.status_val, ref4.info.iter)
+    assert list(st_wv[2:4]) == [-3, -3] and -4 in st_wv[4:6] and list(st_wv[:2]) == [1, 1], st_wv
+    monkeypatch.setenv("SCO_QP_NO_WV", "1")
+    _, x_rl, st_rl, it_rl = _check(probs, check=[])
+    assert np.array_equal(st_wv, st_rl) and np.array_equal(it_wv, it_rl)
+    assert np.abs(x_wv[:2] - x_rl[:2]).max() < 1e-10
+
+
 def test_wavefront_tier_time_slices_and_max_iter(gpu, monkeypatch):
     """Parked and resumed solves (sco_qp_settings.max_iter cut into slices by the SQP loop is covered in test_sqp_gpu.py);
     here: a solve that stops on max_iter between two termination checks, and one with check_termination off."""
