@@ -47,7 +47,20 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // (a VALU write of the broadcast operand needs two wait states before a DPP instruction reads it: the first of a chain
 // carries them itself, inline assembly is opaque to the compiler's hazard recogniser.  Plain `asm`, not `asm volatile`:
 // a volatile statement is a scheduling barrier, and the loads of the next block step have to move above this one's chain)
+#ifndef WV_KEEP
+#define WV_KEEP 8        // blocks of G per chain the forward sweep keeps in registers for the backward sweep
+#endif
+#ifndef WV_JREG
+#define WV_JREG 1
+#endif
+#ifndef WV_VARIANT
+#define WV_VARIANT 0          // timing variants (scripts/build_ablate.py wv:WV_VARIANT=1): 1 = plain v_fmac_f64 instead of the DPP broadcasts (results wrong)
+#endif
+#if WV_VARIANT == 1
+#define WV_FMAC_DPP(acc, w, g, k) asm("v_fmac_f64 %0, %1, %2" : "+v"(acc) : "v"(w), "v"(g))
+#else
 #define WV_FMAC_DPP(acc, w, g, k) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(g))
+#endif
 
 __host__ __device__ __forceinline__ size_t wv_tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // packed lower, j <= i
 
@@ -409,9 +422,13 @@ __device__ __forceinline__ double wv_matvec(double acc, double w, const WvRow<BS
   // states: the two chains are independent, so as separate statements the scheduler was free to put the second chain's
   // first broadcast directly behind the instruction that writes w (seen as wrong results of one build, r04).
   double acc2 = 0.0;
+#if WV_VARIANT == 1
+  WV_FMAC_DPP(acc, w, g0.x, 0); WV_FMAC_DPP(acc2, w, g0.y, 1);
+#else
   asm("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
       "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf"
       : "+v"(acc), "+v"(acc2) : "v"(w), "v"(g0.x), "v"(g0.y));
+#endif
   WV_FMAC_DPP(acc, w, g1.x, 2); WV_FMAC_DPP(acc2, w, g1.y, 3);
   WV_FMAC_DPP(acc, w, g2.x, 4); WV_FMAC_DPP(acc2, w, g2.y, 5); WV_FMAC_DPP(acc, w, g3.x, 6);
   if (BS > 7) WV_FMAC_DPP(acc2, w, g3.y, 7);
@@ -470,6 +487,11 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   double *const jl_p = lds + oJ + lane * 2;                                     // Jacobian rows, lane-private
   // hinge slots: constants and state
   double h_ae[NS], h_ab[NS], h_u[NS], h_q[NS], h_kinv[NS], h_z[NS], h_y[NS], h_zb[NS], h_yb[NS], h_xe[NS], h_ge[NS];
+  // The lane's Jacobian rows: constants of the solve, read twice per iteration.  In REGISTERS where the instantiation has
+  // room (NS x BS <= 28 doubles: the 7-DOF shapes), else lane-private in LDS: the kernel is bound by the CU's LDS pipe
+  // (four wavefronts share it), and these rows were a third of a wavefront's LDS bytes per iteration.
+  constexpr bool JREG = WV_JREG && NS * BS <= 28;
+  double hJ[JREG ? NS : 1][8];
 #pragma unroll
   for (int q = 0; q < NS; q++) {
     const int h = tab0[(oHROW + q) * 64 + lane], br = tab0[(oHBROW + q) * 64 + lane], ev = tab0[(oHEVAR + q) * 64 + lane];
@@ -486,7 +508,8 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     for (int k = 0; k < 4; k++) {
       const int j0 = on ? tab0[(oHJPOS + q * 8 + 2 * k) * 64 + lane] : -1, j1 = on ? tab0[(oHJPOS + q * 8 + 2 * k + 1) * 64 + lane] : -1;
       d2 v; v.x = j0 >= 0 ? As[j0] : 0.0; v.y = j1 >= 0 ? As[j1] : 0.0;
-      *(d2 *)(jl_p + (q * 4 + k) * 128) = v;
+      if (JREG) { hJ[q][2 * k] = v.x; hJ[q][2 * k + 1] = v.y; }
+      else *(d2 *)(jl_p + (q * 4 + k) * 128) = v;
     }
   }
   // core-variable slots
@@ -566,12 +589,18 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
       xt[0] = a0.x; xt[1] = a0.y; xt[2] = a1.x; xt[3] = a1.y; xt[4] = a2.x; xt[5] = a2.y; xt[6] = a3.x; xt[7] = a3.y;
     }
     double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    d2 jn0, jn1, jn2, jn3;                       // the NEXT slot's row is in flight while this one's arithmetic runs
-    { const d2 *jp = (const d2 *)jl_p; jn0 = jp[0]; jn1 = jp[64]; jn2 = jp[128]; jn3 = jp[192]; }
+    d2 jn0, jn1, jn2, jn3;                       // (rows in LDS) the NEXT slot's row is in flight while this one's arithmetic runs
+    if (!JREG) { const d2 *jp = (const d2 *)jl_p; jn0 = jp[0]; jn1 = jp[64]; jn2 = jp[128]; jn3 = jp[192]; }
 #pragma unroll
     for (int q = 0; q < NS; q++) {
-      const double J[8] = {jn0.x, jn0.y, jn1.x, jn1.y, jn2.x, jn2.y, jn3.x, jn3.y};
-      if (q + 1 < NS) { const d2 *jp = (const d2 *)(jl_p + (q + 1) * 512); jn0 = jp[0]; jn1 = jp[64]; jn2 = jp[128]; jn3 = jp[192]; }
+      double J[8];
+      if (JREG) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) J[k] = hJ[q][k];
+      } else {
+        J[0] = jn0.x; J[1] = jn0.y; J[2] = jn1.x; J[3] = jn1.y; J[4] = jn2.x; J[5] = jn2.y; J[6] = jn3.x; J[7] = jn3.y;
+        if (q + 1 < NS) { const d2 *jp = (const d2 *)(jl_p + (q + 1) * 512); jn0 = jp[0]; jn1 = jp[64]; jn2 = jp[128]; jn3 = jp[192]; }
+      }
       const double ae = h_ae[q], ab = h_ab[q], kinv = h_kinv[q];
       const double c2 = rw * ae;
       if (MODE) {
@@ -700,9 +729,16 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     // read comes back after ~130 (scripts/microbench/wave_cost.hip): the rows of G, the right-hand sides and the couplings
     // are asked for WV_PD block steps ahead (r04: one step ahead left the sweeps waiting for LDS, 176 cycles per step).
     constexpr int PD = WV_PD < NSTEP ? WV_PD : NSTEP;
+    // The sweeps are bound by the CU's LDS pipe, not by their arithmetic (r04: plain v_fmac_f64 in place of the DPP broadcasts
+    // changes nothing, scripts/build_ablate.py wv:WV_VARIANT=1; four wavefronts x 21 steps x 16 lanes x 64 B of G per pass):
+    // rows of G the forward pass has read stay in registers for the backward pass (16 VGPRs per block) where the
+    // instantiation has room.
+    constexpr int KEEPN = NSTEP <= 10 ? (WV_KEEP < NSTEP ? WV_KEEP : NSTEP) : 0;      // the forward pass's last KEEPN blocks
+    constexpr int K0 = NSTEP - KEEPN;
+    WvRow<BS> gk[KEEPN > 0 ? KEEPN : 1];
     double vs[NSTEP];
     WvRow<BS> gq[PD]; double rq[PD], eq[PD];
-    double emk = 0.0;
+    double emk = 0.0, vlast = 0.0;
     if (sw_store) {
       auto fetch_fwd = [&](int st, WvRow<BS> &g, double &r, double &e) {      // block st of the chain; st = NSTEP: the middle block
         if (st < NSTEP) { g = wv_row<BS>(sw_g + st * 64, sw_gd + st * 64); r = sw_v[st * 2]; e = sw_e[st * 8]; }
@@ -718,20 +754,29 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         const double w = __builtin_fma(-ee, vprev, rr);
         vprev = wv_matvec<BS>(0.0, w, g);
         vs[st] = vprev;
+        if (st >= K0) gk[st - K0] = g;
       }
-      // the middle block needs the last vector of BOTH chains: through LDS (the x~ positions of those two blocks)
       emk = lds[oEM + k8];
-      sw_v[(NSTEP - 1) * 2 + (oXT - oR)] = vs[NSTEP - 1];
+      vlast = vs[NSTEP - 1];
     }
-    WV_SYNC();
+    // the middle block needs the last vector of BOTH chains: DPP row 0 holds chain A's, row 1 chain B's.  One
+    // v_permlane16_swap per register half hands each row the other's (through LDS the exchange was a store, a wait and a
+    // read: ~250 cycles of the ~3000 of a sweep).  All lanes take part in the swap; only the sweep lanes use the result.
+    double vother;
+    {
+      const wv_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(vlast), (unsigned)__double2loint(vlast), false, false);
+      const wv_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(vlast), (unsigned)__double2hiint(vlast), false, false);
+      // .x: odd rows now hold the even rows' values; .y: even rows now hold the odd rows' values
+      vother = chain ? __hiloint2double((int)hi.x, (int)lo.x) : __hiloint2double((int)hi.y, (int)lo.y);
+    }
     if (sw_store) {
       // (slot NSTEP % PD of the ring holds the middle block: fetched PD steps before the end of the forward sweep)
       const WvRow<BS> gm = gq[NSTEP % PD]; const double rm = rq[NSTEP % PD], em_ = eq[NSTEP % PD];
-      const double vA = md_v[-2 + (oXT - oR)], vB = md_v[NSTEP * 2 + (oXT - oR)];
+      const double vA = chain ? vother : vlast, vB = chain ? vlast : vother;
       // backward sweep: block st of the chain and its coupling towards the middle, again PD steps ahead
       WvRow<BS> gb[PD]; double eb[PD];
       auto fetch_bwd = [&](int st, WvRow<BS> &g, double &e) {
-        if (st >= 0) { g = wv_row<BS>(sw_g + st * 64, sw_gd + st * 64); e = sw_e[st * 8 + (oEN - oEF)]; }
+        if (st >= 0) { if (st < K0) g = wv_row<BS>(sw_g + st * 64, sw_gd + st * 64); e = sw_e[st * 8 + (oEN - oEF)]; }
       };
 #pragma unroll
       for (int i = 0; i < PD; i++) fetch_bwd(NSTEP - 1 - i, gb[i], eb[i]);
@@ -742,7 +787,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
 #pragma unroll
       for (int st = NSTEP - 1; st >= 0; st--) {
         const int slot = (NSTEP - 1 - st) % PD;
-        const WvRow<BS> g = gb[slot]; const double ee = eb[slot];
+        const WvRow<BS> g = st >= K0 ? gk[st - K0] : gb[slot]; const double ee = eb[slot];
         fetch_bwd(st - PD, gb[slot], eb[slot]);
         const double u = -(ee * xn);
         xn = wv_matvec<BS>(vs[st], u, g);
@@ -786,9 +831,15 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < NS; q++) {
-          const d2 *jp = (const d2 *)(jl_p + q * 512);
-          const d2 j0 = jp[0], j1 = jp[64], j2 = jp[128], j3 = jp[192];
-          const double J[8] = {j0.x, j0.y, j1.x, j1.y, j2.x, j2.y, j3.x, j3.y};
+          double J[8];
+          if (JREG) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) J[k] = hJ[q][k];
+          } else {
+            const d2 *jp = (const d2 *)(jl_p + q * 512);
+            const d2 j0 = jp[0], j1 = jp[64], j2 = jp[128], j3 = jp[192];
+            J[0] = j0.x; J[1] = j0.y; J[2] = j1.x; J[3] = j1.y; J[4] = j2.x; J[5] = j2.y; J[6] = j3.x; J[7] = j3.y;
+          }
           double s = J[0] * xc[0];
 #pragma unroll
           for (int k = 1; k < BS; k++) s = __builtin_fma(J[k], xc[k], s);
@@ -862,9 +913,15 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
           double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int q = 0; q < NS; q++) {
-            const d2 *jp = (const d2 *)(jl_p + q * 512);
-            const d2 j0 = jp[0], j1 = jp[64], j2 = jp[128], j3 = jp[192];
-            const double J[8] = {j0.x, j0.y, j1.x, j1.y, j2.x, j2.y, j3.x, j3.y};
+            double J[8];
+            if (JREG) {
+#pragma unroll
+              for (int k = 0; k < 8; k++) J[k] = hJ[q][k];
+            } else {
+              const d2 *jp = (const d2 *)(jl_p + q * 512);
+              const d2 j0 = jp[0], j1 = jp[64], j2 = jp[128], j3 = jp[192];
+              J[0] = j0.x; J[1] = j0.y; J[2] = j1.x; J[3] = j1.y; J[4] = j2.x; J[5] = j2.y; J[6] = j3.x; J[7] = j3.y;
+            }
             const double wd = wc * dsv.h[q];
             nat = fmax(nat, ck.hc[q][2] * fabs(h_ae[q] * wd + h_ab[q] * dsv.b[q]));      // the slack's column
 #pragma unroll
@@ -921,9 +978,15 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
           const double dxb[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
 #pragma unroll
           for (int q = 0; q < NS; q++) {
-            const d2 *jp = (const d2 *)(jl_p + q * 512);
-            const d2 j0 = jp[0], j1 = jp[64], j2 = jp[128], j3 = jp[192];
-            const double J[8] = {j0.x, j0.y, j1.x, j1.y, j2.x, j2.y, j3.x, j3.y};
+            double J[8];
+            if (JREG) {
+#pragma unroll
+              for (int k = 0; k < 8; k++) J[k] = hJ[q][k];
+            } else {
+              const d2 *jp = (const d2 *)(jl_p + q * 512);
+              const d2 j0 = jp[0], j1 = jp[64], j2 = jp[128], j3 = jp[192];
+              J[0] = j0.x; J[1] = j0.y; J[2] = j1.x; J[3] = j1.y; J[4] = j2.x; J[5] = j2.y; J[6] = j3.x; J[7] = j3.y;
+            }
             double s2 = J[0] * dxb[0];
 #pragma unroll
             for (int k = 1; k < BS; k++) s2 = __builtin_fma(J[k], dxb[k], s2);

@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sco_py_amd import _build
 
-# arguments: ablation masks as integers; "vN" = -DRL_VARIANT=N; "name=path.hip" = an alternative kernel source
+# arguments: ablation masks as integers; "vN" = -DRL_VARIANT=N; "name=path.hip" = an alternative kernel source;
+# "wv:NAME=VAL[,NAME=VAL]" = the wavefront tier's source (sco_admm_wv.hip) with those defines (WV_PD, WV_VARIANT)
 masks = sys.argv[1:] or ["0", "1", "2", "4", "8", "12", "16", "31"]
 _build.build()                                   # product objects are current
 out = os.path.join(_build.CSRC, "variants")
@@ -18,7 +19,13 @@ os.makedirs(out, exist_ok=True)
 
 def one(mask):
     src, defs, tag = os.path.join(_build.CSRC, "sco_admm_rl.hip"), [], mask
-    if "=" in mask:
+    base = "sco_admm_rl.hip"
+    if mask.startswith("wv:"):
+        base = "sco_admm_wv.hip"
+        src = os.path.join(_build.CSRC, base)
+        defs = ["-D" + d for d in mask[3:].split(",")]
+        tag = "wv_" + mask[3:].replace("=", "").replace(",", "_")
+    elif "=" in mask:
         tag, src = mask.split("=", 1)
     elif mask.startswith("v"):
         defs = ["-DRL_VARIANT=%d" % int(mask[1:])]
@@ -27,7 +34,7 @@ def one(mask):
     mask = tag
     obj = os.path.join(out, "rl_%s.o" % mask)
     subprocess.check_call([_build.hipcc_path()] + _build.FLAGS + defs + ["-I", _build.CSRC, "-x", "hip", "-c", src, "-o", obj])
-    objs = [os.path.join(_build.OBJ, os.path.splitext(s)[0] + ".o") for s in _build.SOURCES if s != "sco_admm_rl.hip"]
+    objs = [os.path.join(_build.OBJ, os.path.splitext(s)[0] + ".o") for s in _build.SOURCES if s != base]
     lib = os.path.join(out, "libsco_ablate_%s.so" % mask)
     subprocess.check_call([_build.hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib, obj] + objs)
     os.remove(obj)

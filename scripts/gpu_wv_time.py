@@ -3,7 +3,9 @@ import os, sys
 import numpy as np, scipy.sparse as sp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = [sys.argv[0], "noop"]
-from sco_py_amd import _lib as L
+from sco_py_amd import _lib as L, _build
+if os.environ.get("SCO_LIB_OVERRIDE"):
+    _build.LIB = os.environ["SCO_LIB_OVERRIDE"]; print("library", _build.LIB)
 os.environ["SCO_WV_MIN_PER_CU"] = "0"     # every launch on the wavefront tier (default: > 3.3 problems per CU)
 import importlib.util
 spec = importlib.util.spec_from_file_location("wvc", os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_wv_check.py"))
@@ -32,7 +34,7 @@ def timeit(B, ablate, iters=20000):
     tm = qp.last_timing(); qp.close()
     return 1e3 * tm["admm_ms"] / iters
 
-for B in (64, 1024):
+for B in ((1024,) if os.environ.get("SCO_LIB_OVERRIDE") else (64, 1024)):
     for ab, name in ((0, "full (with termination tests)"), (4, "full, no termination tests"), (64, "tests without infeasibility certificates"),
                      (16, "checked iterations, no test pass"), (1, "no sweeps"), (2, "no row passes")):
         print("B=%5d %-32s %.3f us per iteration" % (B, name, timeit(B, ab)))
