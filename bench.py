@@ -418,7 +418,7 @@ def main():
                   "ratio_to_8TBps": alg_bytes / secs / HBM_PEAK if secs > 0 else 0.0,
                   "algorithmic_bytes_per_launch": alg_bytes / launches}
         if big:
-            tj, src = measured_traffic("r03_traffic_12x50.json")
+            tj, src = measured_traffic("r04_traffic_12x50.json")
             # a PMC record is quoted for the batch it was taken at only (the working set, and with it the share of the
             # Infinity Cache, follows the batch)
             if tj and tj.get("batch") != r["B"]:
