@@ -304,6 +304,17 @@ int sco_sqp_load_quadratic(sco_sqp *h, const double *Q, const double *a, const d
  * is uploaded.  May be called again (new parameters per solve): the handle reuses its buffers. */
 int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts, const double *consts,
                          int n_params, const double *params);
+/* r04: the same with one parameter vector per problem AND timestep, params[batch][horizon][n_params]: block t (the Variable of
+ * timesteps t .. t + span - 1) and the objective term of timestep t read params[problem][t] -- what a caller of the reference
+ * gets by closing each timestep's Expr over its own data (moving obstacles, time-varying references: expr.py:22-41,
+ * prob.py:112-144).  Rows t >= horizon - span + 1 of the parameter array are read by the objective term only. */
+int sco_sqp_load_program_steps(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts, const double *consts,
+                               int n_params, const double *params);
+/* r04: per-problem, per-joint weights of the smoothing objective, w[batch][dof] finite and >= 0:
+ *     sum_t sum_j w_j (theta[t+1][j] - theta[t][j])^2
+ * i.e. the QuadExpr a caller of the reference builds from a weighted difference matrix (prob.py:88-104, 348-367; the unweighted
+ * form is the default).  After sco_sqp_load; NULL restores all weights 1.  Any family. */
+int sco_sqp_load_obj_weights(sco_sqp *h, const double *w);
 /* SCO_FAM_FLAG_VEL_LIMITS only, after sco_sqp_load: vmax[batch] > 0, one limit per problem. */
 int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax);
 /* SCO_FAM_FLAG_JOINT_LIMITS only, after sco_sqp_load: lo[batch][dof] < hi[batch][dof]. */

@@ -480,10 +480,11 @@ def trajopt_flat(prob, analytic_jac=False):
     d, T = prob["d"], prob["T"]
     n_x = d * T
     Q = sp.lil_matrix((n_x, n_x))
+    ow = prob["obj_w"] if prob.get("obj_w") is not None else np.ones(d)      # r04: per-joint weights of the smoothing objective
     for t in range(T - 1):
         for j in range(d):
             a, b = t * d + j, (t + 1) * d + j
-            Q[a, a] += 2.0; Q[b, b] += 2.0; Q[a, b] -= 2.0; Q[b, a] -= 2.0
+            Q[a, a] += 2.0 * ow[j]; Q[b, b] += 2.0 * ow[j]; Q[a, b] -= 2.0 * ow[j]; Q[b, a] -= 2.0 * ow[j]
     reach = bool(prob.get("reach"))
     lin = sp.lil_matrix((d if reach else 2 * d, n_x))
     for j in range(d):
@@ -514,8 +515,8 @@ def trajopt_flat(prob, analytic_jac=False):
             for kind, rows in (("leq", prog.ineq_rows), ("eq", prog.eq_rows)):
                 if not rows:
                     continue
-                f = prog.numpy_fn(prob["row_params"], rows)
-                jac = prog.numpy_jac(prob["row_params"], rows) if analytic_jac else None
+                f = prog.numpy_fn(af.step_params(prob, t), rows)
+                jac = prog.numpy_jac(af.step_params(prob, t), rows) if analytic_jac else None
                 blocks.append(Block(kind, f, idx, np.zeros(len(rows)), jac=jac, groups=gids))
     if prob.get("quad_n_eq"):
         # quadratic rows with equality rows (r03): the block's inequality rows are one LEqExpr, its last quad_n_eq rows one
@@ -530,8 +531,8 @@ def trajopt_flat(prob, analytic_jac=False):
                 blocks.append(Block(kind, f, idx, np.zeros(len(range(R)[sl])), jac=jac, groups=gids))
     for t in range(T if not ((prog is not None and (span > 1 or prog.n_eq > 0)) or prob.get("quad_n_eq")) else 0):
         if prob.get("row_program") is not None:  # SCO_FAM_STATE_PROGRAM: closed-form rows
-            f = prob["row_program"].numpy_fn(prob["row_params"])
-            jac = prob["row_program"].numpy_jac(prob["row_params"]) if analytic_jac else None
+            f = prob["row_program"].numpy_fn(af.step_params(prob, t))
+            jac = prob["row_program"].numpy_jac(af.step_params(prob, t)) if analytic_jac else None
         elif prob.get("quad_Q") is not None:    # SCO_FAM_STATE_QUADRATIC: general quadratic rows on the state
             f = (lambda th, pr=prob: af.quad_rows(th, pr["quad_Q"], pr["quad_a"], pr["quad_c"]))
             jac = (lambda th, pr=prob: af.quad_rows_jac(th, pr["quad_Q"], pr["quad_a"], pr["quad_c"])) if analytic_jac else None
@@ -553,7 +554,7 @@ def trajopt_flat(prob, analytic_jac=False):
     obj_blocks = []
     if prog is not None and prog.objective:      # SCO_FAM_FLAG_OBJ_PROGRAM: a non-quadratic objective term per timestep
         for t in range(T):
-            obj_blocks.append(ObjBlock(prog.objective_fn(prob["row_params"]), np.arange(t * d, (t + 1) * d)))
+            obj_blocks.append(ObjBlock(prog.objective_fn(af.step_params(prob, t)), np.arange(t * d, (t + 1) * d)))
     if prob.get("cost_weight") is not None:
         for t in range(T):
             fc = (lambda th, pr=prob: af.ee_cost(th, pr["link_len"], pr["cost_target"], pr["cost_weight"]))

@@ -117,9 +117,11 @@ class TrajOptBatch(object):
 
     def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles, target=None, vmax=None,
              jlo=None, jhi=None, cost_weight=None, cost_target=None, quad_Q=None, quad_a=None, quad_c=None,
-             row_program=None, row_params=None):
+             row_program=None, row_params=None, obj_weights=None):
         """Upload per-problem data (host arrays, copied).  ``target`` (B, 2): end-effector
-        position of the reach variant (``goal`` is then ignored by the device)."""
+        position of the reach variant (``goal`` is then ignored by the device).  r04: ``row_params`` may be (B, T, n_params) --
+        one parameter vector per timestep (block t and the objective term of timestep t read row_params[b, t]);
+        ``obj_weights`` (B, dof): weights w_j of the smoothing objective sum_t sum_j w_j (x[t+1][j] - x[t][j])^2."""
         B, d, K, O = self.B, self.d, self.K, self.O
 
         def arr(a, shape, dt=np.float64):
@@ -149,8 +151,12 @@ class TrajOptBatch(object):
                                  % (row_program.n_rows, row_program.n_eq, row_program.n_state, row_program.span, row_program.objective,
                                     O, self.n_eq, d, self.span, self.obj_program))
             npar = row_program.n_params
-            par = arr(row_params if row_params is not None else np.zeros((B, 0)), (B, npar)) if npar else np.zeros((B, 0))
-            _lib.check(_lib.load().sco_sqp_load_program(
+            per_step = npar > 0 and row_params is not None and np.ndim(row_params) == 3
+            if per_step:
+                par = arr(row_params, (B, self.T, npar))
+            else:
+                par = arr(row_params if row_params is not None else np.zeros((B, 0)), (B, npar)) if npar else np.zeros((B, 0))
+            _lib.check((_lib.load().sco_sqp_load_program_steps if per_step else _lib.load().sco_sqp_load_program)(
                 self._h, len(row_program.words), _lib.iptr(np.ascontiguousarray(row_program.words.ravel())), _lib.iptr(row_program.row_ptr),
                 len(row_program.consts), _lib.dptr(row_program.consts) if len(row_program.consts) else None,
                 npar, _lib.dptr(par) if npar else None))
@@ -176,6 +182,11 @@ class TrajOptBatch(object):
             jlo = arr(np.broadcast_to(np.asarray(jlo, dtype=np.float64), (B, d)), (B, d))
             jhi = arr(np.broadcast_to(np.asarray(jhi, dtype=np.float64), (B, d)), (B, d))
             _lib.check(_lib.load().sco_sqp_load_joint_limits(self._h, _lib.dptr(jlo), _lib.dptr(jhi)))
+        if obj_weights is not None:
+            ow = arr(np.broadcast_to(np.asarray(obj_weights, dtype=np.float64), (B, d)), (B, d))
+            _lib.check(_lib.load().sco_sqp_load_obj_weights(self._h, _lib.dptr(ow)))
+        else:
+            _lib.check(_lib.load().sco_sqp_load_obj_weights(self._h, None))
 
     def set_groups(self, block_groups):
         """Constraint groups (``prob.add_cnt_expr(bound_expr, group_ids)``): one list of group ids
@@ -261,7 +272,7 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
                 target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
                 cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),
                 quad_Q=a.get("quad_Q"), quad_a=a.get("quad_a"), quad_c=a.get("quad_c"),
-                row_program=a.get("row_program"), row_params=a.get("row_params"))
+                row_program=a.get("row_program"), row_params=a.get("row_params"), obj_weights=a.get("obj_w"))
         if a.get("groups") is not None:
             tb.set_groups(a["groups"])
         tb.solve(params, qp_settings)

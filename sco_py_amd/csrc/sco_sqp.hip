@@ -68,6 +68,9 @@ struct SqpDev {
   double *qQ, *qa, *qc;   // [B][O][d*d], [B][O][d], [B][O]
                      // 3 SCO_FAM_STATE_PROGRAM: rows as postfix programs (shared) over the state and per-problem parameters
   const int *pw, *pptr; const double *pconst; const double *ppar; int n_par;
+  int par_step;      // r04: 0 = one parameter vector per problem; n_par = one per problem AND timestep (sco_sqp_load_program_steps:
+                     // block t and the objective term of timestep t read params[problem][t])
+  const double *objw;     // r04: [B][d] weights of the smoothing objective sum_t sum_j w_j (x[t+1][j] - x[t][j])^2, nullptr = all 1
   // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows, then m_jl joint-limit
   // rows (theta <= hi for every trajectory variable, then -theta <= -lo)
   int m_pin, m_vel, m_jl;
@@ -125,6 +128,7 @@ struct sco_sqp {
   std::vector<void *> allocs;
   std::vector<hipEvent_t> events;
   void *prog_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // sco_sqp_load_program: words, row starts, constants, parameters
+  void *objw_buf = nullptr;                                    // sco_sqp_load_obj_weights
   size_t prog_bytes[4] = {0, 0, 0, 0};
   bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false, cost_loaded = false, quad_loaded = false, prog_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
@@ -307,11 +311,11 @@ __device__ __forceinline__ RowRef row_ref(int e, const RowLay &L) {
 
 struct RowCtx { const double *len, *obs, *target; const int *point_link; const double *point_frac; int d, O, point;
                 const double *qQ, *qa, *qc;         // SCO_FAM_STATE_QUADRATIC: this problem's row coefficients (point == 2)
-                const int *pw, *pptr; const double *pconst, *ppar; };   // SCO_FAM_STATE_PROGRAM (point == 3): words, row starts, constants, this problem's parameters
+                const int *pw, *pptr; const double *pconst, *ppar; int par_step; };   // SCO_FAM_STATE_PROGRAM (point == 3): words, row starts, constants, this problem's parameters (block t: ppar + t * par_step)
 // (for the state families `d` is the dimension of a BLOCK's state, span x dof)
 
 // SCO_FAM_STATE_PROGRAM: value of program `o` at th, up to two coordinates perturbed (finite differences)
-__device__ __forceinline__ double prog_eval(const RowCtx &c, int o, const double *th, int pi, double hi, int pj, double hj) {
+__device__ __forceinline__ double prog_eval(const RowCtx &c, const double *par, int o, const double *th, int pi, double hi, int pj, double hj) {
   double st[SCO_PROGRAM_STACK];
   int sp = 0;
   for (int w = c.pptr[o];; w++) {
@@ -319,7 +323,7 @@ __device__ __forceinline__ double prog_eval(const RowCtx &c, int o, const double
     if (op == SCO_OP_END) break;
     switch (op) {
       case SCO_OP_X: st[sp++] = th[arg] + (arg == pi ? hi : 0.0) + (arg == pj ? hj : 0.0); break;
-      case SCO_OP_P: st[sp++] = c.ppar[arg]; break;
+      case SCO_OP_P: st[sp++] = par[arg]; break;
       case SCO_OP_C: st[sp++] = c.pconst[arg]; break;
       case SCO_OP_ADD: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
       case SCO_OP_SUB: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
@@ -338,7 +342,7 @@ __device__ __forceinline__ double prog_eval(const RowCtx &c, int o, const double
 // d(program o) / d x_j by forward-mode differentiation: every stack slot carries (value, derivative along e_j); the rules,
 // in this order of operations, are the ones sco_py_amd/rowexpr.py:Program.jacobian applies on the host (the `grad` a caller
 // hands to the reference's Expr, expr.py:86-100), so host and device agree to rounding
-__device__ __forceinline__ double prog_dual(const RowCtx &c, int o, const double *th, int j) {
+__device__ __forceinline__ double prog_dual(const RowCtx &c, const double *par, int o, const double *th, int j) {
   // no fused multiply-adds here: the host applies the rules operation by operation (NumPy), and a derivative that differs in
   // its last bit can move the iteration count of a slowly converging QP by many termination checks
 #pragma clang fp contract(off)
@@ -349,7 +353,7 @@ __device__ __forceinline__ double prog_dual(const RowCtx &c, int o, const double
     if (op == SCO_OP_END) break;
     switch (op) {
       case SCO_OP_X: sv[sp] = th[arg]; sd[sp++] = (arg == j) ? 1.0 : 0.0; break;
-      case SCO_OP_P: sv[sp] = c.ppar[arg]; sd[sp++] = 0.0; break;
+      case SCO_OP_P: sv[sp] = par[arg]; sd[sp++] = 0.0; break;
       case SCO_OP_C: sv[sp] = c.pconst[arg]; sd[sp++] = 0.0; break;
       case SCO_OP_ADD: sp--; sv[sp - 1] = sv[sp - 1] + sv[sp]; sd[sp - 1] = sd[sp - 1] + sd[sp]; break;
       case SCO_OP_SUB: sp--; sv[sp - 1] = sv[sp - 1] - sv[sp]; sd[sp - 1] = sd[sp - 1] - sd[sp]; break;
@@ -370,7 +374,7 @@ __device__ __forceinline__ double prog_dual(const RowCtx &c, int o, const double
 __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, const double *th, int pert, double h) {
   if (q.eq == 1) return arm_ee(th, c.len, c.d, q.r, pert, h);
   const int kp = q.r / c.O, o = q.r % c.O;
-  if (c.point == 3) return prog_eval(c, o, th, pert, h, -1, 0.0);      // SCO_FAM_STATE_PROGRAM: the row's postfix program
+  if (c.point == 3) return prog_eval(c, c.ppar + q.t * c.par_step, o, th, pert, h, -1, 0.0);      // SCO_FAM_STATE_PROGRAM: the row's postfix program
   if (c.point == 2) {                          // SCO_FAM_STATE_QUADRATIC: 1/2 x' Q x + a' x + c of row o
     const double *Q = c.qQ + (size_t)o * c.d * c.d, *av = c.qa + (size_t)o * c.d;
     double val = c.qc[o];
@@ -391,7 +395,7 @@ __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, co
 __device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, const double *th, int j) {
   if (q.eq == 1) return arm_ee_grad(th, c.len, c.d, q.r, j);
   const int kp = q.r / c.O, o = q.r % c.O;
-  if (c.point == 3) return prog_dual(c, o, th, j);      // forward-mode differentiation of the row's program (r03)
+  if (c.point == 3) return prog_dual(c, c.ppar + q.t * c.par_step, o, th, j);      // forward-mode differentiation of the row's program (r03)
   if (c.point == 2) {                          // a_j + sum_i Q_ji x_i  (Q symmetric)
     const double *Q = c.qQ + (size_t)o * c.d * c.d;
     double g = c.qa[(size_t)o * c.d + j];
@@ -408,8 +412,8 @@ __device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, con
 // non-quadratic objective term of a timestep with up to two perturbed coordinates: the arm's end-effector term
 // (SCO_FAM_FLAG_EE_COST) or the objective program (SCO_FAM_FLAG_OBJ_PROGRAM: program index O)
 struct ObjCtx { int kind; const double *len; int d; double tx, ty, w; };
-__device__ __forceinline__ double obj_value(const ObjCtx &oc, const RowCtx &c, const double *th, int pi, double hi, int pj, double hj) {
-  if (oc.kind == 2) return prog_eval(c, c.O, th, pi, hi, pj, hj);
+__device__ __forceinline__ double obj_value(const ObjCtx &oc, const RowCtx &c, int t, const double *th, int pi, double hi, int pj, double hj) {
+  if (oc.kind == 2) return prog_eval(c, c.ppar + t * c.par_step, c.O, th, pi, hi, pj, hj);
   return arm_ee_cost(th, oc.len, oc.d, oc.tx, oc.ty, oc.w, pi, hi, pj, hj);
 }
 __device__ __forceinline__ double row_rhs(const RowCtx &c, const RowRef &q) { return q.eq == 1 ? c.target[q.r] : 0.0; }
@@ -427,11 +431,12 @@ __device__ __forceinline__ int memo_find(const double *keys, int count, int d, c
   return -1;
 }
 
-__device__ __forceinline__ double traj_obj_partial(const double *x, int d, int T, int tid) {
+// w: the problem's objective weights (r04, QuadExpr with per-joint weights, prob.py:348-367) or nullptr = all 1
+__device__ __forceinline__ double traj_obj_partial(const double *x, int d, int T, int tid, const double *w) {
   double s = 0.0;
   for (int e = tid; e < (T - 1) * d; e += SCO_BLOCK) {
     const double df = x[e + d] - x[e];
-    s += df * df;
+    s += w ? w[e % d] * (df * df) : df * df;
   }
   return s;
 }
@@ -518,9 +523,10 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
     for (int col = 0; col < n_x; col++) {   // cheap: n_x entries, one thread
       if (tid == 0) {
         const int t = col / d;
-        if (t > 0) Pv[pos++] = -2.0;
+        const double wj = s.objw ? s.objw[(size_t)b * d + col % d] : 1.0;
+        if (t > 0) Pv[pos++] = -2.0 * wj;
         if (s.cost) for (int i = 0; i < col % d; i++) Pv[pos++] = 0.0;
-        Pv[pos++] = (t == 0 || t == s.T - 1) ? 2.0 : 4.0;
+        Pv[pos++] = ((t == 0 || t == s.T - 1) ? 2.0 : 4.0) * wj;
       }
     }
     double *qv = q1.q + (size_t)b * n;
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     const int H = s.H, HC = s.HC, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
     const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, ds, O, s.point,
                   s.qQ + (size_t)b * O * ds * ds, s.qa + (size_t)b * O * ds, s.qc + (size_t)b * O,
-                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par};
+                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step};
     double *hkey = s.hkey + (size_t)b * NB * H * ds, *hval = s.hval + (size_t)b * NB * H * RM;
     double *ckey = s.ckey + (size_t)b * NB * HC * ds, *cJ = s.cJ + (size_t)b * NB * HC * RM * ds, *cb = s.cb + (size_t)b * NB * HC * RM;
     int *hn = s.hn + (size_t)b * NB, *cn = s.cn + (size_t)b * NB;
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         double f;
         if (ev_hit[t] >= 0) f = hval[((size_t)t * H + ev_hit[t]) * RM + (RM - 1)];
         else {
-          f = obj_value(oc, rc, x + t * d, -1, 0.0, -1, 0.0);
+          f = obj_value(oc, rc, t, x + t * d, -1, 0.0, -1, 0.0);
           if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * RM + (RM - 1)] = f;
         }
         of0[t] = f;
@@ -711,14 +717,14 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         for (int lv = 0; lv < FD_LEVELS; lv++) {
           const double hi = si / (double)(1 << lv), hj = sj / (double)(1 << lv);
           if (i == j) {
-            const double fp = obj_value(oc, rc, th, i, hi, -1, 0.0);
-            const double fm = obj_value(oc, rc, th, i, -hi, -1, 0.0);
+            const double fp = obj_value(oc, rc, t, th, i, hi, -1, 0.0);
+            const double fm = obj_value(oc, rc, t, th, i, -hi, -1, 0.0);
             tab[lv] = (fp - 2.0 * of0[t] + fm) / (hi * hi);
           } else {
-            const double fpp = obj_value(oc, rc, th, i, hi, j, hj);
-            const double fpm = obj_value(oc, rc, th, i, hi, j, -hj);
-            const double fmp = obj_value(oc, rc, th, i, -hi, j, hj);
-            const double fmm = obj_value(oc, rc, th, i, -hi, j, -hj);
+            const double fpp = obj_value(oc, rc, t, th, i, hi, j, hj);
+            const double fpm = obj_value(oc, rc, t, th, i, hi, j, -hj);
+            const double fmp = obj_value(oc, rc, t, th, i, -hi, j, hj);
+            const double fmm = obj_value(oc, rc, t, th, i, -hi, j, -hj);
             tab[lv] = (fpp - fpm - fmp + fmm) / (4.0 * hi * hj);
           }
         }
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
 #pragma unroll
         for (int lv = 0; lv < FD_LEVELS; lv++) {
           const double h = h0 / (double)(1 << lv);
-          tab[lv] = (obj_value(oc, rc, th, j, h, -1, 0.0) - obj_value(oc, rc, th, j, -h, -1, 0.0)) / (2.0 * h);
+          tab[lv] = (obj_value(oc, rc, t, th, j, h, -1, 0.0) - obj_value(oc, rc, t, th, j, -h, -1, 0.0)) / (2.0 * h);
         }
         oA[e] = richardson(tab);
       }
@@ -763,13 +769,13 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         int k = e % npair, i = 0;
         while (k >= d - i) { k -= d - i; i++; }
         const int j = i + k;
-        const double base = (i == j) ? ((t == 0 || t == T - 1) ? 2.0 : 4.0) : 0.0;
+        const double base = (i == j) ? ((t == 0 || t == T - 1) ? 2.0 : 4.0) * (s.objw ? s.objw[(size_t)b * d + i] : 1.0) : 0.0;
         Pv[s.ppos[t * d + j] + i] = base + oH[(size_t)t * d * d + i * d + j];
       }
       for (int e = tid; e < n_x; e += SCO_BLOCK) qv[e] = oA[e];
     }
     // S7: merit at the convexification point (prob.py:571-579), S4 prerequisite: save
-    double v[2] = {traj_obj_partial(x, d, T, tid) + ((s.cost && tid < T) ? of0[tid] : 0.0), 0.0};
+    double v[2] = {traj_obj_partial(x, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr) + ((s.cost && tid < T) ? of0[tid] : 0.0), 0.0};
     for (int e = tid; e < m_nl; e += SCO_BLOCK) {
       const RowRef q = row_ref(e, L);
       v[1] += row_viol(q, gs[e] - row_rhs(rc, q));
@@ -855,7 +861,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   const int H = s.H, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
   const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, ds, O, s.point,
                   s.qQ + (size_t)b * O * ds * ds, s.qa + (size_t)b * O * ds, s.qc + (size_t)b * O,
-                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par};
+                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step};
   double *hkey = s.hkey + (size_t)b * NB * H * ds, *hval = s.hval + (size_t)b * NB * H * RM;
   int *hn = s.hn + (size_t)b * NB;
   for (int t = tid; t < NB; t += SCO_BLOCK)
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   // model violation uses the FULL Jacobian (prob.py:627-628), new violation f at the new point (prob.py:575-577)
   // v: quadratic objective, model violation, new violation, objective MODELS at the new point (prob.py:625-626),
   //    objective terms at the new point (prob.py:571-573), max violation at the saved point
-  double v[6] = {traj_obj_partial(xq, d, T, tid), 0.0, 0.0, 0.0, 0.0, 0.0};
+  double v[6] = {traj_obj_partial(xq, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr), 0.0, 0.0, 0.0, 0.0, 0.0};
   if (s.cost) {
     const double *oH = s.oH + (size_t)b * T * d * d, *oA = s.oA + (size_t)b * T * d, *ob = s.ob + (size_t)b * T;
     for (int t = tid; t < T; t += SCO_BLOCK) {
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
       double f;
       if (ev_hit[t] >= 0) f = hval[((size_t)t * H + ev_hit[t]) * RM + (RM - 1)];
       else {
-        f = obj_value(ObjCtx{s.cost, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b]}, rc, th, -1, 0.0, -1, 0.0);
+        f = obj_value(ObjCtx{s.cost, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b]}, rc, t, th, -1, 0.0, -1, 0.0);
         if (p.memo && hn[t] < H) hval[((size_t)t * H + hn[t]) * RM + (RM - 1)] = f;
       }
       v[4] += f;
@@ -1016,12 +1022,12 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *
   const double *obs = s.obstacles + (size_t)b * O * 3;
   const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, s.ds, O, s.point,
                   s.qQ + (size_t)b * O * s.ds * s.ds, s.qa + (size_t)b * O * s.ds, s.qc + (size_t)b * O,
-                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par};
+                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step};
   const RowLay L{T, s.NBt, R, s.Req};
-  double v[3] = {traj_obj_partial(x, d, T, tid), 0.0, 0.0};
+  double v[3] = {traj_obj_partial(x, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr), 0.0, 0.0};
   if (s.cost)
     for (int t = tid; t < T; t += SCO_BLOCK)
-      v[0] += obj_value(ObjCtx{s.cost, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b]}, rc, x + t * d, -1, 0.0, -1, 0.0);
+      v[0] += obj_value(ObjCtx{s.cost, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b]}, rc, t, x + t * d, -1, 0.0, -1, 0.0);
   for (int e = tid; e < s.m_nl; e += SCO_BLOCK) {
     const RowRef q = row_ref(e, L);
     const double g = row_viol(q, row_value(rc, q, x + q.t * d, -1, 0.0) - row_rhs(rc, q));
@@ -1251,6 +1257,7 @@ extern "C" int sco_sqp_destroy(sco_sqp *h) {
   if (h->qp1) sco_qp_destroy(h->qp1);
   for (void *p : h->allocs) (void)hipFree(p);
   for (void *p : h->prog_buf) if (p) (void)hipFree(p);
+  if (h->objw_buf) (void)hipFree(h->objw_buf);
   for (auto e : h->events) (void)hipEventDestroy(e);
   for (auto &ge : h->gevents) for (auto e : ge) (void)hipEventDestroy(e);
   for (auto e : h->done) (void)hipEventDestroy(e);
@@ -1355,8 +1362,8 @@ extern "C" int sco_sqp_load_quadratic(sco_sqp *h, const double *Q, const double 
   return SCO_OK;
 }
 
-extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts, const double *consts,
-                                    int n_params, const double *params) {
+static int load_program_impl(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts, const double *consts,
+                             int n_params, const double *params, bool per_step) {
   if (!h || !words || !row_ptr || (n_consts > 0 && !consts) || (n_params > 0 && !params)) {
     sco_set_error("sco_sqp_load_program: null pointer"); return SCO_ERR_ARG;
   }
@@ -1395,12 +1402,12 @@ extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, c
   // the four buffers belong to the handle: a reload of the same sizes (new parameters per solve) reuses them, another
   // size frees the old ones first
   const size_t need[4] = {(size_t)2 * n_words * sizeof(int), ((size_t)R + 1) * sizeof(int), (size_t)std::max(n_consts, 1) * sizeof(double),
-                          std::max<size_t>((size_t)s.batch * n_params, 1) * sizeof(double)};
+                          std::max<size_t>((size_t)s.batch * (per_step ? s.T : 1) * n_params, 1) * sizeof(double)};
   // From here until every buffer is in place and filled the handle has NO program: a failed hipMalloc / hipMemcpy below
   // returns early, and the kernels of a later sco_sqp_solve must not read freed or half-written buffers (solve refuses
   // while prog_loaded is false).
   h->prog_loaded = false; h->solved = false;
-  s.pw = nullptr; s.pptr = nullptr; s.pconst = nullptr; s.ppar = nullptr; s.n_par = 0;
+  s.pw = nullptr; s.pptr = nullptr; s.pconst = nullptr; s.ppar = nullptr; s.n_par = 0; s.par_step = 0;
   for (int k = 0; k < 4; k++)
     if (h->prog_bytes[k] != need[k]) {
       if (h->prog_buf[k]) { (void)hipFree(h->prog_buf[k]); h->prog_buf[k] = nullptr; h->prog_bytes[k] = 0; }
@@ -1410,10 +1417,42 @@ extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, c
   SCO_HIP(hipMemcpy(h->prog_buf[0], words, (size_t)2 * n_words * sizeof(int), hipMemcpyHostToDevice));
   SCO_HIP(hipMemcpy(h->prog_buf[1], row_ptr, ((size_t)R + 1) * sizeof(int), hipMemcpyHostToDevice));
   if (n_consts) SCO_HIP(hipMemcpy(h->prog_buf[2], consts, (size_t)n_consts * sizeof(double), hipMemcpyHostToDevice));
-  if (n_params) SCO_HIP(hipMemcpy(h->prog_buf[3], params, (size_t)s.batch * n_params * sizeof(double), hipMemcpyHostToDevice));
+  if (n_params) SCO_HIP(hipMemcpy(h->prog_buf[3], params, (size_t)s.batch * (per_step ? s.T : 1) * n_params * sizeof(double), hipMemcpyHostToDevice));
   s.pw = (const int *)h->prog_buf[0]; s.pptr = (const int *)h->prog_buf[1];
   s.pconst = (const double *)h->prog_buf[2]; s.ppar = (const double *)h->prog_buf[3]; s.n_par = n_params;
+  s.par_step = per_step ? n_params : 0;
   h->prog_loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
+extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts, const double *consts,
+                                    int n_params, const double *params) {
+  return load_program_impl(h, n_words, words, row_ptr, n_consts, consts, n_params, params, false);
+}
+// r04: parameters per problem AND timestep, params[batch][horizon][n_params]: block t (the Variable of timesteps t .. t + span - 1)
+// and the objective term of timestep t are evaluated with params[problem][t] -- what a caller of the reference gets by closing
+// each timestep's Expr over its own data (moving obstacles, time-varying references; expr.py:22-41, prob.py:112-144)
+extern "C" int sco_sqp_load_program_steps(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts,
+                                          const double *consts, int n_params, const double *params) {
+  return load_program_impl(h, n_words, words, row_ptr, n_consts, consts, n_params, params, true);
+}
+
+// r04: weights of the smoothing objective, w[batch][dof] >= 0: sum_t sum_j w_j (theta[t+1][j] - theta[t][j])^2 -- the QuadExpr a
+// caller of the reference builds with a weighted difference matrix (prob.py:88-104, 348-367).  After sco_sqp_load; nullptr
+// restores the unweighted objective.
+extern "C" int sco_sqp_load_obj_weights(sco_sqp *h, const double *w) {
+  if (!h) { sco_set_error("sco_sqp_load_obj_weights: null pointer"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_load_obj_weights: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  SqpDev &s = h->d;
+  if (!w) { s.objw = nullptr; h->solved = false; return SCO_OK; }
+  for (size_t i = 0; i < (size_t)s.batch * s.d; i++)
+    if (!(w[i] >= 0.0) || !(w[i] < 1e30)) { sco_set_error("sco_sqp_load_obj_weights: weights must be finite and >= 0"); return SCO_ERR_ARG; }
+  SCO_ON_DEVICE(h->device);
+  s.objw = nullptr;
+  if (!h->objw_buf) SCO_HIP(hipMalloc(&h->objw_buf, (size_t)s.batch * s.d * sizeof(double)));
+  SCO_HIP(hipMemcpy(h->objw_buf, w, (size_t)s.batch * s.d * sizeof(double), hipMemcpyHostToDevice));
+  s.objw = (const double *)h->objw_buf;
+  h->solved = false;
   return SCO_OK;
 }
 

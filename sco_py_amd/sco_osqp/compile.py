@@ -191,16 +191,24 @@ def _compile(prob):
             want.append((ex.LEqExpr, prog.ineq_rows))
         if prog.eq_rows:
             want.append((ex.EqExpr, prog.eq_rows))
+        step_par = []                      # the parameter vector of every block (r04: they may differ per timestep)
         for bl in blocks:
             if len(bl) != len(want):
                 _no("a block does not hold the program's inequality and equality rows")
             for be, (cls, rows) in zip(bl, want):
                 e = be.expr.expr
-                if e.program is not prog or type(be.expr) is not cls or e.rows != list(rows) or not _same(e.params, e0.params):
-                    _no("blocks differ in program, rows or parameters (per-timestep parameters are not in the template)")
+                if e.program is not prog or type(be.expr) is not cls or e.rows != list(rows) or \
+                        np.shape(e.params) != np.shape(e0.params) or not _same(e.params, bl[0].expr.expr.params):
+                    _no("blocks differ in program or rows, or the rows of one block in their parameters")
+            step_par.append(np.asarray(bl[0].expr.expr.params, dtype=np.float64))
         n_eq = prog.n_eq
-        pr.update(K=1, O=prog.n_rows, obstacles=np.zeros((prog.n_rows, 3)), row_program=prog, row_params=e0.params.copy())
-        key_fam = ("program", id(prog))
+        per_step = any(not _same(q, step_par[0]) for q in step_par)
+        if per_step:                       # (T, n_params): block t reads row t; rows beyond the last block belong to objective terms
+            par = np.stack(step_par + [step_par[-1]] * (T - len(step_par)))
+        else:
+            par = step_par[0].copy()
+        pr.update(K=1, O=prog.n_rows, obstacles=np.zeros((prog.n_rows, 3)), row_program=prog, row_params=par)
+        key_fam = ("program", id(prog), per_step)
     else:
         _no("no device family for %r" % fam)
 
@@ -240,8 +248,14 @@ def _compile(prob):
     qe = qb.expr
     if not isinstance(qe, ex.QuadExpr) or not np.array_equal(cols_of(qb.var), np.arange(n_x)):
         _no("the quadratic objective is not a QuadExpr on the whole trajectory")
-    if not (_same(qe.Q, _smooth_Q(d, T)) and not np.any(qe.A) and not np.any(qe.b)):
-        _no("the quadratic objective is not sum_t |x[t+1] - x[t]|^2")
+    # sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 with weights w_j >= 0 read off the first super-diagonal (r04; all 1 = the
+    # reference examples' smoothing term)
+    Qm = np.asarray(qe.Q, dtype=np.float64)
+    ow = -0.5 * Qm[np.arange(d), d + np.arange(d)] if (T > 1 and Qm.shape == (n_x, n_x)) else np.ones(d)
+    if not (Qm.shape == (n_x, n_x) and np.all(ow >= 0) and np.allclose(Qm, _smooth_Q(d, T, ow), rtol=1e-12, atol=1e-14) and not np.any(qe.A) and not np.any(qe.b)):
+        _no("the quadratic objective is not sum_t sum_j w_j (x[t+1][j] - x[t][j])^2")
+    if not np.all(ow == 1.0):
+        pr["obj_w"] = ow
     nq = list(prob._nonquad_obj_exprs)
     if nq:
         if len(nq) != T:
@@ -258,8 +272,10 @@ def _compile(prob):
                 _no("per-timestep objective parameters")
             pr["cost_weight"] = o0.weight; pr["cost_target"] = o0.target.copy()
         elif o0.kind == "program_obj" and fam == "program" and span == 1:
-            if any(be.expr.program is not pr["row_program"] or not _same(be.expr.params, pr["row_params"]) for be in nq):
-                _no("the objective program is not the constraint rows' program")
+            rp = pr["row_params"]
+            if any(be.expr.program is not pr["row_program"] or not _same(be.expr.params, rp[t] if np.ndim(rp) == 2 else rp)
+                   for t, be in enumerate(nq)):
+                _no("the objective program is not the constraint rows' program (or its parameters are not its timestep's)")
         else:
             _no("this objective term does not go with the %s family" % fam)
     elif fam == "program" and pr["row_program"].objective:
@@ -347,7 +363,16 @@ def _compile(prob):
 _Q_CACHE = {}
 
 
-def _smooth_Q(d, T):
+def _smooth_Q(d, T, w=None):
+    """Q of sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 in the 0.5 x'Qx form of QuadExpr, entry by entry in the order a caller's
+    loop over (t, j) adds them (tests/trajopt_build.py); w None = all 1 (cached)."""
+    if w is not None and not np.all(np.asarray(w) == 1.0):
+        n = d * T
+        Q = np.zeros((n, n))
+        w2 = 2.0 * np.tile(np.asarray(w, dtype=np.float64), T - 1)
+        i = np.arange(n - d)
+        Q[i, i] += w2; Q[i + d, i + d] += w2; Q[i, i + d] -= w2; Q[i + d, i] -= w2
+        return Q
     if (d, T) not in _Q_CACHE:
         n = d * T
         Q = np.zeros((n, n))
@@ -388,6 +413,9 @@ def _stack(cps):
             a[k] = st(k)
     if p0.get("groups") is not None:
         a["groups"] = p0["groups"]
+    if any(c.pr.get("obj_w") is not None for c in cps):          # weights are values: weighted and plain problems share a batch
+        a["obj_w"] = np.stack([np.asarray(c.pr["obj_w"], dtype=np.float64) if c.pr.get("obj_w") is not None else np.ones(p0["d"])
+                               for c in cps])
     return a
 
 
@@ -416,7 +444,7 @@ def run_compiled(cps, params, qp_settings, device=0):
             target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
             cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),
             quad_Q=a.get("quad_Q"), quad_a=a.get("quad_a"), quad_c=a.get("quad_c"),
-            row_program=a.get("row_program"), row_params=a.get("row_params"))
+            row_program=a.get("row_program"), row_params=a.get("row_params"), obj_weights=a.get("obj_w"))
     if a.get("groups") is not None:
         tb.set_groups(a["groups"])
     t1 = time.perf_counter()

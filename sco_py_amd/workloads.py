@@ -421,9 +421,34 @@ def make_program_variant(i, variant, d=2, T=12, noise=0.03, groups=None, vel_lim
     return out
 
 
-def make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None,
-                 ee_cost_weight=None, point=False, quadratic=False, program=False, variant=None, n_eq=0):
-    """Seeded problem i of the batch.  reach=True: the goal pin
+def make_problem(i, obj_weights=False, per_step=False, **kw):
+    """Seeded problem i of the batch; see _make_problem for the families.  r04 (wider template):
+    obj_weights=True adds per-joint weights w_j in [0.4, 3] of the smoothing objective (``obj_w``; a QuadExpr built from a
+    weighted difference matrix, prob.py:88-104, 348-367); per_step=True (program family) gives every timestep its own
+    parameter vector (``row_params`` of shape (T, n_params): obstacles that drift and pulse along the horizon -- each
+    timestep's Expr closes over its own data, expr.py:22-41).  Both draw from their own generators: every other number of
+    the problem is what it is without them."""
+    out = _make_problem(i, **kw)
+    if obj_weights:
+        out["obj_w"] = np.random.default_rng(7000 + i).uniform(0.4, 3.0, size=out["d"])
+    if per_step:
+        if out.get("row_program") is None:
+            raise ValueError("per_step needs the program family")
+        par = np.asarray(out["row_params"], dtype=np.float64)
+        t = np.arange(out["T"], dtype=np.float64)[:, None]
+        out["row_params"] = par[None, :] + 0.04 * np.abs(par)[None, :] * np.sin(0.9 * t + np.arange(par.shape[0])[None, :])
+    return out
+
+
+def step_params(pr, t):
+    """Parameter vector of constraint block / objective term t of a program problem (shared or per timestep)."""
+    par = pr["row_params"]
+    return par[t] if np.ndim(par) == 2 else par
+
+
+def _make_problem(i, d=7, T=20, K=5, O=2, noise=0.05, reach=False, groups=None, vel_limit=None, joint_limit=None,
+                  ee_cost_weight=None, point=False, quadratic=False, program=False, variant=None, n_eq=0):
+    """reach=True: the goal pin
     theta[T-1] = goal is replaced by the non-linear equality ee(theta[T-1]) = ee(goal)
     (EqExpr on an Expr: the abs-penalty path of prob.py:280-315); same random draws."""
     if program:
@@ -492,6 +517,8 @@ def make_batch(B, first=0, **kw):
         extra["cost_target"] = np.stack([p["cost_target"] for p in probs])
     if p0.get("jlo") is not None:
         extra["jlo"] = np.stack([p["jlo"] for p in probs]); extra["jhi"] = np.stack([p["jhi"] for p in probs])
+    if p0.get("obj_w") is not None:
+        extra["obj_w"] = np.stack([p["obj_w"] for p in probs])
     return dict(
         d=p0["d"], T=p0["T"], K=p0["K"], O=p0["O"], B=B, **extra,
         x0=np.stack([p["x0"] for p in probs]),

@@ -8,13 +8,19 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 import os as _os
 ONLY = _os.environ.get("FAMILIES")
 for name, kw in (("circles", {}), ("reach", dict(reach=True)), ("vel", dict(vel_limit=0.3)), ("jl", dict(joint_limit=0.2)),
-                 ("vel+jl", dict(vel_limit=0.3, joint_limit=0.2)), ("reach+vel+jl", dict(reach=True, vel_limit=0.3, joint_limit=0.2))):
+                 ("vel+jl", dict(vel_limit=0.3, joint_limit=0.2)), ("reach+vel+jl", dict(reach=True, vel_limit=0.3, joint_limit=0.2)),
+                 # r04, the wider template: weighted smoothing objective (any family), program parameters per timestep
+                 ("circles+weights", dict(obj_weights=True)), ("vel+weights", dict(vel_limit=0.3, obj_weights=True)),
+                 ("program d=2 T=20", dict(d=2, T=20, K=1, program=True)), ("program+steps", dict(d=2, T=20, K=1, program=True, per_step=True)),
+                 ("sweep+steps (span 2)", dict(d=2, T=20, K=1, program=True, variant="sweep", per_step=True)),
+                 ("attract+steps+weights", dict(d=2, T=20, K=1, program=True, variant="attract", per_step=True, obj_weights=True))):
     if ONLY and name not in ONLY.split(','):
         continue
     arrays, _ = af.make_batch(B, **kw)
     res = sb.solve_batch(arrays)
     t = time.time(); res = sb.solve_batch(arrays); dt = time.time() - t
     tm = res.timing
-    print("%-14s wall %.2fs sco_it/s %.0f success %.3f admm iters/problem %.0f -> %.2f us per problem-iteration (admm %.0f ms, setup %.0f ms)" % (
-        name, dt, res.sqp_iters.sum() / dt, res.success.mean(), res.admm_iters.mean(),
+    tier = "wavefront %d + other %d launches" % (tm.get("wv_launches", 0), tm.get("other_launches", 0))
+    print("%-24s [%s] wall %.2fs sco_it/s %.0f success %.3f admm iters/problem %.0f -> %.2f us per problem-iteration (admm %.0f ms, setup %.0f ms)" % (
+        name, tier, dt, res.sqp_iters.sum() / dt, res.success.mean(), res.admm_iters.mean(),
         1e3 * tm["admm_ms"] / (res.admm_iters.sum() / 256.0), tm["admm_ms"], tm["qp_setup_ms"]), flush=True)

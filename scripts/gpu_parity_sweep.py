@@ -18,6 +18,8 @@ for tok in sys.argv[4:]:                                         # reach, vel, g
     if tok.startswith("prog:"):                                                    # prog:sweep | prog:dynamics | prog:curve | prog:attract
         v = tok.split(":")[1]
         KW.update(program=True, variant=v, d=3 if v in ("dynamics", "curve") else 2, T=10, K=1)
+    if tok == "objw": KW["obj_weights"] = True                                     # r04: weighted smoothing objective
+    if tok == "steps": KW["per_step"] = True                                       # r04: program parameters per timestep
     if tok == "ajac": AJ = True
 AJ = "ajac" in sys.argv[4:]
 

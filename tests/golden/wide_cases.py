@@ -1,0 +1,15 @@
+"""Cases of tests/golden/trajopt_wide.npz (r04, the wider device template): (prefix, make_problem kwargs, problem index, analytic_jac).
+w*: per-joint weights of the smoothing objective (a QuadExpr from a weighted difference matrix); ps*: program rows whose
+parameters differ from timestep to timestep (every timestep's Expr closes over its own data)."""
+ARM = dict(d=3, T=6, K=2, O=2)
+P = dict(K=1, program=True)
+CASES = [("w%d_" % i, dict(ARM, obj_weights=True), i, False) for i in range(2)] + \
+        [("wr_", dict(ARM, obj_weights=True, reach=True), 1, False),
+         ("wj_", dict(ARM, obj_weights=True, joint_limit=0.3, vel_limit=0.6), 0, False),
+         ("wc_", dict(ARM, obj_weights=True, ee_cost_weight=1.0), 2, False),
+         ("wp_", dict(d=2, T=8, K=1, O=3, point=True, obj_weights=True), 1, True)] + \
+        [("ps%d_" % i, dict(P, d=2, T=8, per_step=True), i, False) for i in range(2)] + \
+        [("pssw_", dict(P, d=2, T=8, variant="sweep", per_step=True), 0, False),
+         ("psdy_", dict(P, d=3, T=8, variant="dynamics", per_step=True), 1, True),
+         ("psat_", dict(P, d=2, T=8, variant="attract", per_step=True), 0, False),
+         ("psw_", dict(P, d=2, T=8, per_step=True, obj_weights=True, groups="split"), 2, False)]

@@ -23,6 +23,9 @@ FAMILIES = [
     dict(d=2, T=8, O=3, quadratic=True), dict(d=2, T=8, O=3, quadratic=True, n_eq=1), dict(d=2, T=8, program=True),
     dict(d=3, T=6, K=1, program=True, variant="dynamics"), dict(d=2, T=6, K=1, program=True, variant="sweep", groups="split"),
     dict(d=2, T=6, K=1, program=True, variant="attract"), dict(d=3, T=6, K=1, program=True, variant="curve"), dict(),
+    # r04, the wider template: weighted smoothing objective; program parameters per timestep
+    dict(SMALL, obj_weights=True), dict(SMALL, obj_weights=True, reach=True, vel_limit=0.6), dict(d=2, T=8, program=True, per_step=True),
+    dict(d=2, T=6, K=1, program=True, variant="sweep", per_step=True), dict(d=2, T=6, K=1, program=True, variant="attract", per_step=True, obj_weights=True),
 ]
 
 
@@ -42,6 +45,9 @@ def test_compile_prob_reads_the_problem_record_back_out_of_the_object_api(kw):
             assert cp.pr[k] == v
         elif isinstance(v, bool) or v is None:
             assert bool(cp.pr.get(k)) == bool(v), k
+        elif k == "row_params" and np.ndim(v) == 2:
+            nb = pr["T"] - pr["row_program"].span + 1          # rows of the blocks; the rest belongs to objective terms (or to nobody)
+            assert np.shape(cp.pr[k]) == np.shape(v) and np.array_equal(np.asarray(cp.pr[k])[:nb], np.asarray(v)[:nb]), k
         else:
             assert np.array_equal(np.asarray(cp.pr[k]), np.asarray(v)), k
     assert cp.key[6] == 2                              # prox_count: the trajectory Variable + one block Variable per atom

@@ -581,3 +581,56 @@ def test_flat_oracle_reproduces_reference_for_quadratic_rows_with_an_equality(ca
     assert out.success == bool(g[prefix + "success"])
     assert np.abs(out.x - g[prefix + "x"]).max() < 2e-7
     assert abs(out.max_violation - float(g[prefix + "max_violation"])) < 1e-7
+
+
+def _wide_cases():
+    import sys
+    sys.path.insert(0, GOLD)
+    from wide_cases import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("case", _wide_cases(), ids=lambda c: c[0])
+def test_flat_oracle_reproduces_reference_for_the_wider_template(case):
+    """r04: per-joint weights of the smoothing objective -- a QuadExpr built from a weighted difference
+    matrix (prob.py:88-104, 348-367), alone and with reach / limits / objective terms / the point robot -- and program rows
+    whose parameters change from timestep to timestep (each timestep's Expr closes over its own data, expr.py:22-41:
+    drifting, pulsing obstacles; span 2, equality rows and objective programs included).  Runs of the reference's own
+    modules (tests/golden/make_golden_wide.py): every QP it assembled, statuses, iteration counts, answer."""
+    prefix, kw, i, aj = case
+    g = np.load(os.path.join(GOLD, "trajopt_wide.npz"))
+    pr = af.make_problem(i, **kw)
+    out = sr.penalty_sqp(sr.trajopt_flat(pr, analytic_jac=aj), record_qps=True)
+    prog = pr.get("row_program")
+    loose = bool(pr.get("reach")) or pr.get("cost_weight") is not None or (prog is not None and (prog.n_eq > 0 or prog.objective))
+    _compare_sequence(ct.load_golden_qps(g, prefix), out.qps, prefix, xtol=1e-7 if loose else 1e-9, qptol=1e-7 if loose else 1e-9)
+    assert out.success == bool(g[prefix + "success"])
+    assert np.abs(out.x - g[prefix + "x"]).max() < (2e-7 if loose else 1e-9)
+    assert abs(out.max_violation - float(g[prefix + "max_violation"])) < 1e-9
+
+
+def test_the_wider_template_is_exercised_by_its_goldens():
+    """The weights differ between joints and the per-timestep parameters between timesteps (else the goldens would pin nothing)."""
+    for prefix, kw, i, aj in _wide_cases():
+        pr = af.make_problem(i, **kw)
+        if kw.get("obj_weights"):
+            assert np.ptp(pr["obj_w"]) > 0.05
+        if kw.get("per_step"):
+            assert pr["row_params"].shape == (kw["T"], pr["row_program"].n_params) and np.abs(np.diff(pr["row_params"], axis=0)).max() > 1e-3
+            plain = af.make_problem(i, **dict(kw, per_step=False))
+            assert np.array_equal(plain["x0"], pr["x0"]) and np.array_equal(plain["row_params"].shape, (pr["row_program"].n_params,))
+
+
+def test_mirror_api_reproduces_reference_for_the_wider_template(oracle_qp_backend):
+    g = np.load(os.path.join(GOLD, "trajopt_wide.npz"))
+    cases = _wide_cases()
+    for prefix, kw, i, aj in [cases[0], cases[3], cases[6], cases[8], cases[11]]:
+        del oracle_qp_backend[:]
+        mods = ct.mirror_mods()
+        prob, traj, _, _ = tb.build_prob(mods, af.make_problem(i, **kw), analytic_jac=aj)
+        ok = mods.Solver().solve(prob, method="penalty_sqp")
+        gold = ct.load_golden_qps(g, prefix)
+        assert [a["iters"] for a in gold] == [r["iters"] for r in oracle_qp_backend]
+        assert [a["status"] for a in gold] == [r["status"] for r in oracle_qp_backend]
+        assert ok == bool(g[prefix + "success"])
+        assert np.abs(traj.get_value().ravel() - g[prefix + "x"]).max() < 2e-7

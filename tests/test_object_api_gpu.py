@@ -223,3 +223,19 @@ def test_solve_many_buckets_by_structure_and_keeps_the_rest_on_the_host(gpu):
         assert oks[j] == ok1 and np.array_equal(built[k][1].get_value(), traj1.get_value())
         assert sum(e.host_evals for e in _device_exprs(p)) == 0
         k += 1
+
+
+def test_wider_template_goldens_through_plain_solver_solve(gpu):
+    """r04: a QuadExpr with per-joint weights and ProgramExpr objects that close over per-timestep parameters are recognised
+    by compile_prob; the reference's runs of these cases (trajopt_wide.npz) through plain Solver().solve(prob), no Python f."""
+    from wide_cases import CASES
+    g = np.load(os.path.join(GOLD, "trajopt_wide.npz"))
+    for prefix, kw, i, aj in CASES:
+        pr = af.make_problem(i, **kw)
+        ok, prob, traj, _, solver = _solve(pr, analytic=aj)
+        prog = pr.get("row_program")
+        exact = not (kw.get("reach") or kw.get("ee_cost_weight") or (prog is not None and (prog.n_eq or prog.objective)))
+        _against_golden(g, prefix, ok, traj, solver, iters=exact)
+        from sco_py_amd.sco_osqp import compile as cc
+        rec = cc.compile_prob(tb.build_prob(ct.mirror_mods(), pr, analytic_jac=aj, device_exprs=True)[0]).pr
+        assert (rec.get("obj_w") is not None) == bool(kw.get("obj_weights")) and (np.ndim(rec.get("row_params")) == 2) == bool(kw.get("per_step"))

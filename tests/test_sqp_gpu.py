@@ -1172,3 +1172,73 @@ def test_program_reload_with_another_size_and_the_n_eq_rows_check(gpu):
     assert np.array_equal(outs[0].x, outs[1].x) and np.array_equal(first.x, again.x) and not np.array_equal(first.x, outs[0].x)
     with pytest.raises(ValueError):
         sb.TrajOptBatch(B, d, T, 1, 4, program=arrays["row_program"], n_eq_rows=2)
+
+
+# ---- r04: the wider device template: weighted smoothing objective, per-timestep program parameters ----
+@pytest.mark.parametrize("kw,analytic", [
+    (dict(d=3, T=6, K=2, O=2, obj_weights=True), False), (dict(d=3, T=6, K=2, O=2, obj_weights=True, reach=True, vel_limit=0.6), False),
+    (dict(d=3, T=6, K=2, O=2, obj_weights=True, ee_cost_weight=1.0), False), (dict(d=2, T=8, K=1, O=3, point=True, obj_weights=True, joint_limit=0.2), True),
+    (dict(d=2, T=8, K=1, program=True, per_step=True), False), (dict(d=2, T=8, K=1, program=True, variant="sweep", per_step=True), True),
+    (dict(d=3, T=8, K=1, program=True, variant="dynamics", per_step=True), False),
+    (dict(d=2, T=8, K=1, program=True, variant="attract", per_step=True, obj_weights=True), False),
+    (dict(obj_weights=True), False)],
+    ids=["weights", "weights-reach-vel", "weights-objterm", "weights-point-jl-analytic", "steps", "steps-sweep-analytic", "steps-dynamics",
+         "steps-attract-weights", "weights-7x20"])
+def test_wider_template_matches_the_oracle(gpu, kw, analytic):
+    """sco_sqp_load_obj_weights: sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 with per-problem, per-joint weights (objective value, P
+    of every QP, the degree-2 model of an objective term on top of it); sco_sqp_load_program_steps: block t and the objective
+    term of timestep t evaluated with params[problem][t] (values, finite-difference and forward-mode Jacobians, numeric
+    Hessians).  Every decision, QP status, iteration count, merit and the answer against the oracle, which reproduces the
+    reference's own runs of these cases (tests/test_golden.py, trajopt_wide.npz)."""
+    n = 4 if kw.get("d", 7) == 7 else 8
+    arrays, probs = af.make_batch(n, **kw)
+    res = sb.solve_batch(arrays, analytic_jac=analytic)
+    _compare(res, probs, range(n), analytic=analytic)
+    # the extension is live: the same problems without it end elsewhere
+    plain = {k: v for k, v in arrays.items() if k != "obj_w"}
+    if kw.get("per_step"):
+        plain["row_params"] = arrays["row_params"][:, 0, :].copy()
+    res0 = sb.solve_batch(plain, analytic_jac=analytic)
+    assert np.abs(res0.x - res.x).max() > 1e-4
+
+
+def test_wider_template_matches_reference_golden_runs(gpu):
+    """The same against runs of the REFERENCE's own modules (tests/golden/make_golden_wide.py -> trajopt_wide.npz):
+    trajectory to 1e-6, success flag, status of every QP, iteration counts where no equality row / objective term is in play."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from wide_cases import CASES
+    g = np.load(os.path.join(GOLD, "trajopt_wide.npz"))
+    for prefix, kw, i, aj in CASES:
+        arrays, probs = af.make_batch(1, first=i, **kw)
+        res = sb.solve_batch(arrays, analytic_jac=aj)
+        assert np.abs(res.x[0] - g[prefix + "x"]).max() < TOL, (prefix, np.abs(res.x[0] - g[prefix + "x"]).max())
+        assert bool(res.success[0]) == bool(g[prefix + "success"]), prefix
+        nq = int(g[prefix + "n_qp"])
+        assert [int(v) for v in res.trace[0][:, 6]] == [int(g["%sqp%d_status" % (prefix, k)]) for k in range(nq)], prefix
+        prog = arrays.get("row_program")
+        if not (kw.get("reach") or kw.get("ee_cost_weight") or (prog is not None and (prog.n_eq or prog.objective))):
+            assert [int(v) for v in res.trace[0][:, 7]] == [int(g["%sqp%d_iters" % (prefix, k)]) for k in range(nq)], prefix
+
+
+def test_wider_template_reloads_and_argument_checks(gpu):
+    """A handle switches between weighted and plain, shared and per-timestep parameters from one load to the next (results =
+    fresh handles'); shapes and values are checked before anything is uploaded."""
+    kw = dict(d=2, T=8, K=1, program=True)
+    a_plain, _ = af.make_batch(4, **kw)
+    a_wide, _ = af.make_batch(4, per_step=True, obj_weights=True, **kw)
+    ref_plain, ref_wide = sb.solve_batch(a_plain), sb.solve_batch(a_wide)
+    with sb.TrajOptBatch(4, 2, 8, 1, a_plain["O"], program=a_plain["row_program"]) as tb:
+        for a, ref in ((a_wide, ref_wide), (a_plain, ref_plain), (a_wide, ref_wide)):
+            tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
+                    row_program=a["row_program"], row_params=a["row_params"], obj_weights=a.get("obj_w"))
+            tb.solve()
+            r = tb.fetch()
+            assert np.array_equal(r.x, ref.x) and np.array_equal(r.admm_iters, ref.admm_iters)
+        a = a_wide
+        with pytest.raises(ValueError):
+            tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
+                    row_program=a["row_program"], row_params=a["row_params"][:, :5, :])
+        with pytest.raises(_lib.ScoHipError):
+            tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
+                    row_program=a["row_program"], row_params=a["row_params"], obj_weights=-np.ones((4, 2)))

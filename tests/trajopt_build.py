@@ -30,10 +30,11 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
     prob.add_var(traj)
 
     Q = np.zeros((n_x, n_x))
+    ow = pr["obj_w"] if pr.get("obj_w") is not None else np.ones(d)          # r04: weighted smoothing objective
     for t in range(T - 1):
         for j in range(d):
             a, b = t * d + j, (t + 1) * d + j
-            Q[a, a] += 2.0; Q[b, b] += 2.0; Q[a, b] -= 2.0; Q[b, a] -= 2.0
+            Q[a, a] += 2.0 * ow[j]; Q[b, b] += 2.0 * ow[j]; Q[a, b] -= 2.0 * ow[j]; Q[b, a] -= 2.0 * ow[j]
     prob.add_obj_expr(mods.BoundExpr(mods.QuadExpr(Q, np.zeros((1, n_x)), np.zeros((1, 1))), traj))
 
     reach = bool(pr.get("reach"))
@@ -75,14 +76,14 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
                 if not rows:
                     continue
 
-                def f(x, pr=pr, rows=rows):
-                    return pr["row_program"].evaluate(x.ravel(), pr["row_params"], rows).reshape(-1, 1)
+                def f(x, pr=pr, rows=rows, t=t):
+                    return pr["row_program"].evaluate(x.ravel(), af.step_params(pr, t), rows).reshape(-1, 1)
 
-                def grad(x, pr=pr, rows=rows):
-                    return pr["row_program"].jacobian(x.ravel(), pr["row_params"], rows)
+                def grad(x, pr=pr, rows=rows, t=t):
+                    return pr["row_program"].jacobian(x.ravel(), af.step_params(pr, t), rows)
                 e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
                 if dx is not None:
-                    e = dx.ProgramExpr(prog, pr["row_params"], rows=rows, analytic=analytic_jac)
+                    e = dx.ProgramExpr(prog, af.step_params(pr, t), rows=rows, analytic=analytic_jac)
                 prob.add_cnt_expr(mods.BoundExpr(cls(e, np.zeros((len(rows), 1))), sv), gids)
     if pr.get("quad_n_eq"):
         # quadratic rows with equality rows (r03): per timestep one LEqExpr and one EqExpr (val 0) on the same Variable
@@ -106,9 +107,9 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
         sv = mods.Variable(atoms[t * d:(t + 1) * d, :], pr["x0"][t * d:(t + 1) * d].reshape(d, 1).copy())
         step_vars.append(sv)
 
-        def f(x, pr=pr):
+        def f(x, pr=pr, t=t):
             if pr.get("row_program") is not None:    # program family: the compiled rows as a NumPy callable
-                return pr["row_program"].evaluate(x.ravel(), pr["row_params"]).reshape(-1, 1)
+                return pr["row_program"].evaluate(x.ravel(), af.step_params(pr, t)).reshape(-1, 1)
             if pr.get("quad_Q") is not None:    # quadratic-row family
                 return af.quad_rows(x.ravel(), pr["quad_Q"], pr["quad_a"], pr["quad_c"]).reshape(-1, 1)
             if pr.get("point"):                 # point-robot family: distance of the point itself to the discs
@@ -118,9 +119,9 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
 
         grad = None
         if analytic_jac:
-            def grad(x, pr=pr):
+            def grad(x, pr=pr, t=t):
                 if pr.get("row_program") is not None:       # forward-mode derivative of the compiled rows
-                    return pr["row_program"].jacobian(x.ravel(), pr["row_params"])
+                    return pr["row_program"].jacobian(x.ravel(), af.step_params(pr, t))
                 if pr.get("quad_Q") is not None:
                     return af.quad_rows_jac(x.ravel(), pr["quad_Q"], pr["quad_a"], pr["quad_c"])
                 if pr.get("point"):
@@ -129,7 +130,7 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
                                        pr["obstacles"])
         e = mods.Expr(f, grad) if analytic_jac else mods.Expr(f)
         if dx is not None:
-            e = (dx.ProgramExpr(pr["row_program"], pr["row_params"], analytic=analytic_jac) if pr.get("row_program") is not None else
+            e = (dx.ProgramExpr(pr["row_program"], af.step_params(pr, t), analytic=analytic_jac) if pr.get("row_program") is not None else
                  dx.QuadRowsExpr(pr["quad_Q"], pr["quad_a"], pr["quad_c"], analytic=analytic_jac) if pr.get("quad_Q") is not None else
                  dx.PointCirclesExpr(pr["obstacles"], analytic=analytic_jac) if pr.get("point") else
                  dx.ArmCirclesExpr(pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"], analytic=analytic_jac))
@@ -138,9 +139,9 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
     if prog is not None and prog.objective:
         # the program family's objective term: one plain Expr per timestep Variable (prob.py:88-104), degree-2 convexified
         for t in range(T):
-            def fo(x, pr=pr):
-                return np.array([[pr["row_program"].evaluate(x.ravel(), pr["row_params"], rows=[pr["row_program"].n_rows])[0]]])
-            prob.add_obj_expr(mods.BoundExpr(dx.ProgramObjExpr(prog, pr["row_params"]) if dx is not None else mods.Expr(fo), step_vars[t]))
+            def fo(x, pr=pr, t=t):
+                return np.array([[pr["row_program"].evaluate(x.ravel(), af.step_params(pr, t), rows=[pr["row_program"].n_rows])[0]]])
+            prob.add_obj_expr(mods.BoundExpr(dx.ProgramObjExpr(prog, af.step_params(pr, t)) if dx is not None else mods.Expr(fo), step_vars[t]))
     if pr.get("cost_weight") is not None:
         # non-quadratic objective terms, one Expr per timestep Variable: numeric gradient and Hessian, degree-2
         # convexification with the eigenvalue shift (expr.py:102-156; prob.py:88-104)
