@@ -202,7 +202,7 @@ void sco_sqp_default_params(sco_sqp_params *p);
                                   (EqExpr -> abs penalty, prob.py:280-315).  Flags as for SCO_FAM_POINT_CIRCLES */
 #define SCO_FAM_STATE_PROGRAM 5 /* closed-form rows given as small postfix programs over the state of a constraint block and a
                                   per-problem parameter vector (sco_sqp_load_program) -- what the reference's Expr(f) is for
-                                  any f one can write down with + - * / sin cos sqrt exp.  A block is `span` (1 or 2)
+                                  any f one can write down with + - * / sin cos sqrt exp.  A block is `span` (1 .. 4)
                                   consecutive timesteps: block t binds the rows to the Variable (theta[t], .., theta[t+span-1])
                                   (the reference binds any Expr to any Variable, expr.py:413-437, prob.py:112-144; swept-volume
                                   and dynamics constraints live on two timesteps), state = their concatenation, span * dof <= 32,
@@ -269,7 +269,7 @@ typedef struct sco_trajopt_desc {
                         find_closest_feasible_point adds one (x_i - x0_i)^2 per Variable
                         (prob.py:381-404); 0 is read as 1.  With span > 1 this is the count of an atom that ONE
                         block Variable covers; an atom covered by k blocks counts prox_count - 1 + k */
-  int span;          /* SCO_FAM_STATE_PROGRAM: timesteps per constraint block, 1 or 2 (0 is read as 1) */
+  int span;          /* SCO_FAM_STATE_PROGRAM: timesteps per constraint block, 1 .. 4 (0 is read as 1; r04: 3 and 4) */
   int n_eq_rows;     /* SCO_FAM_STATE_PROGRAM and SCO_FAM_STATE_QUADRATIC: how many of the n_obstacles rows of a block (the last
                         ones) are equalities */
 } sco_trajopt_desc;

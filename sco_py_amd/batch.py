@@ -46,7 +46,7 @@ class TrajOptBatch(object):
     per-problem coefficients (``load(..., quad_Q=, quad_a=, quad_c=)``); ``program=True``: SCO_FAM_STATE_PROGRAM, rows
     given as closed-form expressions over the state and a per-problem parameter vector, compiled by
     ``sco_py_amd.rowexpr.compile_rows`` (``load(..., row_program=, row_params=)``); the program says how many timesteps
-    a constraint block spans (``span`` 1 or 2: block t binds its rows to (theta[t], .., theta[t+span-1])), how many of a
+    a constraint block spans (``span`` 1 .. 4: block t binds its rows to (theta[t], .., theta[t+span-1])), how many of a
     block's rows are equalities (``n_eq``) and whether it carries a non-quadratic objective term per timestep -- pass it
     to the constructor as ``program=prog``; ``analytic_jac=True`` differentiates program rows in forward mode)
     solved per problem exactly like ``Solver().solve(prob, method="penalty_sqp")``.

@@ -1074,7 +1074,7 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
       (statefam && (desc->n_points != 1 || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
       (fam == SCO_FAM_STATE_QUADRATIC && desc->dof > OBJ_DMAX) ||
       // blocks of `span` timesteps, equality rows and objective programs: the state families' extensions (r03)
-      desc->span < 0 || desc->span > 2 || desc->n_eq_rows < 0 || desc->n_eq_rows > desc->n_obstacles ||
+      desc->span < 0 || desc->span > 4 || desc->n_eq_rows < 0 || desc->n_eq_rows > desc->n_obstacles ||
       (span > 1 && fam != SCO_FAM_STATE_PROGRAM) || (desc->n_eq_rows > 0 && !statefam) ||
       (fam == SCO_FAM_STATE_PROGRAM && (span * desc->dof > SCO_STATE_MAX || span >= desc->horizon)) ||
       ((desc->family & SCO_FAM_FLAG_OBJ_PROGRAM) && (fam != SCO_FAM_STATE_PROGRAM || span != 1 || desc->dof > OBJ_DMAX))) {

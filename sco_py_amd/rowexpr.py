@@ -169,8 +169,8 @@ def compile_rows(rows, eq_rows=(), objective=None, span=1):
     """List of Node expressions -> Program.  ``rows``: inequality rows g_r(x, p) <= 0; ``eq_rows``: equality rows
     g_r(x, p) = 0 (they follow the inequalities in a block); ``objective``: a non-quadratic objective term f(x, p) of ONE
     timestep (span 1 only); ``span``: timesteps per constraint block (X(i) addresses i < span * dof)."""
-    if span not in (1, 2) or (objective is not None and span != 1):
-        raise ValueError("span is 1 or 2; an objective term needs span 1")
+    if span not in (1, 2, 3, 4) or (objective is not None and span != 1):
+        raise ValueError("span is 1 .. 4; an objective term needs span 1")
     rows, eq_rows = list(rows), list(eq_rows)          # (generators are welcome: they are walked once, here)
     words, row_ptr, consts = [], [0], []
     for r in rows + eq_rows + ([objective] if objective is not None else []):

@@ -280,7 +280,11 @@ def variant_program(variant, d):
     "curve"     span 1, dof = 3: the third coordinate follows z = p[8] sin(p[9] x) (an equality row on ONE timestep) and the
                 two rippled discs of the corridor program keep out;
     "attract"   span 1, dof >= 2: the corridor rows plus a NON-QUADRATIC OBJECTIVE TERM per timestep, a Gaussian well
-                -p[13] exp(-|x - g|^2 / 0.18) around g = p[14:16] (non-convex away from g: the eigenvalue shift acts)."""
+                -p[13] exp(-|x - g|^2 / 0.18) around g = p[14:16] (non-convex away from g: the eigenvalue shift acts);
+    "accel"     (r04) span 3, dof >= 2: the squared second difference |x_t - 2 x_t+1 + x_t+2|^2 <= p[6]^2 (1 + p[7] y_mid)^2 -- an
+                acceleration limit that tightens with height -- and two keep-out discs on the MIDDLE timestep;
+    "jerk"      (r04) span 4, dof >= 2: the squared third difference |x_t+3 - 3 x_t+2 + 3 x_t+1 - x_t|^2 <= p[6]^2, a keep-out disc
+                on the centroid of the four points whose radius grows with the squared chord |x_t+3 - x_t|^2, one on x_t+1."""
     key = (variant, d)
     if key in _PROGRAMS:
         return _PROGRAMS[key]
@@ -294,6 +298,22 @@ def variant_program(variant, d):
             rows.append(P(3 * o + 2) * (1.0 + P(6) * step2) - sqrt(dx ** 2 + dy ** 2 + 1e-12))
         rows.append(step2 - (P(7) + P(8) * my) ** 2)                  # shorter steps where the midpoint is low
         prog = compile_rows(rows, span=2)
+    elif variant == "accel":
+        rows = []
+        for o in range(2):
+            dx, dy = X(d) - P(3 * o), X(d + 1) - P(3 * o + 1)
+            rows.append(P(3 * o + 2) - sqrt(dx ** 2 + dy ** 2 + 1e-12))
+        ax, ay = X(0) - 2.0 * X(d) + X(2 * d), X(1) - 2.0 * X(d + 1) + X(2 * d + 1)
+        rows.append(ax ** 2 + ay ** 2 - (P(6) * (1.0 + P(7) * X(d + 1))) ** 2)
+        prog = compile_rows(rows, span=3)
+    elif variant == "jerk":
+        jx, jy = X(3 * d) - 3.0 * X(2 * d) + 3.0 * X(d) - X(0), X(3 * d + 1) - 3.0 * X(2 * d + 1) + 3.0 * X(d + 1) - X(1)
+        cx, cy = 0.25 * (X(0) + X(d) + X(2 * d) + X(3 * d)), 0.25 * (X(1) + X(d + 1) + X(2 * d + 1) + X(3 * d + 1))
+        chord2 = (X(3 * d) - X(0)) ** 2 + (X(3 * d + 1) - X(1)) ** 2
+        rows = [P(2) * (1.0 + P(7) * chord2) - sqrt((cx - P(0)) ** 2 + (cy - P(1)) ** 2 + 1e-12),
+                P(5) - sqrt((X(d) - P(3)) ** 2 + (X(d + 1) - P(4)) ** 2 + 1e-12),
+                jx ** 2 + jy ** 2 - P(6) ** 2]
+        prog = compile_rows(rows, span=4)
     elif variant == "dynamics":
         assert d == 3
         ineq = [P(3) - sqrt((X(0) - P(1)) ** 2 + (X(1) - P(2)) ** 2 + 1e-12),            # keep-out disc on x_t
@@ -364,7 +384,9 @@ def make_program_problem(i, d=2, T=20, noise=0.03, groups=None, vel_limit=None, 
 
 def make_program_variant(i, variant, d=2, T=12, noise=0.03, groups=None, vel_limit=None, joint_limit=None):
     """Seeded problem i of a r03 variant of the program family (variant_program)."""
-    rng = np.random.default_rng(9500 + 97 * (sorted(["sweep", "dynamics", "curve", "attract"]).index(variant)) + i)
+    # (the r03 variants keep their seeds; the r04 ones follow)
+    order = sorted(["sweep", "dynamics", "curve", "attract"]) + ["accel", "jerk"]
+    rng = np.random.default_rng(9500 + 97 * order.index(variant) + i)
     prog = variant_program(variant, d)
     start = np.concatenate([[-1.0, rng.uniform(-0.2, 0.2)], rng.uniform(-0.3, 0.3, size=d - 2)])
     goal = np.concatenate([[1.0, rng.uniform(-0.2, 0.2)], rng.uniform(-0.3, 0.3, size=d - 2)])
@@ -388,6 +410,18 @@ def make_program_variant(i, variant, d=2, T=12, noise=0.03, groups=None, vel_lim
         par[6] = rng.uniform(1.0, 3.0)                               # clearance grows with the squared step
         step = np.linalg.norm(goal[:2] - start[:2]) / (T - 1)
         par[7] = rng.uniform(1.6, 2.2) * step; par[8] = rng.uniform(0.0, 0.4) * step
+    elif variant == "accel":
+        par = np.zeros(8)
+        for o in range(2):
+            par[3 * o:3 * o + 2] = disc(0.25 + 0.3 * o, 0.45 + 0.3 * o); par[3 * o + 2] = rng.uniform(0.12, 0.2)
+        step = np.linalg.norm(goal[:2] - start[:2]) / (T - 1)
+        par[6] = rng.uniform(0.25, 0.45) * step; par[7] = rng.uniform(-0.3, 0.3)
+    elif variant == "jerk":
+        par = np.zeros(8)
+        par[0:2] = disc(0.3, 0.45); par[2] = rng.uniform(0.1, 0.16)
+        par[3:5] = disc(0.55, 0.7); par[5] = rng.uniform(0.12, 0.2)
+        step = np.linalg.norm(goal[:2] - start[:2]) / (T - 1)
+        par[6] = rng.uniform(0.3, 0.6) * step; par[7] = rng.uniform(0.5, 1.5)
     elif variant == "dynamics":
         par = np.zeros(6)
         par[0] = rng.uniform(1.05, 1.2) * np.linalg.norm(goal[:2] - start[:2]) / (T - 1)        # a little faster than the chord

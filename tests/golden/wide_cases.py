@@ -1,6 +1,7 @@
 """Cases of tests/golden/trajopt_wide.npz (r04, the wider device template): (prefix, make_problem kwargs, problem index, analytic_jac).
 w*: per-joint weights of the smoothing objective (a QuadExpr from a weighted difference matrix); ps*: program rows whose
-parameters differ from timestep to timestep (every timestep's Expr closes over its own data)."""
+parameters differ from timestep to timestep (every timestep's Expr closes over its own data); ac* / jk*: constraint blocks on
+THREE and FOUR consecutive timesteps (acceleration and jerk limits as non-linear rows on a Variable of 3 / 4 timesteps)."""
 ARM = dict(d=3, T=6, K=2, O=2)
 P = dict(K=1, program=True)
 CASES = [("w%d_" % i, dict(ARM, obj_weights=True), i, False) for i in range(2)] + \
@@ -12,4 +13,8 @@ CASES = [("w%d_" % i, dict(ARM, obj_weights=True), i, False) for i in range(2)] 
         [("pssw_", dict(P, d=2, T=8, variant="sweep", per_step=True), 0, False),
          ("psdy_", dict(P, d=3, T=8, variant="dynamics", per_step=True), 1, True),
          ("psat_", dict(P, d=2, T=8, variant="attract", per_step=True), 0, False),
-         ("psw_", dict(P, d=2, T=8, per_step=True, obj_weights=True, groups="split"), 2, False)]
+         ("psw_", dict(P, d=2, T=8, per_step=True, obj_weights=True, groups="split"), 2, False)] + \
+        [("ac%d_" % i, dict(P, d=2, T=8, variant="accel"), i, False) for i in range(2)] + \
+        [("acs_", dict(P, d=2, T=8, variant="accel", per_step=True, obj_weights=True), 2, False),
+         ("ja_ac_", dict(P, d=3, T=8, variant="accel"), 0, True),
+         ("jk_", dict(P, d=2, T=9, variant="jerk"), 0, False), ("ja_jk_", dict(P, d=2, T=9, variant="jerk", groups="split"), 1, True)]

@@ -26,6 +26,7 @@ FAMILIES = [
     # r04, the wider template: weighted smoothing objective; program parameters per timestep
     dict(SMALL, obj_weights=True), dict(SMALL, obj_weights=True, reach=True, vel_limit=0.6), dict(d=2, T=8, program=True, per_step=True),
     dict(d=2, T=6, K=1, program=True, variant="sweep", per_step=True), dict(d=2, T=6, K=1, program=True, variant="attract", per_step=True, obj_weights=True),
+    dict(d=2, T=8, K=1, program=True, variant="accel"), dict(d=2, T=9, K=1, program=True, variant="jerk", per_step=True),      # span 3, span 4
 ]
 
 

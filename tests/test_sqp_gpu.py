@@ -1181,25 +1181,29 @@ def test_program_reload_with_another_size_and_the_n_eq_rows_check(gpu):
     (dict(d=2, T=8, K=1, program=True, per_step=True), False), (dict(d=2, T=8, K=1, program=True, variant="sweep", per_step=True), True),
     (dict(d=3, T=8, K=1, program=True, variant="dynamics", per_step=True), False),
     (dict(d=2, T=8, K=1, program=True, variant="attract", per_step=True, obj_weights=True), False),
-    (dict(obj_weights=True), False)],
+    (dict(obj_weights=True), False),
+    (dict(d=2, T=8, K=1, program=True, variant="accel"), False), (dict(d=3, T=8, K=1, program=True, variant="accel", per_step=True, vel_limit=0.6), True),
+    (dict(d=2, T=9, K=1, program=True, variant="jerk"), False), (dict(d=2, T=9, K=1, program=True, variant="jerk", groups="split", obj_weights=True), True)],
     ids=["weights", "weights-reach-vel", "weights-objterm", "weights-point-jl-analytic", "steps", "steps-sweep-analytic", "steps-dynamics",
-         "steps-attract-weights", "weights-7x20"])
+         "steps-attract-weights", "weights-7x20", "span3", "span3-steps-vel-analytic", "span4", "span4-groups-weights-analytic"])
 def test_wider_template_matches_the_oracle(gpu, kw, analytic):
     """sco_sqp_load_obj_weights: sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 with per-problem, per-joint weights (objective value, P
     of every QP, the degree-2 model of an objective term on top of it); sco_sqp_load_program_steps: block t and the objective
     term of timestep t evaluated with params[problem][t] (values, finite-difference and forward-mode Jacobians, numeric
-    Hessians).  Every decision, QP status, iteration count, merit and the answer against the oracle, which reproduces the
+    Hessians); span 3 and 4: constraint blocks on three / four consecutive timesteps (acceleration and jerk limits, a keep-out
+    on the centroid of four points).  Every decision, QP status, iteration count, merit and the answer against the oracle, which reproduces the
     reference's own runs of these cases (tests/test_golden.py, trajopt_wide.npz)."""
     n = 4 if kw.get("d", 7) == 7 else 8
     arrays, probs = af.make_batch(n, **kw)
     res = sb.solve_batch(arrays, analytic_jac=analytic)
     _compare(res, probs, range(n), analytic=analytic)
     # the extension is live: the same problems without it end elsewhere
-    plain = {k: v for k, v in arrays.items() if k != "obj_w"}
-    if kw.get("per_step"):
-        plain["row_params"] = arrays["row_params"][:, 0, :].copy()
-    res0 = sb.solve_batch(plain, analytic_jac=analytic)
-    assert np.abs(res0.x - res.x).max() > 1e-4
+    if kw.get("obj_weights") or kw.get("per_step"):
+        plain = {k: v for k, v in arrays.items() if k != "obj_w"}
+        if kw.get("per_step"):
+            plain["row_params"] = arrays["row_params"][:, 0, :].copy()
+        res0 = sb.solve_batch(plain, analytic_jac=analytic)
+        assert np.abs(res0.x - res.x).max() > 1e-4
 
 
 def test_wider_template_matches_reference_golden_runs(gpu):
