@@ -73,3 +73,38 @@ def test_margin_at_the_check_where_the_r03_device_stopped(fx, i, margin_lo, marg
         assert margin_lo < ck[1, 3] / eps - 1 < margin_hi, (name, ck[1, 3] / eps - 1)
         assert abs(ck[1, 3] - ref) / eps < noise
     assert abs(fx["p%d_x87_reduced_checks" % i][1, 3] - ref) / eps < 1e-7       # the two extended routes agree to 8 digits
+
+
+# ---- r04 sweeps: two more problems where two float64 routes of the ORACLE ITSELF part (profiles/r04_parity_sweep.txt) ----
+WIDE = {6072: dict(program=True, variant="dynamics", d=3, T=10, K=1), 6233: dict(program=True, variant="jerk", d=2, T=10, K=1)}
+
+
+def oracle_route(i, **kw):
+    from oracle import arm_family as af, sco_ref as sr
+    solver = (lambda P, q, A, l, u, w, s: o.solve(P, q, A, l, u, w=w, **dict(s, **kw))) if kw else None
+    return sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i, **WIDE[i]), analytic_jac=True), None, emulate_memo=True, qp_solver=solver)
+
+
+def test_a_qp_at_the_edge_of_max_iter_splits_the_oracles_own_float64_routes():
+    """prog:dynamics (forward-mode Jacobians), problem 6072: the sixth QP creeps towards its tolerance for ~1e5 iterations.
+    With the KKT LDL' route (float64 and x87) and the x87 reduced route it is still short of it at max_iter = 100 000
+    (status -2: the SQP loop gives up, 6 QPs); with the float64 reduced-Cholesky route -- the device's algebra -- rounding lets
+    it pass at 94 075, and the loop goes on for 8 more QPs.  Same algorithm, same data, two float64 routes of the oracle, two
+    different runs: a parity sweep of the device against the KKT route counts this problem as a mismatch (|dx| = 0.76) although
+    the device reproduces the oracle's reduced route decision for decision (tests/test_adjudicate_gpu.py)."""
+    kkt, red, x87 = oracle_route(6072), oracle_route(6072, linsys=1), oracle_route(6072, extended=True, linsys=1)
+    assert kkt.trace[:, 7].astype(int).tolist() == [50, 2750, 2700, 100000, 9950, 100000] and int(kkt.trace[-1, 6]) == -2
+    assert np.array_equal(x87.trace[:, 6:8], kkt.trace[:, 6:8])
+    assert red.trace[:, 7].astype(int).tolist() == [50, 2750, 2700, 100000, 9950, 94075, 16050, 12750, 16650, 16750, 22675, 36275, 39975, 25]
+    assert np.abs(red.x - kkt.x).max() > 0.5
+
+
+def test_unconverged_qps_put_the_noise_floor_of_a_run_above_the_parity_bar():
+    """prog:jerk (forward-mode), problem 6233: two of its QPs end at max_iter (status 2).  All routes take the same decisions with
+    the same iteration counts, yet the float64 KKT route ends 3.2e-5 from the x87 run and 1.6e-5 from the float64 reduced
+    route: the 1e-6 bar on x is below what float64 can reproduce here, for the oracle as for the device (sweep: 4.0e-5)."""
+    kkt, red, x87 = oracle_route(6233), oracle_route(6233, linsys=1), oracle_route(6233, extended=True)
+    for r in (red, x87):
+        assert np.array_equal(r.trace[:, 0], kkt.trace[:, 0]) and np.array_equal(r.trace[:, 6:8], kkt.trace[:, 6:8])
+    assert sorted(kkt.trace[:, 6].astype(int).tolist()).count(2) == 2
+    assert 1e-5 < np.abs(x87.x - kkt.x).max() < 1e-4 and 5e-6 < np.abs(red.x - kkt.x).max() < 1e-4
