@@ -154,11 +154,15 @@ bool wv_plan_build(const QpPlan &pl, WvHost &wh) {
   for (auto &v : hin) maxh = std::max(maxh, (int)v.size());
   const int NS = std::max(1, (maxh + lpb - 1) / lpb), NV = (bs + lpb - 1) / lpb;
   const int mid = nb / 2;
-  // instantiations <BS, NS, NV, NSTEP>: <7, 4, 3, 10> for the 7-DOF x 20 shapes, <8, 1, 1, 4>, <8, 2, 2, 8>, <8, 4, 4, 16>
-  if (bs == 7 && NS <= 4 && NV <= 3 && mid <= 10) { wh.BS = 7; wh.NS = 4; wh.NV = 3; wh.NSTEP = 10; }
-  else if (NS <= 1 && NV <= 1 && mid <= 4) { wh.BS = 8; wh.NS = 1; wh.NV = 1; wh.NSTEP = 4; }
+  // instantiations <BS, NS, NV, NSTEP>, the smallest that holds the shape first (row slots and padded block steps of a larger one
+  // are executed all the same): <8, 1, 1, 4>, <8, 2, 2, 8>, <8, 2, 2, 10>, and <7, 4, 3, 10> for the 7-DOF x 20 shapes.  A shape that
+  // would need more (e.g. 4-DOF x 24: 3 row slots, 12 steps) stays on the row-local tier: an instantiation with 4 x 4 slots and 16
+  // steps (r04, dropped) held 496 VGPRs and 42 KB of LDS -- three problems per CU at half the row-local kernel's rate
+  // (profiles/r04_tier_choice.txt).
+  if (NS <= 1 && NV <= 1 && mid <= 4) { wh.BS = 8; wh.NS = 1; wh.NV = 1; wh.NSTEP = 4; }
   else if (NS <= 2 && NV <= 2 && mid <= 8) { wh.BS = 8; wh.NS = 2; wh.NV = 2; wh.NSTEP = 8; }
-  else if (NS <= 4 && NV <= 4 && mid <= 16) { wh.BS = 8; wh.NS = 4; wh.NV = 4; wh.NSTEP = 16; }
+  else if (NS <= 2 && NV <= 2 && mid <= 10) { wh.BS = 8; wh.NS = 2; wh.NV = 2; wh.NSTEP = 10; }
+  else if (bs == 7 && NS <= 4 && NV <= 3 && mid <= 10) { wh.BS = 7; wh.NS = 4; wh.NV = 3; wh.NSTEP = 10; }
   else return false;
   wh.bs = bs; wh.nb = nb; wh.mid = mid; wh.lpb = lpb; wh.n_extra = n_extra;
   const int NSTEP = wh.NSTEP, lenB = nb - 1 - mid, npos = 2 * NSTEP + 2, dummy = npos - 1;
@@ -205,12 +209,14 @@ bool wv_plan_build(const QpPlan &pl, WvHost &wh) {
       if (single[c].size() == 2) { at(T.xrow, xl) = single[c][0]; at(T.xpos, xl) = apos(single[c][0], var); at(T.xpk, xl) = wv_vidx(npos, p, k); xl++; }
     }
   }
-  // LDS of the ADMM kernel (doubles): G, ef, en, em | r, x~, x, extra | Jacobian rows | partials
+  // LDS of the ADMM kernel (doubles): G, ef, en, em | r, x~, x, extra | Jacobian rows (unless they live in registers) | partials
+  const bool jreg = WV_JREG && wh.NS * wh.BS <= 28;
   wh.g_doubles = (size_t)npos * 64 + 2 * (size_t)npos * 8 + 8;
-  wh.lds_doubles = wh.g_doubles + 4 * (size_t)npos * 8 + (size_t)wh.NS * 512 + (size_t)npos * lpb * 8;
+  wh.lds_doubles = wh.g_doubles + 4 * (size_t)npos * 8 + (jreg ? 0 : (size_t)wh.NS * 512) + (size_t)npos * lpb * 8;
   wh.lds_bytes = wh.lds_doubles * sizeof(double);
   wh.cst_slots = 3 * wh.NS + 13 * wh.NV + 1;
-  return wh.lds_bytes <= 64 * 1024;     // (<= 40 KB: four problems per CU, the 7 x 20 shapes; more LDS = fewer per CU)
+  // the tier pays only with FOUR problems per CU (one wavefront per SIMD): 40 KB each at most
+  return wh.lds_bytes <= 40 * 1024;
 }
 
 int wv_upload(const WvHost &wh, int batch, int n, int m, std::vector<void *> &allocs, WvDev &wd) {
@@ -455,8 +461,12 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   const int n = a.n, m = a.m, lpb = LPB > 0 ? LPB : a.lpb;
   constexpr int NPOS = 2 * NSTEP + 2;
   // LDS (doubles), compile-time offsets: the vectors sit at fixed distances from each other
+  // The lane's Jacobian rows: constants of the solve, read twice per iteration.  In REGISTERS where the instantiation has
+  // room (NS x BS <= 28 doubles: every instantiation built today), else lane-private in LDS: the kernel is bound by the CU's LDS
+  // pipe (four wavefronts share it), and these rows were a third of a wavefront's LDS bytes per iteration.
+  constexpr bool JREG = WV_JREG && NS * BS <= 28;
   constexpr int oG = 0, oEF = oG + NPOS * 64, oEN = oEF + NPOS * 8, oEM = oEN + NPOS * 8, oR = oEM + 8, oXT = oR + NPOS * 8,
-                oXC = oXT + NPOS * 8, oEX = oXC + NPOS * 8, oJ = oEX + NPOS * 8, oPART = oJ + NS * 512;
+                oXC = oXT + NPOS * 8, oEX = oXC + NPOS * 8, oJ = oEX + NPOS * 8, oPART = oJ + (JREG ? 0 : NS * 512);
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int *tab0 = a.tab;
   constexpr int oPOS = 0, oHROW = 1, oHBROW = oHROW + NS, oHEVAR = oHBROW + NS, oHEIDX = oHEVAR + NS, oHEPOS = oHEIDX + NS,
@@ -487,10 +497,6 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   double *const jl_p = lds + oJ + lane * 2;                                     // Jacobian rows, lane-private
   // hinge slots: constants and state
   double h_ae[NS], h_ab[NS], h_u[NS], h_q[NS], h_kinv[NS], h_z[NS], h_y[NS], h_zb[NS], h_yb[NS], h_xe[NS], h_ge[NS];
-  // The lane's Jacobian rows: constants of the solve, read twice per iteration.  In REGISTERS where the instantiation has
-  // room (NS x BS <= 28 doubles: the 7-DOF shapes), else lane-private in LDS: the kernel is bound by the CU's LDS pipe
-  // (four wavefronts share it), and these rows were a third of a wavefront's LDS bytes per iteration.
-  constexpr bool JREG = WV_JREG && NS * BS <= 28;
   double hJ[JREG ? NS : 1][8];
 #pragma unroll
   for (int q = 0; q < NS; q++) {
@@ -1136,10 +1142,10 @@ int wv_launch(const AdmmArgs &aa, const WvHost &wh, const WvDev &wd, hipStream_t
   WvArgs a; wv_fill_args(aa, wh, wd, nullptr, a);
   const int nwg = aa.d.nb > 0 ? aa.d.nb : aa.d.batch;
   // the LDS request also fixes how many problems share a CU: at most 4 (one wavefront per SIMD)
-  const size_t lds = std::max(wh.lds_bytes, (size_t)36 * 1024);
-  if (wh.NSTEP == 10 && wh.lpb == 3) return wv_launch_k<7, 4, 3, 10, 3>(a, nwg, lds, st);    // 7-DOF, 17 .. 20 timesteps
-  if (wh.NSTEP == 10) return wv_launch_k<7, 4, 3, 10, 0>(a, nwg, lds, st);
+  const size_t lds = std::max(wh.lds_bytes, (size_t)36 * 1024);      // (36 KB: never a fifth workgroup on a CU)
+  if (wh.NSTEP == 10 && wh.NS == 4 && wh.lpb == 3) return wv_launch_k<7, 4, 3, 10, 3>(a, nwg, lds, st);    // 7-DOF, 17 .. 20 timesteps
+  if (wh.NSTEP == 10 && wh.NS == 4) return wv_launch_k<7, 4, 3, 10, 0>(a, nwg, lds, st);
+  if (wh.NSTEP == 10) return wv_launch_k<8, 2, 2, 10, 0>(a, nwg, lds, st);
   if (wh.NSTEP == 4) return wv_launch_k<8, 1, 1, 4, 0>(a, nwg, lds, st);
-  if (wh.NSTEP == 8) return wv_launch_k<8, 2, 2, 8, 0>(a, nwg, lds, st);
-  return wv_launch_k<8, 4, 4, 16, 0>(a, nwg, lds, st);
+  return wv_launch_k<8, 2, 2, 8, 0>(a, nwg, lds, st);
 }

@@ -13,7 +13,10 @@ for name, kw in (("circles", {}), ("reach", dict(reach=True)), ("vel", dict(vel_
                  ("circles+weights", dict(obj_weights=True)), ("vel+weights", dict(vel_limit=0.3, obj_weights=True)),
                  ("program d=2 T=20", dict(d=2, T=20, K=1, program=True)), ("program+steps", dict(d=2, T=20, K=1, program=True, per_step=True)),
                  ("sweep+steps (span 2)", dict(d=2, T=20, K=1, program=True, variant="sweep", per_step=True)),
-                 ("attract+steps+weights", dict(d=2, T=20, K=1, program=True, variant="attract", per_step=True, obj_weights=True))):
+                 ("attract+steps+weights", dict(d=2, T=20, K=1, program=True, variant="attract", per_step=True, obj_weights=True)),
+                 # shapes other than 7 x 20 on the patterns the wavefront tier takes (which tier is faster where)
+                 ("point d=2 T=20", dict(d=2, T=20, K=1, O=3, point=True)), ("quad d=3 T=12", dict(d=3, T=12, K=1, O=4, quadratic=True)),
+                 ("arm 4x24", dict(d=4, T=24, K=3, O=2)), ("arm 7x12", dict(T=12)), ("arm 5x16", dict(d=5, T=16, K=4, O=2)), ("arm 3x6", dict(d=3, T=6, K=2, O=2))):
     if ONLY and name not in ONLY.split(','):
         continue
     arrays, _ = af.make_batch(B, **kw)

@@ -1127,14 +1127,15 @@ def test_wavefront_rounds_then_row_local_tail_agree_with_the_row_local_loop(gpu,
 @pytest.mark.parametrize("kw,params", [
     (dict(d=3, T=6, K=2, O=2), {}), (dict(d=3, T=6, K=2, O=2), dict(compound_penalty=0, duplicate_rows=0, max_sqp_iters=20)),
     (dict(), {}), (dict(d=2, T=8, O=3, point=True), {}), (dict(d=2, T=8, O=3, quadratic=True), {}),
-    (dict(d=2, T=8, K=1, program=True), {}), (dict(d=3, T=6, K=2, O=2, ee_cost_weight=0.5), {})],
-    ids=["3x6", "3x6 quirks off", "7x20", "point", "quadratic rows", "program rows", "objective terms"])
+    (dict(d=2, T=8, K=1, program=True), {}), (dict(d=3, T=6, K=2, O=2, ee_cost_weight=0.5), {}),
+    (dict(T=12), {}), (dict(d=2, T=20, K=1, program=True, per_step=True, obj_weights=True), {})],
+    ids=["3x6", "3x6 quirks off", "7x20", "point", "quadratic rows", "program rows", "objective terms", "7x12", "program 2x20 steps weights"])
 def test_wavefront_tier_forced_through_the_device_loop(gpu, monkeypatch, kw, params):
     """By default a round goes to the wavefront tier only with > 3.3 live problems per CU; SCO_WV_MIN_PER_CU=0 sends every
     round of every batch there: decisions, QP statuses, iteration counts and trajectories of the flat oracle for the
     families whose penalty QP the tier takes (dense P blocks of the objective terms included), time slices of 300."""
     monkeypatch.setenv("SCO_WV_MIN_PER_CU", "0")
-    nb = 6 if not kw else 12
+    nb = 6 if (not kw or kw.get("T") == 12) else 12
     arrays, probs = af.make_batch(nb, **kw)
     dp = _lib.default_sqp_params(admm_slice=300, **params)
     op = sr.SolverParams(compound_penalty=False, duplicate_rows=False, max_qp_solves=20) if params else None
