@@ -1057,14 +1057,14 @@ def test_wide_program_blocks_above_the_cu_count_and_descriptor_rules(gpu):
             g = prog.evaluate(x[t * 3:(t + 2) * 3], arrays["row_params"][b])
             assert g[prog.ineq_rows].max() < 1e-3 and np.abs(g[prog.eq_rows]).max() < 1e-3
     from sco_py_amd.rowexpr import X, compile_rows
-    with pytest.raises(_lib.ScoHipError):                       # span 2 of a horizon of 2 leaves one block: allowed; 3 is not a span
+    with pytest.raises(_lib.ScoHipError):                       # span x dof beyond 32 state coordinates
         sb.TrajOptBatch(1, 20, 6, 1, 1, program=compile_rows([X(0) + X(39)], span=2))       # 2 x 20 > 32 state coordinates
     with pytest.raises(ValueError):
         compile_rows([X(0)], objective=X(1), span=2)           # objective terms live on one timestep
     import ctypes as C
     lib = _lib.load()
     for fam, span, neq in ((sb.SCO_FAM_ARM_CIRCLES, 2, 0), (sb.SCO_FAM_ARM_CIRCLES, 1, 1), (sb.SCO_FAM_STATE_QUADRATIC, 2, 0),
-                           (sb.SCO_FAM_STATE_PROGRAM, 3, 0), (sb.SCO_FAM_STATE_PROGRAM, 1, 5),
+                           (sb.SCO_FAM_STATE_PROGRAM, 5, 0), (sb.SCO_FAM_STATE_PROGRAM, 1, 5),       # (span 3 and 4: allowed since r04)
                            (sb.SCO_FAM_STATE_PROGRAM | sb.SCO_FAM_FLAG_OBJ_PROGRAM, 2, 0)):
         h = C.c_void_p()
         desc = _lib.TrajoptDesc(1, 3, 6, 1, 2, fam, 0, 2, span, neq)
