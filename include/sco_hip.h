@@ -277,6 +277,17 @@ typedef struct sco_trajopt_desc {
 typedef struct sco_sqp sco_sqp;
 
 int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out);
+/* r04: the same with n_rows GENERAL affine rows over the trajectory variables, placed behind the built-in linear rows (pins,
+ * velocity limits, joint limits) in every QP -- what a caller of the reference adds with
+ * prob.add_cnt_expr(BoundExpr(EqExpr / LEqExpr(AffExpr(A, b), val), traj)) (prob.py:126-131, 317-346; rows of AffExpr
+ * constraints go straight into the QP, they are never penalised).  The sparsity pattern is shared by the batch and given in CSR
+ * form: row_ptr[n_rows + 1], col_idx[row_ptr[n_rows]] strictly increasing inside a row, column t * dof + j = coordinate j of
+ * timestep t (the name-sorted atoms, osqp_utils.py:136-143); row_is_eq[r] != 0: a x = rhs (lb = ub, prob.py:339-346), else
+ * a x <= rhs (lb = -inf, prob.py:329-338).  Coefficients and right-hand sides are per-problem values:
+ * sco_sqp_load_linear_rows(h, vals[batch][nnz] in CSR order, rhs[batch][n_rows]) after sco_sqp_load, before sco_sqp_solve. */
+int sco_sqp_create_rows(int device, const sco_trajopt_desc *desc, int n_rows, const int *row_ptr, const int *col_idx,
+                        const int *row_is_eq, sco_sqp **out);
+int sco_sqp_load_linear_rows(sco_sqp *h, const double *vals, const double *rhs);
 int sco_sqp_destroy(sco_sqp *h);
 
 /* Upload per-problem data (host pointers, problem-major):

@@ -502,6 +502,11 @@ def trajopt_flat(prob, analytic_jac=False):
         lin = sp.vstack([lin.tocsr(), sp.csr_matrix(af.joint_limit_rows(d, T))]).tolil()
         lin_lo = np.concatenate([lin_lo, np.full(2 * n_x, -np.inf)])
         lin_hi = np.concatenate([lin_hi, np.tile(prob["jhi"], T), -np.tile(prob["jlo"], T)])
+    if prob.get("lin_gen") is not None:            # r04: general affine rows (LEqExpr / EqExpr on an AffExpr, prob.py:317-346), behind the others
+        g = prob["lin_gen"]
+        lin = sp.vstack([sp.csr_matrix(lin), sp.csr_matrix(g["A"])]).tolil()
+        lin_lo = np.concatenate([lin_lo, np.where(g["is_eq"] != 0, g["rhs"], -np.inf)])
+        lin_hi = np.concatenate([lin_hi, g["rhs"]])
     blocks = []
     R = prob["K"] * prob["O"]
     prog = prob.get("row_program")

@@ -76,6 +76,7 @@ ABI = {
     "sco_qp_last_timing": (C.c_int, [C.c_void_p, _DP]),
     "sco_sqp_default_params": (None, [C.POINTER(SqpParams)]),
     "sco_sqp_create": (C.c_int, [C.c_int, C.POINTER(TrajoptDesc), C.POINTER(C.c_void_p)]),
+    "sco_sqp_create_rows": (C.c_int, [C.c_int, C.POINTER(TrajoptDesc), C.c_int, _IP, _IP, _IP, C.POINTER(C.c_void_p)]),
     "sco_sqp_destroy": (C.c_int, [C.c_void_p]),
     "sco_sqp_load": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, _IP, _DP, _DP]),
     "sco_sqp_load_target": (C.c_int, [C.c_void_p, _DP]),
@@ -83,6 +84,7 @@ ABI = {
     "sco_sqp_load_program": (C.c_int, [C.c_void_p, C.c_int, _IP, _IP, C.c_int, _DP, C.c_int, _DP]),
     "sco_sqp_load_program_steps": (C.c_int, [C.c_void_p, C.c_int, _IP, _IP, C.c_int, _DP, C.c_int, _DP]),
     "sco_sqp_load_obj_weights": (C.c_int, [C.c_void_p, _DP]),
+    "sco_sqp_load_linear_rows": (C.c_int, [C.c_void_p, _DP, _DP]),
     "sco_sqp_load_vel_limit": (C.c_int, [C.c_void_p, _DP]),
     "sco_sqp_load_joint_limits": (C.c_int, [C.c_void_p, _DP, _DP]),
     "sco_sqp_load_ee_cost": (C.c_int, [C.c_void_p, _DP, _DP]),

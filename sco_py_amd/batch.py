@@ -58,7 +58,11 @@ class TrajOptBatch(object):
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
                  prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False, point=False,
-                 quadratic=False, program=False, n_eq_rows=0):
+                 quadratic=False, program=False, n_eq_rows=0, lin_rows=None):
+        """lin_rows (r04): pattern of GENERAL affine rows over the trajectory variables, shared by the batch:
+        (row_ptr, col_idx, is_eq) in CSR form, column t * dof + j (``rows_pattern`` builds it from a dense 0 / 1 mask) -- the rows
+        a caller of the reference adds with prob.add_cnt_expr(BoundExpr(EqExpr / LEqExpr(AffExpr(A, b), val), traj)); values and
+        right-hand sides per problem go to ``load(lin_vals=, lin_rhs=)``."""
         self.B, self.d, self.T, self.K, self.O = int(batch), int(dof), int(horizon), int(n_points), int(n_obstacles)
         self.n_x = self.d * self.T
         self.device = int(device)
@@ -96,7 +100,17 @@ class TrajOptBatch(object):
                                 (SCO_FAM_FLAG_EE_COST if self.ee_cost else 0) |
                                 (SCO_FAM_FLAG_OBJ_PROGRAM if self.obj_program else 0),
                                 1 if analytic_jac else 0, int(prox_count), self.span, self.n_eq)
-        _lib.check(_lib.load().sco_sqp_create(self.device, C.byref(desc), C.byref(self._h)))
+        self.lin_rows = None
+        if lin_rows is not None and len(lin_rows[2]):
+            rp = np.ascontiguousarray(lin_rows[0], dtype=np.int32); ci = np.ascontiguousarray(lin_rows[1], dtype=np.int32)
+            eq = np.ascontiguousarray(lin_rows[2], dtype=np.int32)
+            if rp.shape != (eq.shape[0] + 1,) or ci.shape != (int(rp[-1]),):
+                raise ValueError("lin_rows = (row_ptr [n_rows + 1], col_idx [nnz], is_eq [n_rows])")
+            self.lin_rows = (rp, ci, eq)
+            _lib.check(_lib.load().sco_sqp_create_rows(self.device, C.byref(desc), eq.shape[0], _lib.iptr(rp), _lib.iptr(ci), _lib.iptr(eq),
+                                                       C.byref(self._h)))
+        else:
+            _lib.check(_lib.load().sco_sqp_create(self.device, C.byref(desc), C.byref(self._h)))
 
     def close(self):
         if self._h:
@@ -117,7 +131,7 @@ class TrajOptBatch(object):
 
     def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles, target=None, vmax=None,
              jlo=None, jhi=None, cost_weight=None, cost_target=None, quad_Q=None, quad_a=None, quad_c=None,
-             row_program=None, row_params=None, obj_weights=None):
+             row_program=None, row_params=None, obj_weights=None, lin_vals=None, lin_rhs=None):
         """Upload per-problem data (host arrays, copied).  ``target`` (B, 2): end-effector
         position of the reach variant (``goal`` is then ignored by the device).  r04: ``row_params`` may be (B, T, n_params) --
         one parameter vector per timestep (block t and the objective term of timestep t read row_params[b, t]);
@@ -182,6 +196,13 @@ class TrajOptBatch(object):
             jlo = arr(np.broadcast_to(np.asarray(jlo, dtype=np.float64), (B, d)), (B, d))
             jhi = arr(np.broadcast_to(np.asarray(jhi, dtype=np.float64), (B, d)), (B, d))
             _lib.check(_lib.load().sco_sqp_load_joint_limits(self._h, _lib.dptr(jlo), _lib.dptr(jhi)))
+        if self.lin_rows is not None:
+            if lin_vals is None or lin_rhs is None:
+                raise ValueError("general affine rows need lin_vals (B, nnz) and lin_rhs (B, n_rows)")
+            lv = arr(lin_vals, (B, self.lin_rows[1].shape[0])); lr = arr(lin_rhs, (B, self.lin_rows[2].shape[0]))
+            _lib.check(_lib.load().sco_sqp_load_linear_rows(self._h, _lib.dptr(lv), _lib.dptr(lr)))
+        elif lin_vals is not None or lin_rhs is not None:
+            raise ValueError("the batch was created without general affine rows (lin_rows=)")
         if obj_weights is not None:
             ow = arr(np.broadcast_to(np.asarray(obj_weights, dtype=np.float64), (B, d)), (B, d))
             _lib.check(_lib.load().sco_sqp_load_obj_weights(self._h, _lib.dptr(ow)))
@@ -257,6 +278,14 @@ class TrajOptBatch(object):
                     other_launches=int(tl[1]))
 
 
+def rows_pattern(mask):
+    """CSR pattern (row_ptr, col_idx) of a dense (n_rows, dof * horizon) 0 / 1 mask, and the gather index of its entries."""
+    mask = np.asarray(mask) != 0
+    row_ptr = np.concatenate([[0], np.cumsum(mask.sum(axis=1))]).astype(np.int32)
+    r, c = np.nonzero(mask)                      # row-major: CSR order
+    return row_ptr, c.astype(np.int32), (r, c)
+
+
 def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_jac=False, prox_count=2):
     """One-shot helper: dict with keys d, T, K, O, B, x0, start, goal, link_len,
     point_link, point_frac, obstacles (as produced by the synthetic workload
@@ -267,12 +296,13 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
                       joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
                       point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None,
                       program=a.get("row_program") if a.get("row_program") is not None else False,
-                      n_eq_rows=a.get("quad_n_eq", 0)) as tb:
+                      n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows")) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                 target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
                 cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),
                 quad_Q=a.get("quad_Q"), quad_a=a.get("quad_a"), quad_c=a.get("quad_c"),
-                row_program=a.get("row_program"), row_params=a.get("row_params"), obj_weights=a.get("obj_w"))
+                row_program=a.get("row_program"), row_params=a.get("row_params"), obj_weights=a.get("obj_w"),
+                lin_vals=a.get("lin_vals"), lin_rhs=a.get("lin_rhs"))
         if a.get("groups") is not None:
             tb.set_groups(a["groups"])
         tb.solve(params, qp_settings)

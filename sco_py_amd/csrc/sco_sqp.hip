@@ -74,6 +74,12 @@ struct SqpDev {
   // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows, then m_jl joint-limit
   // rows (theta <= hi for every trajectory variable, then -theta <= -lo)
   int m_pin, m_vel, m_jl;
+  // r04: m_gen GENERAL affine rows behind them (a shared CSR pattern over the trajectory variables, values and right-hand
+  // sides per problem: sco_sqp_create_rows / sco_sqp_load_linear_rows): row r is an equality (gen_eq[r]) a x = rhs or an
+  // inequality a x <= rhs; gpos0 / gpos1: where entry k of the pattern sits in the A values of the projection / penalty QP
+  int m_gen, nnz_gen;
+  const int *gen_eq, *gpos0, *gpos1;
+  const double *gen_rhs, *gen_val;      // [B][m_gen], [B][nnz_gen]
   // SCO_FAM_FLAG_EE_COST: non-quadratic objective term weight * ||ee(theta_t) - target||^2 per timestep, convexified to
   // degree 2 every SQP iteration (expr.py:143-153): oH = Hessian after the eigenvalue shift, oA, ob = the model's
   // linear and constant part; ppos = position in qp1's P values of entry (row (t, 0), column (t, j))
@@ -129,6 +135,8 @@ struct sco_sqp {
   std::vector<hipEvent_t> events;
   void *prog_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // sco_sqp_load_program: words, row starts, constants, parameters
   void *objw_buf = nullptr;                                    // sco_sqp_load_obj_weights
+  std::vector<int> gen_ptr, gen_col, gen_iseq;                 // sco_sqp_create_rows: the general affine rows' pattern
+  bool gen_loaded = false;
   size_t prog_bytes[4] = {0, 0, 0, 0};
   bool loaded = false, solved = false, target_loaded = false, vel_loaded = false, jl_loaded = false, cost_loaded = false, quad_loaded = false, prog_loaded = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
@@ -441,9 +449,13 @@ __device__ __forceinline__ double traj_obj_partial(const double *x, int d, int T
   return s;
 }
 
-// upper bound of linear inequality row i (m_pin <= i < m_lin): velocity rows, then theta <= hi, then -theta <= -lo
-// (prob.py:329-338: lb = -inf, ub = val - b)
+// upper bound of linear inequality row i (m_pin <= i < m_lin): velocity rows, then theta <= hi, then -theta <= -lo, then the
+// general affine rows (prob.py:329-338: lb = -inf, ub = val - b; an equality among the general rows: lb = ub, prob.py:339-346)
+__device__ __forceinline__ bool lin_row_is_eq(const SqpDev &s, int i) {
+  return i >= s.m_lin - s.m_gen && s.gen_eq[i - (s.m_lin - s.m_gen)] != 0;
+}
 __device__ __forceinline__ double lin_ineq_hi(const SqpDev &s, int b, int i) {
+  if (i >= s.m_lin - s.m_gen) return s.gen_rhs[(size_t)b * s.m_gen + (i - (s.m_lin - s.m_gen))];      // general rows (r04)
   const int v = i - s.m_pin;
   if (v < s.m_vel) return s.vmax[b];
   const int k = v - s.m_vel;
@@ -471,11 +483,15 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_assemble_kernel(SqpDev s, 
     s.x[(size_t)b * n_x + i] = x0[i];
   }
   for (int t = tid; t < q0.nnzA; t += SCO_BLOCK) q0.Aval[(size_t)b * q0.nnzA + t] = s.a0c[t];
+  if (s.nnz_gen) {                       // per-problem coefficients of the general affine rows over the shared constants
+    __syncthreads();
+    for (int k = tid; k < s.nnz_gen; k += SCO_BLOCK) q0.Aval[(size_t)b * q0.nnzA + s.gpos0[k]] = s.gen_val[(size_t)b * s.nnz_gen + k];
+  }
   for (int i = tid; i < m0; i += SCO_BLOCK) {
     double lo, hi;
     if (i < d) lo = hi = s.start[(size_t)b * d + i];
     else if (i < s.m_pin) lo = hi = s.goal[(size_t)b * d + (i - d)];
-    else if (i < s.m_lin) { lo = -INFINITY; hi = lin_ineq_hi(s, b, i); }
+    else if (i < s.m_lin) { hi = lin_ineq_hi(s, b, i); lo = lin_row_is_eq(s, i) ? hi : -INFINITY; }
     else { lo = -INFINITY; hi = INFINITY; }
     q0.l[(size_t)b * m0 + i] = lo; q0.u[(size_t)b * m0 + i] = hi;
     q0.w[(size_t)b * m0 + i] = 1;
@@ -535,13 +551,17 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
     // constant entries (pins, velocity rows, slack and bound entries; zeros where convexify writes the
     // Jacobian), built once on the host (sco_sqp_create)
     for (int t = tid; t < q1.nnzA; t += SCO_BLOCK) Av[t] = s.a1c[t];
+    if (s.nnz_gen) {
+      __syncthreads();
+      for (int k = tid; k < s.nnz_gen; k += SCO_BLOCK) Av[s.gpos1[k]] = s.gen_val[(size_t)b * s.nnz_gen + k];
+    }
     double *l = q1.l + (size_t)b * m, *u = q1.u + (size_t)b * m;
     int *w = q1.w + (size_t)b * m;
     for (int i = tid; i < m; i += SCO_BLOCK) {
       double lo, hi;
       if (i < d) lo = hi = s.start[(size_t)b * d + i];
       else if (i < s.m_pin) lo = hi = s.goal[(size_t)b * d + (i - d)];
-      else if (i < s.m_lin) { lo = -INFINITY; hi = lin_ineq_hi(s, b, i); }
+      else if (i < s.m_lin) { hi = lin_ineq_hi(s, b, i); lo = lin_row_is_eq(s, i) ? hi : -INFINITY; }
       else if (i < s.m_lin + s.m_nl) {                                  // hinge rows; equality rows are set by convexify
         const RowRef qr = row_ref(i - s.m_lin, RowLay{s.T, s.NBt, s.R, s.Req});
         lo = qr.eq ? 0.0 : -INFINITY; hi = 0.0;
@@ -1062,8 +1082,26 @@ static int sq_alloc(sco_sqp *h, size_t count, T **out) {
 
 static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc);
 
-extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
+// r04: sco_sqp_create with n_rows GENERAL affine rows over the trajectory variables behind the built-in linear rows -- what a
+// caller of the reference adds with prob.add_cnt_expr(BoundExpr(EqExpr / LEqExpr(AffExpr(A, b), val), traj)) (prob.py:126-131,
+// 317-346): a shared CSR pattern (row_ptr[n_rows + 1], col_idx strictly increasing inside a row, columns = name-sorted
+// trajectory atoms t * dof + j), row_is_eq[r] != 0: a x = rhs, else a x <= rhs; coefficients and right-hand sides per problem
+// through sco_sqp_load_linear_rows.
+extern "C" int sco_sqp_create_rows(int device, const sco_trajopt_desc *desc, int n_rows, const int *row_ptr, const int *col_idx,
+                                   const int *row_is_eq, sco_sqp **out) {
   if (!desc || !out) { sco_set_error("sco_sqp_create: null pointer"); return SCO_ERR_ARG; }
+  if (n_rows < 0 || n_rows > 65536 || (n_rows > 0 && (!row_ptr || !col_idx || !row_is_eq))) { sco_set_error("sco_sqp_create_rows: bad row pattern"); return SCO_ERR_ARG; }
+  if (n_rows > 0) {
+    if (row_ptr[0] != 0) { sco_set_error("sco_sqp_create_rows: bad row pattern"); return SCO_ERR_ARG; }
+    const long long nx = (long long)desc->dof * desc->horizon;
+    for (int r = 0; r < n_rows; r++) {
+      if (row_ptr[r + 1] <= row_ptr[r] || row_ptr[r + 1] - row_ptr[r] > nx) { sco_set_error("sco_sqp_create_rows: bad row pattern (empty row or row_ptr not increasing)"); return SCO_ERR_ARG; }
+      for (int k = row_ptr[r]; k < row_ptr[r + 1]; k++)
+        if (col_idx[k] < 0 || col_idx[k] >= nx || (k > row_ptr[r] && col_idx[k] <= col_idx[k - 1])) {
+          sco_set_error("sco_sqp_create_rows: column indices must lie in [0, dof * horizon) and increase inside a row"); return SCO_ERR_ARG;
+        }
+    }
+  }
   const int fam = desc->family & 15, span = desc->span > 0 ? desc->span : 1;
   const bool statefam = fam == SCO_FAM_STATE_QUADRATIC || fam == SCO_FAM_STATE_PROGRAM;
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
@@ -1090,10 +1128,19 @@ extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp 
   SCO_ON_DEVICE(device);
   sco_sqp *h = new sco_sqp();
   h->device = device; h->desc = *desc;
+  if (n_rows > 0) {
+    h->gen_ptr.assign(row_ptr, row_ptr + n_rows + 1); h->gen_col.assign(col_idx, col_idx + row_ptr[n_rows]);
+    h->gen_iseq.resize(n_rows);
+    for (int r = 0; r < n_rows; r++) h->gen_iseq[r] = row_is_eq[r] ? 1 : 0;
+  }
   const int rc = sqp_create_impl(h, device, desc);
   if (rc) { sco_sqp_destroy(h); return rc; }       // frees whatever had been allocated
   *out = h;
   return SCO_OK;
+}
+
+extern "C" int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out) {
+  return sco_sqp_create_rows(device, desc, 0, nullptr, nullptr, nullptr, out);
 }
 
 static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc) {
@@ -1113,11 +1160,17 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   const int m_pin = reach ? d : 2 * d, dT1 = d * (T - 1), m_vel = vel ? 2 * dT1 : 0;
   const int m_jl = jl ? 2 * d * T : 0;
   // a hinge row has one slack, an equality row two (prob.py:258, 285-286); block-major, hinge rows of a block first
-  const int R = K * O, n_x = d * T, SB = R + Req, n_slack = NBt * SB + 2 * NE, n = n_x + n_slack, m_lin = m_pin + m_vel + m_jl;
+  // general affine rows (r04): column lists of the CSR pattern; entry k of the pattern = (row, column) in CSR order
+  const int m_gen = (int)h->gen_iseq.size(), nnz_gen = m_gen ? h->gen_ptr[m_gen] : 0;
+  std::vector<std::vector<std::pair<int, int>>> gen_of_col(d * T);       // (row, k), rows ascending
+  for (int r = 0; r < m_gen; r++)
+    for (int k = h->gen_ptr[r]; k < h->gen_ptr[r + 1]; k++) gen_of_col[h->gen_col[k]].push_back({r, k});
+  std::vector<int> gpos0(std::max(nnz_gen, 1), 0), gpos1(std::max(nnz_gen, 1), 0);
+  const int R = K * O, n_x = d * T, SB = R + Req, n_slack = NBt * SB + 2 * NE, n = n_x + n_slack, m_lin = m_pin + m_vel + m_jl + m_gen;
   const int m_nl = NBt * R + NE, m = m_lin + m_nl + n;
   // linear rows of column (t, j), ascending: pin, velocity rows "theta[t] - theta[t-1] <= vmax" (+1),
   // "theta[t+1] - theta[t] <= vmax" (-1), then the two negated rows
-  auto linear_entries = [&](int t, int j, std::vector<int> &Ai, std::vector<double> &Av) {
+  auto linear_entries = [&](int t, int j, std::vector<int> &Ai, std::vector<double> &Av, std::vector<int> &gpos) {
     if (t == 0) { Ai.push_back(j); Av.push_back(1.0); }
     if (t == T - 1 && !reach) { Ai.push_back(d + j); Av.push_back(1.0); }
     if (vel) {
@@ -1130,6 +1183,10 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
       Ai.push_back(m_pin + m_vel + t * d + j); Av.push_back(1.0);
       Ai.push_back(m_pin + m_vel + d * T + t * d + j); Av.push_back(-1.0);
     }
+    for (const auto &rk : gen_of_col[t * d + j]) {        // values per problem (sco_sqp_load_linear_rows): 0 in the constants
+      gpos[rk.second] = (int)Ai.size();
+      Ai.push_back(m_pin + m_vel + m_jl + rk.first); Av.push_back(0.0);
+    }
   };
   std::vector<double> a0c, a1c;
   // ---- projection QP pattern: P = diag, A = [linear rows ; I]
@@ -1140,7 +1197,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
     for (int col = 0; col < n_x; col++) {
       Ap[col] = (int)Ai.size();
       const int t = col / d, j = col % d;
-      linear_entries(t, j, Ai, a0c);
+      linear_entries(t, j, Ai, a0c, gpos0);
       Ai.push_back(m_lin + col); a0c.push_back(1.0);
     }
     Ap[n_x] = (int)Ai.size();
@@ -1167,7 +1224,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
       Ap[col] = (int)Ai.size();
       if (col < n_x) {
         const int t = col / d, j = col % d;
-        linear_entries(t, j, Ai, a1c);
+        linear_entries(t, j, Ai, a1c, gpos1);
         jpos[col] = (int)Ai.size();
         // Jacobian slots: the R rows of every block that covers timestep t (blocks t - S + 1 .. t), in block order
         for (int blk = std::max(0, t - S + 1); blk <= std::min(t, NBt - 1); blk++)
@@ -1208,6 +1265,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
             (desc->family & 15) == SCO_FAM_STATE_PROGRAM ? 3 : 0;
   s.NE = NE; s.NB = NBt + (reach ? 1 : 0); s.RM = std::max(R, NE) + (cost ? 1 : 0);     // + the objective term's value
   s.S = S; s.ds = ds; s.NBt = NBt; s.Req = Req;
+  s.m_gen = m_gen; s.nnz_gen = nnz_gen;
   s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl; s.cost = (desc->family & SCO_FAM_FLAG_OBJ_PROGRAM) ? 2 : cost ? 1 : 0;
   int rc = 0;
 #define AL(f, cnt) if ((rc = sq_alloc(h, (cnt), &s.f))) return rc;
@@ -1246,6 +1304,18 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   { int *p; if ((rc = sq_alloc(h, (size_t)d, &p))) return rc; s.epos = p;
     SCO_HIP(hipMemcpy(p, epos.data(), d * sizeof(int), hipMemcpyHostToDevice)); }
   s.bpos = nullptr;
+  s.gen_eq = s.gpos0 = s.gpos1 = nullptr; s.gen_rhs = s.gen_val = nullptr;
+  if (m_gen) {
+    int *p; double *q;
+    if ((rc = sq_alloc(h, (size_t)m_gen, &p))) return rc;
+    SCO_HIP(hipMemcpy(p, h->gen_iseq.data(), m_gen * sizeof(int), hipMemcpyHostToDevice)); s.gen_eq = p;
+    if ((rc = sq_alloc(h, (size_t)nnz_gen, &p))) return rc;
+    SCO_HIP(hipMemcpy(p, gpos0.data(), nnz_gen * sizeof(int), hipMemcpyHostToDevice)); s.gpos0 = p;
+    if ((rc = sq_alloc(h, (size_t)nnz_gen, &p))) return rc;
+    SCO_HIP(hipMemcpy(p, gpos1.data(), nnz_gen * sizeof(int), hipMemcpyHostToDevice)); s.gpos1 = p;
+    if ((rc = sq_alloc(h, (size_t)B * m_gen, &q))) return rc; s.gen_rhs = q;
+    if ((rc = sq_alloc(h, (size_t)B * nnz_gen, &q))) return rc; s.gen_val = q;
+  }
   return SCO_OK;
 }
 
@@ -1437,6 +1507,24 @@ extern "C" int sco_sqp_load_program_steps(sco_sqp *h, int n_words, const int *wo
   return load_program_impl(h, n_words, words, row_ptr, n_consts, consts, n_params, params, true);
 }
 
+// r04: coefficients vals[batch][nnz] (CSR order of the pattern given to sco_sqp_create_rows) and right-hand sides
+// rhs[batch][n_rows] of the general affine rows; after sco_sqp_load, before sco_sqp_solve; may be called again.
+extern "C" int sco_sqp_load_linear_rows(sco_sqp *h, const double *vals, const double *rhs) {
+  if (!h || !vals || !rhs) { sco_set_error("sco_sqp_load_linear_rows: null pointer"); return SCO_ERR_ARG; }
+  SqpDev &s = h->d;
+  if (!s.m_gen) { sco_set_error("sco_sqp_load_linear_rows: the handle was created without general affine rows"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_load_linear_rows: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  for (size_t i = 0; i < (size_t)s.batch * s.nnz_gen; i++)
+    if (!(fabs(vals[i]) < 1e30)) { sco_set_error("sco_sqp_load_linear_rows: coefficients must be finite"); return SCO_ERR_ARG; }
+  for (size_t i = 0; i < (size_t)s.batch * s.m_gen; i++)
+    if (!(fabs(rhs[i]) < 1e30)) { sco_set_error("sco_sqp_load_linear_rows: right-hand sides must be finite"); return SCO_ERR_ARG; }
+  SCO_ON_DEVICE(h->device);
+  SCO_HIP(hipMemcpy((void *)s.gen_val, vals, (size_t)s.batch * s.nnz_gen * sizeof(double), hipMemcpyHostToDevice));
+  SCO_HIP(hipMemcpy((void *)s.gen_rhs, rhs, (size_t)s.batch * s.m_gen * sizeof(double), hipMemcpyHostToDevice));
+  h->gen_loaded = true; h->solved = false;
+  return SCO_OK;
+}
+
 // r04: weights of the smoothing objective, w[batch][dof] >= 0: sum_t sum_j w_j (theta[t+1][j] - theta[t][j])^2 -- the QuadExpr a
 // caller of the reference builds with a weighted difference matrix (prob.py:88-104, 348-367).  After sco_sqp_load; nullptr
 // restores the unweighted objective.
@@ -1614,6 +1702,9 @@ extern "C" int sco_sqp_solve(sco_sqp *h, const sco_sqp_params *params, const sco
   }
   if ((h->desc.family & SCO_FAM_FLAG_JOINT_LIMITS) && !h->jl_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_joint_limits first"); return SCO_ERR_STATE;
+  }
+  if (h->d.m_gen && !h->gen_loaded) {
+    sco_set_error("sco_sqp_solve: call sco_sqp_load_linear_rows first"); return SCO_ERR_STATE;
   }
   if ((h->desc.family & 15) == SCO_FAM_STATE_PROGRAM && !h->prog_loaded) {
     sco_set_error("sco_sqp_solve: call sco_sqp_load_program first"); return SCO_ERR_STATE;

@@ -455,14 +455,40 @@ def make_program_variant(i, variant, d=2, T=12, noise=0.03, groups=None, vel_lim
     return out
 
 
-def make_problem(i, obj_weights=False, per_step=False, **kw):
+def general_rows(i, d, T, start, goal):
+    """r04: GENERAL affine rows of problem i (prob.add_cnt_expr(BoundExpr(LEqExpr / EqExpr(AffExpr(A, 0), rhs), traj)), prob.py:126-131,
+    317-346): the pattern depends on (d, T) only, coefficients and right-hand sides on the problem.  Inequalities first:
+    for every odd timestep t < T - 1 a coupling of two joints  theta[t][0] + c_t theta[t][1] <= b_t  and a two-step limit
+    theta[t+1][0] - theta[t-1][0] <= g_t; then ONE equality at the middle timestep  theta[m][0] - a theta[m][1] = e.  Right-hand sides
+    sit a margin away from the straight line between start and goal, so some rows are active and the problem stays feasible.
+    Returns dict(A (n_rows, d T) dense, rhs, is_eq)."""
+    rng = np.random.default_rng(8000 + i)
+    s = np.linspace(0.0, 1.0, T)[:, None]
+    line = (1 - s) * start[None, :] + s * goal[None, :]
+    rows, rhs, eq = [], [], []
+    for t in range(1, T - 1, 2):
+        c = rng.uniform(0.5, 1.5)
+        r = np.zeros(d * T); r[t * d] = 1.0; r[t * d + 1] = c
+        rows.append(r); rhs.append(line[t, 0] + c * line[t, 1] + rng.uniform(0.02, 0.3)); eq.append(0)
+        r = np.zeros(d * T); r[(t + 1) * d] = 1.0; r[(t - 1) * d] = -1.0
+        rows.append(r); rhs.append(line[t + 1, 0] - line[t - 1, 0] + rng.uniform(0.02, 0.2)); eq.append(0)
+    m_ = T // 2
+    a = rng.uniform(0.5, 1.5)
+    r = np.zeros(d * T); r[m_ * d] = 1.0; r[m_ * d + 1] = -a
+    rows.append(r); rhs.append(line[m_, 0] - a * line[m_, 1] + rng.uniform(-0.05, 0.05)); eq.append(1)
+    return dict(A=np.array(rows), rhs=np.array(rhs), is_eq=np.array(eq, dtype=np.int32))
+
+
+def make_problem(i, obj_weights=False, per_step=False, lin_rows=False, **kw):
     """Seeded problem i of the batch; see _make_problem for the families.  r04 (wider template):
     obj_weights=True adds per-joint weights w_j in [0.4, 3] of the smoothing objective (``obj_w``; a QuadExpr built from a
     weighted difference matrix, prob.py:88-104, 348-367); per_step=True (program family) gives every timestep its own
     parameter vector (``row_params`` of shape (T, n_params): obstacles that drift and pulse along the horizon -- each
     timestep's Expr closes over its own data, expr.py:22-41).  Both draw from their own generators: every other number of
-    the problem is what it is without them."""
+    the problem is what it is without them.  lin_rows=True adds the general affine rows of ``general_rows`` (``lin_gen``)."""
     out = _make_problem(i, **kw)
+    if lin_rows:
+        out["lin_gen"] = general_rows(i, out["d"], out["T"], out["start"], out["goal"])
     if obj_weights:
         out["obj_w"] = np.random.default_rng(7000 + i).uniform(0.4, 3.0, size=out["d"])
     if per_step:
@@ -553,6 +579,15 @@ def make_batch(B, first=0, **kw):
         extra["jlo"] = np.stack([p["jlo"] for p in probs]); extra["jhi"] = np.stack([p["jhi"] for p in probs])
     if p0.get("obj_w") is not None:
         extra["obj_w"] = np.stack([p["obj_w"] for p in probs])
+    if p0.get("lin_gen") is not None:
+        # shared CSR pattern = the union of the problems' non-zeros (a problem's structural zero is a zero coefficient), values
+        # and right-hand sides per problem (sco_sqp_create_rows / sco_sqp_load_linear_rows)
+        mask = np.any(np.stack([p["lin_gen"]["A"] != 0 for p in probs]), axis=0)
+        row_ptr = np.concatenate([[0], np.cumsum(mask.sum(axis=1))]).astype(np.int32)
+        r, c = np.nonzero(mask)
+        extra["lin_rows"] = (row_ptr, c.astype(np.int32), p0["lin_gen"]["is_eq"].astype(np.int32))
+        extra["lin_vals"] = np.stack([p["lin_gen"]["A"][r, c] for p in probs])
+        extra["lin_rhs"] = np.stack([p["lin_gen"]["rhs"] for p in probs])
     return dict(
         d=p0["d"], T=p0["T"], K=p0["K"], O=p0["O"], B=B, **extra,
         x0=np.stack([p["x0"] for p in probs]),

@@ -59,6 +59,14 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
         prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(mods.AffExpr(-eye, np.zeros((n_x, 1))),
                                                       -np.tile(pr["jlo"], T).reshape(-1, 1)), traj))
 
+    if pr.get("lin_gen") is not None:
+        # r04: general affine rows -- the inequalities as one LEqExpr(AffExpr), the equalities as one EqExpr(AffExpr), on the
+        # whole trajectory (prob.py:126-131, 317-346)
+        g = pr["lin_gen"]
+        for cls, sel in ((mods.LEqExpr, g["is_eq"] == 0), (mods.EqExpr, g["is_eq"] != 0)):
+            if np.any(sel):
+                prob.add_cnt_expr(mods.BoundExpr(cls(mods.AffExpr(g["A"][sel], np.zeros((int(sel.sum()), 1))), g["rhs"][sel].reshape(-1, 1)), traj))
+
     R = pr["K"] * pr["O"]
     step_vars = []
     prog = pr.get("row_program")
