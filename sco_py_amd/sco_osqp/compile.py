@@ -20,7 +20,8 @@ What is read and what it must look like (each test names the reference behaviour
 * objective: one ``QuadExpr`` sum_t |x_{t+1} - x_t|^2 on the whole trajectory (prob.py:348-367), optionally one
   non-quadratic ``DeviceExpr`` objective term per timestep (prob.py:88-104);
 * affine rows in the order they were added (``_osqp_lin_cnt_exprs``, prob.py:317-346): start pin, goal pin, velocity
-  limits, joint limits;
+  limits, joint limits; r04: whatever follows them is taken as general affine rows (equalities and upper bounds over the
+  trajectory atoms) -- a shared sparsity pattern per device batch, coefficients and right-hand sides per problem;
 * non-linear blocks in timestep order (``_nonlin_cnt_exprs``, prob.py:132-142): ``LEqExpr`` (val 0) and ``EqExpr``
   bodies of one device family, same structure at every timestep, per-problem parameters.
 """
@@ -335,8 +336,26 @@ def _compile(prob):
         pr["jlo"], pr["jhi"] = jlo[0].copy(), jhi[0].copy()
     else:
         pos[0] = save
+    lin_key = None
     if pos[0] != len(rows):
-        _no("affine rows outside the template (pins, velocity limits, joint limits, in this order)")
+        # r04: whatever follows is taken as GENERAL affine rows (sco_sqp_create_rows): equalities (lb = ub) and inequalities
+        # (lb = -inf) over the trajectory atoms, pattern = the atoms each row names (prob.py:317-346)
+        rest = rows[pos[0]:]
+        A = np.zeros((len(rest), n_x)); rhs = np.zeros(len(rest)); is_eq = np.zeros(len(rest), dtype=np.int32)
+        for k, r in enumerate(rest):
+            ra = r.osqp_vars.ravel()
+            cs = [col.get(id(a)) for a in ra]
+            if any(c is None for c in cs) or len(set(cs)) != len(cs):
+                _no("an affine row names an atom outside the trajectory (or one twice)")
+            lb_, ub_ = float(np.ravel(r.lb)[0]), float(np.ravel(r.ub)[0])
+            if not np.isfinite(ub_) or not (lb_ == ub_ or lb_ == -np.inf):
+                _no("affine rows are equalities (lb = ub) or upper bounds (lb = -inf)")
+            A[k, cs] = np.asarray(r.coeffs, dtype=np.float64).ravel()
+            rhs[k] = ub_; is_eq[k] = 1 if lb_ == ub_ else 0
+        if np.any(np.sum(A != 0, axis=1) == 0):
+            _no("an affine row without coefficients")
+        pr["lin_gen"] = dict(A=A, rhs=rhs, is_eq=is_eq)
+        lin_key = ((A != 0).tobytes(), is_eq.tobytes())          # problems share a batch when the PATTERN agrees
 
     # ---- groups ---------------------------------------------------------------------------------------------------
     groups = prob._cnt_groups
@@ -356,7 +375,7 @@ def _compile(prob):
     gkey = None if trivial else tuple(tuple(g) for g in block_groups)
 
     key = (d, T, span, n_eq, key_fam, analytic, prox_count, reach_be is not None, "vmax" in pr, "jlo" in pr,
-           "cost_weight" in pr, bool(nq), gkey)
+           "cost_weight" in pr, bool(nq), gkey, lin_key)
     return CompiledProb(key, pr, holders, atoms, gids)
 
 
@@ -413,6 +432,11 @@ def _stack(cps):
             a[k] = st(k)
     if p0.get("groups") is not None:
         a["groups"] = p0["groups"]
+    if p0.get("lin_gen") is not None:
+        from ..batch import rows_pattern
+        row_ptr, col_idx, (r, c) = rows_pattern(p0["lin_gen"]["A"] != 0)
+        a["lin_rows"] = (row_ptr, col_idx, p0["lin_gen"]["is_eq"])
+        a["lin_vals"] = np.stack([cp.pr["lin_gen"]["A"][r, c] for cp in cps]); a["lin_rhs"] = np.stack([cp.pr["lin_gen"]["rhs"] for cp in cps])
     if any(c.pr.get("obj_w") is not None for c in cps):          # weights are values: weighted and plain problems share a batch
         a["obj_w"] = np.stack([np.asarray(c.pr["obj_w"], dtype=np.float64) if c.pr.get("obj_w") is not None else np.ones(p0["d"])
                                for c in cps])
@@ -434,7 +458,7 @@ def run_compiled(cps, params, qp_settings, device=0):
                              joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
                              point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None,
                              program=a.get("row_program") if a.get("row_program") is not None else False,
-                             n_eq_rows=a.get("quad_n_eq", 0))
+                             n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows"))
     _HANDLES[hk] = tb                       # most recently used last
     while len(_HANDLES) > _HANDLE_CAP:
         _HANDLES.pop(next(iter(_HANDLES))).close()
@@ -444,7 +468,8 @@ def run_compiled(cps, params, qp_settings, device=0):
             target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
             cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),
             quad_Q=a.get("quad_Q"), quad_a=a.get("quad_a"), quad_c=a.get("quad_c"),
-            row_program=a.get("row_program"), row_params=a.get("row_params"), obj_weights=a.get("obj_w"))
+            row_program=a.get("row_program"), row_params=a.get("row_params"), obj_weights=a.get("obj_w"),
+            lin_vals=a.get("lin_vals"), lin_rhs=a.get("lin_rhs"))
     if a.get("groups") is not None:
         tb.set_groups(a["groups"])
     t1 = time.perf_counter()

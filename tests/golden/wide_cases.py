@@ -1,7 +1,8 @@
 """Cases of tests/golden/trajopt_wide.npz (r04, the wider device template): (prefix, make_problem kwargs, problem index, analytic_jac).
 w*: per-joint weights of the smoothing objective (a QuadExpr from a weighted difference matrix); ps*: program rows whose
 parameters differ from timestep to timestep (every timestep's Expr closes over its own data); ac* / jk*: constraint blocks on
-THREE and FOUR consecutive timesteps (acceleration and jerk limits as non-linear rows on a Variable of 3 / 4 timesteps)."""
+THREE and FOUR consecutive timesteps (acceleration and jerk limits as non-linear rows on a Variable of 3 / 4 timesteps); lr*:
+GENERAL affine rows (LEqExpr / EqExpr on an AffExpr over the whole trajectory: joint couplings, a two-step limit, one equality)."""
 ARM = dict(d=3, T=6, K=2, O=2)
 P = dict(K=1, program=True)
 CASES = [("w%d_" % i, dict(ARM, obj_weights=True), i, False) for i in range(2)] + \
@@ -17,4 +18,8 @@ CASES = [("w%d_" % i, dict(ARM, obj_weights=True), i, False) for i in range(2)] 
         [("ac%d_" % i, dict(P, d=2, T=8, variant="accel"), i, False) for i in range(2)] + \
         [("acs_", dict(P, d=2, T=8, variant="accel", per_step=True, obj_weights=True), 2, False),
          ("ja_ac_", dict(P, d=3, T=8, variant="accel"), 0, True),
-         ("jk_", dict(P, d=2, T=9, variant="jerk"), 0, False), ("ja_jk_", dict(P, d=2, T=9, variant="jerk", groups="split"), 1, True)]
+         ("jk_", dict(P, d=2, T=9, variant="jerk"), 0, False), ("ja_jk_", dict(P, d=2, T=9, variant="jerk", groups="split"), 1, True)] + \
+        [("lr%d_" % i, dict(ARM, lin_rows=True), i, False) for i in range(2)] + \
+        [("lrv_", dict(ARM, lin_rows=True, vel_limit=0.6, joint_limit=0.3, obj_weights=True), 1, False),
+         ("lrp_", dict(d=2, T=8, K=1, O=3, point=True, lin_rows=True), 0, True),
+         ("lrg_", dict(P, d=2, T=8, lin_rows=True, per_step=True), 1, False)]

@@ -27,6 +27,7 @@ FAMILIES = [
     dict(SMALL, obj_weights=True), dict(SMALL, obj_weights=True, reach=True, vel_limit=0.6), dict(d=2, T=8, program=True, per_step=True),
     dict(d=2, T=6, K=1, program=True, variant="sweep", per_step=True), dict(d=2, T=6, K=1, program=True, variant="attract", per_step=True, obj_weights=True),
     dict(d=2, T=8, K=1, program=True, variant="accel"), dict(d=2, T=9, K=1, program=True, variant="jerk", per_step=True),      # span 3, span 4
+    dict(SMALL, lin_rows=True), dict(SMALL, lin_rows=True, vel_limit=0.6, joint_limit=0.3, obj_weights=True), dict(d=2, T=8, K=1, O=3, point=True, lin_rows=True),
 ]
 
 
@@ -46,6 +47,8 @@ def test_compile_prob_reads_the_problem_record_back_out_of_the_object_api(kw):
             assert cp.pr[k] == v
         elif isinstance(v, bool) or v is None:
             assert bool(cp.pr.get(k)) == bool(v), k
+        elif k == "lin_gen":
+            assert all(np.array_equal(cp.pr[k][f], v[f]) for f in ("A", "rhs", "is_eq"))
         elif k == "row_params" and np.ndim(v) == 2:
             nb = pr["T"] - pr["row_program"].span + 1          # rows of the blocks; the rest belongs to objective terms (or to nobody)
             assert np.shape(cp.pr[k]) == np.shape(v) and np.array_equal(np.asarray(cp.pr[k])[:nb], np.asarray(v)[:nb]), k
@@ -83,7 +86,12 @@ def test_what_compile_prob_declines_and_why():
     declined(prob, "callback")
     prob, traj, *_ = fresh()
     prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(mods.AffExpr(np.ones((1, 18)), np.zeros((1, 1))), np.ones((1, 1))), traj))
-    declined(prob, "outside the template")                                           # a general affine row
+    cp = cc.compile_prob(prob)                                                        # a general affine row: in the template since r04
+    assert cp is not None and cp.pr["lin_gen"]["A"].shape == (1, 18) and cp.pr["lin_gen"]["is_eq"].tolist() == [0] and cp.key[-1] is not None
+    prob, traj, *_ = fresh()
+    extra = mods.OSQPVar("zz_extra"); prob.add_osqp_var(extra)
+    prob._osqp_lin_cnt_exprs.append(mods.OSQPLinearConstraint(np.array([extra]), np.array([1.0]), -1.0, 1.0))
+    assert cc.compile_prob(prob) is None                                              # (an atom outside the trajectory)
     prob, traj, *_ = fresh()
     prob.add_obj_expr(mods.BoundExpr(mods.QuadExpr(np.eye(18), np.zeros((1, 18)), np.zeros((1, 1))), traj))
     declined(prob, "one quadratic objective")

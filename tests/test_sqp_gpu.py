@@ -1184,21 +1184,31 @@ def test_program_reload_with_another_size_and_the_n_eq_rows_check(gpu):
     (dict(d=2, T=8, K=1, program=True, variant="attract", per_step=True, obj_weights=True), False),
     (dict(obj_weights=True), False),
     (dict(d=2, T=8, K=1, program=True, variant="accel"), False), (dict(d=3, T=8, K=1, program=True, variant="accel", per_step=True, vel_limit=0.6), True),
-    (dict(d=2, T=9, K=1, program=True, variant="jerk"), False), (dict(d=2, T=9, K=1, program=True, variant="jerk", groups="split", obj_weights=True), True)],
+    (dict(d=2, T=9, K=1, program=True, variant="jerk"), False), (dict(d=2, T=9, K=1, program=True, variant="jerk", groups="split", obj_weights=True), True),
+    (dict(d=3, T=6, K=2, O=2, lin_rows=True), False), (dict(d=3, T=6, K=2, O=2, lin_rows=True, vel_limit=0.6, joint_limit=0.3, obj_weights=True, reach=True), True),
+    (dict(d=2, T=8, K=1, program=True, lin_rows=True, per_step=True), False), (dict(lin_rows=True), False)],
     ids=["weights", "weights-reach-vel", "weights-objterm", "weights-point-jl-analytic", "steps", "steps-sweep-analytic", "steps-dynamics",
-         "steps-attract-weights", "weights-7x20", "span3", "span3-steps-vel-analytic", "span4", "span4-groups-weights-analytic"])
+         "steps-attract-weights", "weights-7x20", "span3", "span3-steps-vel-analytic", "span4", "span4-groups-weights-analytic",
+         "rows", "rows-vel-jl-weights-reach-analytic", "rows-program-steps", "rows-7x20"])
 def test_wider_template_matches_the_oracle(gpu, kw, analytic):
     """sco_sqp_load_obj_weights: sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 with per-problem, per-joint weights (objective value, P
     of every QP, the degree-2 model of an objective term on top of it); sco_sqp_load_program_steps: block t and the objective
     term of timestep t evaluated with params[problem][t] (values, finite-difference and forward-mode Jacobians, numeric
     Hessians); span 3 and 4: constraint blocks on three / four consecutive timesteps (acceleration and jerk limits, a keep-out
-    on the centroid of four points).  Every decision, QP status, iteration count, merit and the answer against the oracle, which reproduces the
+    on the centroid of four points); sco_sqp_create_rows / sco_sqp_load_linear_rows: general affine rows (a shared CSR pattern,
+    coefficients and right-hand sides per problem; inequalities and an equality) in the projection QP and in every penalty QP.
+    Every decision, QP status, iteration count, merit and the answer against the oracle, which reproduces the
     reference's own runs of these cases (tests/test_golden.py, trajopt_wide.npz)."""
     n = 4 if kw.get("d", 7) == 7 else 8
     arrays, probs = af.make_batch(n, **kw)
     res = sb.solve_batch(arrays, analytic_jac=analytic)
     _compare(res, probs, range(n), analytic=analytic)
     # the extension is live: the same problems without it end elsewhere
+    if kw.get("lin_rows"):
+        g0 = probs[0]["lin_gen"]
+        for b in np.nonzero(res.qp_solves > 1)[0]:                      # (projection feasible) the rows hold at every returned point
+            v = probs[b]["lin_gen"]["A"] @ res.x[b] - probs[b]["lin_gen"]["rhs"]
+            assert v[g0["is_eq"] == 0].max() < 1e-5 and np.abs(v[g0["is_eq"] != 0]).max() < 1e-5
     if kw.get("obj_weights") or kw.get("per_step"):
         plain = {k: v for k, v in arrays.items() if k != "obj_w"}
         if kw.get("per_step"):
@@ -1247,3 +1257,16 @@ def test_wider_template_reloads_and_argument_checks(gpu):
         with pytest.raises(_lib.ScoHipError):
             tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                     row_program=a["row_program"], row_params=a["row_params"], obj_weights=-np.ones((4, 2)))
+        with pytest.raises(ValueError):                                  # no general rows in this handle
+            tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
+                    row_program=a["row_program"], row_params=a["row_params"], lin_vals=np.ones((4, 3)), lin_rhs=np.ones((4, 2)))
+    # patterns are checked before anything is built: a column out of range, columns not increasing, an empty row
+    for rp, ci in (([0, 2], [0, 99]), ([0, 2], [3, 3]), ([0, 0, 1], [1])):
+        with pytest.raises(_lib.ScoHipError):
+            sb.TrajOptBatch(2, 3, 6, 2, 2, lin_rows=(np.array(rp), np.array(ci), np.zeros(len(rp) - 1, dtype=np.int32)))
+    arr, _ = af.make_batch(2, d=3, T=6, K=2, O=2, lin_rows=True)
+    with sb.TrajOptBatch(2, 3, 6, 2, 2, lin_rows=arr["lin_rows"]) as tb2:
+        tb2.load(arr["x0"], arr["start"], arr["goal"], arr["link_len"], arr["point_link"], arr["point_frac"], arr["obstacles"],
+                 lin_vals=arr["lin_vals"], lin_rhs=arr["lin_rhs"])
+        with pytest.raises(ValueError):
+            tb2.load(arr["x0"], arr["start"], arr["goal"], arr["link_len"], arr["point_link"], arr["point_frac"], arr["obstacles"])
