@@ -17,4 +17,6 @@ run 6000 256 parity prog:accel
 run 6000 256 parity prog:jerk ajac
 run 6000 256 parity prog:dynamics ajac
 run 6000 256 parity jl vel
+run 6000 256 parity rows
+run 6000 256 parity rows reach objw
 cat $O
