@@ -288,6 +288,13 @@ int sco_sqp_create(int device, const sco_trajopt_desc *desc, sco_sqp **out);
 int sco_sqp_create_rows(int device, const sco_trajopt_desc *desc, int n_rows, const int *row_ptr, const int *col_idx,
                         const int *row_is_eq, sco_sqp **out);
 int sco_sqp_load_linear_rows(sco_sqp *h, const double *vals, const double *rhs);
+/* r04: TWO kinds of non-linear rows in one problem.  SCO_FAM_STATE_PROGRAM with span 1 and dof >= 2, before sco_sqp_load_program:
+ * the first n_rows rows of every block are keep-out rows  r_o - || x[0:2] - c_o || <= 0  of the point (x[0], x[1]) against
+ * obstacles[problem][0 .. n_rows) of sco_sqp_load (the rows of SCO_FAM_POINT_CIRCLES, closed-form gradients with analytic_jac), the
+ * program supplies the remaining n_obstacles - n_rows rows (its equality rows, if any, stay the last rows of the block).  In the
+ * reference these are two BoundExprs on the same timestep Variable, the circle Expr added first (prob.py:112-144).  n_rows = 0
+ * restores the plain program family; changing it invalidates a loaded program. */
+int sco_sqp_set_circle_rows(sco_sqp *h, int n_rows);
 int sco_sqp_destroy(sco_sqp *h);
 
 /* Upload per-problem data (host pointers, problem-major):

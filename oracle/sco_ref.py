@@ -535,6 +535,12 @@ def trajopt_flat(prob, analytic_jac=False):
                 jac = (lambda th, pr=prob, sl=sl: af.quad_rows_jac(th, pr["quad_Q"][sl], pr["quad_a"][sl], pr["quad_c"][sl])) if analytic_jac else None
                 blocks.append(Block(kind, f, idx, np.zeros(len(range(R)[sl])), jac=jac, groups=gids))
     for t in range(T if not ((prog is not None and (span > 1 or prog.n_eq > 0)) or prob.get("quad_n_eq")) else 0):
+        if prob.get("circle_rows"):              # r04: a second kind of rows on the timestep, added first: the point's keep-out discs
+            nc = prob["circle_rows"]
+            fcir = (lambda th, pr=prob, nc=nc: af.point_dist(th, pr["obstacles"][:nc]))
+            jcir = (lambda th, pr=prob, nc=nc: af.point_dist_jac(th, pr["obstacles"][:nc])) if analytic_jac else None
+            blocks.append(Block("leq", fcir, np.arange(t * d, (t + 1) * d), np.zeros(nc), jac=jcir,
+                                groups=prob["groups"][t] if prob.get("groups") is not None else None))
         if prob.get("row_program") is not None:  # SCO_FAM_STATE_PROGRAM: closed-form rows
             f = prob["row_program"].numpy_fn(af.step_params(prob, t))
             jac = prob["row_program"].numpy_jac(af.step_params(prob, t)) if analytic_jac else None
@@ -549,7 +555,7 @@ def trajopt_flat(prob, analytic_jac=False):
             jac = None
         if analytic_jac and not prob.get("point") and prob.get("quad_Q") is None and prob.get("row_program") is None:
             jac = (lambda th, pr=prob: af.arm_dist_jac(th, pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"]))
-        blocks.append(Block("leq", f, np.arange(t * d, (t + 1) * d), np.zeros(R), jac=jac,
+        blocks.append(Block("leq", f, np.arange(t * d, (t + 1) * d), np.zeros(R - int(prob.get("circle_rows") or 0)), jac=jac,
                             groups=prob["groups"][t] if prob.get("groups") is not None else None))
     if reach:
         f = (lambda th, pr=prob: af.ee_pos(th, pr["link_len"]))

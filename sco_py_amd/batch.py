@@ -58,8 +58,11 @@ class TrajOptBatch(object):
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
                  prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False, point=False,
-                 quadratic=False, program=False, n_eq_rows=0, lin_rows=None):
-        """lin_rows (r04): pattern of GENERAL affine rows over the trajectory variables, shared by the batch:
+                 quadratic=False, program=False, n_eq_rows=0, lin_rows=None, circle_rows=0):
+        """circle_rows (r04, program family, span 1): the first ``circle_rows`` of the ``n_obstacles`` rows of a block are keep-out
+        rows of the point (x[0], x[1]) against ``obstacles[b, :circle_rows]`` -- a second kind of non-linear rows next to the
+        program's (two BoundExprs on one timestep Variable in the reference).
+        lin_rows (r04): pattern of GENERAL affine rows over the trajectory variables, shared by the batch:
         (row_ptr, col_idx, is_eq) in CSR form, column t * dof + j (``rows_pattern`` builds it from a dense 0 / 1 mask) -- the rows
         a caller of the reference adds with prob.add_cnt_expr(BoundExpr(EqExpr / LEqExpr(AffExpr(A, b), val), traj)); values and
         right-hand sides per problem go to ``load(lin_vals=, lin_rhs=)``."""
@@ -100,6 +103,9 @@ class TrajOptBatch(object):
                                 (SCO_FAM_FLAG_EE_COST if self.ee_cost else 0) |
                                 (SCO_FAM_FLAG_OBJ_PROGRAM if self.obj_program else 0),
                                 1 if analytic_jac else 0, int(prox_count), self.span, self.n_eq)
+        self.circle_rows = int(circle_rows)
+        if self.circle_rows and not (self.program and self.span == 1):
+            raise ValueError("circle rows next to program rows: program family, blocks on one timestep")
         self.lin_rows = None
         if lin_rows is not None and len(lin_rows[2]):
             rp = np.ascontiguousarray(lin_rows[0], dtype=np.int32); ci = np.ascontiguousarray(lin_rows[1], dtype=np.int32)
@@ -111,6 +117,8 @@ class TrajOptBatch(object):
                                                        C.byref(self._h)))
         else:
             _lib.check(_lib.load().sco_sqp_create(self.device, C.byref(desc), C.byref(self._h)))
+        if self.circle_rows:
+            _lib.check(_lib.load().sco_sqp_set_circle_rows(self._h, self.circle_rows))
 
     def close(self):
         if self._h:
@@ -158,12 +166,12 @@ class TrajOptBatch(object):
         if self.program:
             if row_program is None:
                 raise ValueError("the program family needs row_program (sco_py_amd.rowexpr.compile_rows) and row_params (B, n_params)")
-            if row_program.n_rows != O or row_program.n_state > d * self.span or row_program.span != self.span or \
+            if row_program.n_rows != O - self.circle_rows or row_program.n_state > d * self.span or row_program.span != self.span or \
                     row_program.n_eq != self.n_eq or row_program.objective != self.obj_program:
                 raise ValueError("the program has %d rows (%d equalities) over %d state coordinates, span %d, objective term %s; the "
                                  "batch was created for %d rows per block (%d equalities), dof %d, span %d, objective term %s"
                                  % (row_program.n_rows, row_program.n_eq, row_program.n_state, row_program.span, row_program.objective,
-                                    O, self.n_eq, d, self.span, self.obj_program))
+                                    O - self.circle_rows, self.n_eq, d, self.span, self.obj_program))
             npar = row_program.n_params
             per_step = npar > 0 and row_params is not None and np.ndim(row_params) == 3
             if per_step:
@@ -296,7 +304,7 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
                       joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
                       point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None,
                       program=a.get("row_program") if a.get("row_program") is not None else False,
-                      n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows")) as tb:
+                      n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows"), circle_rows=a.get("circle_rows", 0)) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                 target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
                 cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),

@@ -68,6 +68,9 @@ struct SqpDev {
   double *qQ, *qa, *qc;   // [B][O][d*d], [B][O][d], [B][O]
                      // 3 SCO_FAM_STATE_PROGRAM: rows as postfix programs (shared) over the state and per-problem parameters
   const int *pw, *pptr; const double *pconst; const double *ppar; int n_par;
+  int R1;            // r04 (SCO_FAM_STATE_PROGRAM): the first R1 rows of a block are keep-out rows of the point (x[0], x[1]) against
+                     // obstacles[b][0 .. R1) as in SCO_FAM_POINT_CIRCLES -- a SECOND kind of non-linear rows on the same Variable
+                     // (sco_sqp_set_circle_rows); programs supply the remaining O - R1 rows
   int par_step;      // r04: 0 = one parameter vector per problem; n_par = one per problem AND timestep (sco_sqp_load_program_steps:
                      // block t and the objective term of timestep t read params[problem][t])
   const double *objw;     // r04: [B][d] weights of the smoothing objective sum_t sum_j w_j (x[t+1][j] - x[t][j])^2, nullptr = all 1
@@ -319,7 +322,7 @@ __device__ __forceinline__ RowRef row_ref(int e, const RowLay &L) {
 
 struct RowCtx { const double *len, *obs, *target; const int *point_link; const double *point_frac; int d, O, point;
                 const double *qQ, *qa, *qc;         // SCO_FAM_STATE_QUADRATIC: this problem's row coefficients (point == 2)
-                const int *pw, *pptr; const double *pconst, *ppar; int par_step; };   // SCO_FAM_STATE_PROGRAM (point == 3): words, row starts, constants, this problem's parameters (block t: ppar + t * par_step)
+                const int *pw, *pptr; const double *pconst, *ppar; int par_step, R1; };   // SCO_FAM_STATE_PROGRAM (point == 3): words, row starts, constants, this problem's parameters (block t: ppar + t * par_step)
 // (for the state families `d` is the dimension of a BLOCK's state, span x dof)
 
 // SCO_FAM_STATE_PROGRAM: value of program `o` at th, up to two coordinates perturbed (finite differences)
@@ -382,7 +385,13 @@ __device__ __forceinline__ double prog_dual(const RowCtx &c, const double *par, 
 __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, const double *th, int pert, double h) {
   if (q.eq == 1) return arm_ee(th, c.len, c.d, q.r, pert, h);
   const int kp = q.r / c.O, o = q.r % c.O;
-  if (c.point == 3) return prog_eval(c, c.ppar + q.t * c.par_step, o, th, pert, h, -1, 0.0);      // SCO_FAM_STATE_PROGRAM: the row's postfix program
+  if (c.point == 3) {                          // SCO_FAM_STATE_PROGRAM: the row's postfix program; r04: behind R1 circle rows of the point x[0:2]
+    if (q.r < c.R1) {
+      const double dx = th[0] + (pert == 0 ? h : 0.0) - c.obs[3 * q.r], dy = th[1] + (pert == 1 ? h : 0.0) - c.obs[3 * q.r + 1];
+      return c.obs[3 * q.r + 2] - sqrt(dx * dx + dy * dy);
+    }
+    return prog_eval(c, c.ppar + q.t * c.par_step, q.r - c.R1, th, pert, h, -1, 0.0);
+  }
   if (c.point == 2) {                          // SCO_FAM_STATE_QUADRATIC: 1/2 x' Q x + a' x + c of row o
     const double *Q = c.qQ + (size_t)o * c.d * c.d, *av = c.qa + (size_t)o * c.d;
     double val = c.qc[o];
@@ -403,7 +412,14 @@ __device__ __forceinline__ double row_value(const RowCtx &c, const RowRef &q, co
 __device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, const double *th, int j) {
   if (q.eq == 1) return arm_ee_grad(th, c.len, c.d, q.r, j);
   const int kp = q.r / c.O, o = q.r % c.O;
-  if (c.point == 3) return prog_dual(c, c.ppar + q.t * c.par_step, o, th, j);      // forward-mode differentiation of the row's program (r03)
+  if (c.point == 3) {                          // forward-mode differentiation of the row's program (r03); circle rows in closed form
+    if (q.r < c.R1) {
+      if (j > 1) return 0.0;
+      const double dx = th[0] - c.obs[3 * q.r], dy = th[1] - c.obs[3 * q.r + 1];
+      return -(j == 0 ? dx : dy) / sqrt(dx * dx + dy * dy);
+    }
+    return prog_dual(c, c.ppar + q.t * c.par_step, q.r - c.R1, th, j);
+  }
   if (c.point == 2) {                          // a_j + sum_i Q_ji x_i  (Q symmetric)
     const double *Q = c.qQ + (size_t)o * c.d * c.d;
     double g = c.qa[(size_t)o * c.d + j];
@@ -421,7 +437,7 @@ __device__ __forceinline__ double row_grad(const RowCtx &c, const RowRef &q, con
 // (SCO_FAM_FLAG_EE_COST) or the objective program (SCO_FAM_FLAG_OBJ_PROGRAM: program index O)
 struct ObjCtx { int kind; const double *len; int d; double tx, ty, w; };
 __device__ __forceinline__ double obj_value(const ObjCtx &oc, const RowCtx &c, int t, const double *th, int pi, double hi, int pj, double hj) {
-  if (oc.kind == 2) return prog_eval(c, c.ppar + t * c.par_step, c.O, th, pi, hi, pj, hj);
+  if (oc.kind == 2) return prog_eval(c, c.ppar + t * c.par_step, c.O - c.R1, th, pi, hi, pj, hj);
   return arm_ee_cost(th, oc.len, oc.d, oc.tx, oc.ty, oc.w, pi, hi, pj, hj);
 }
 __device__ __forceinline__ double row_rhs(const RowCtx &c, const RowRef &q) { return q.eq == 1 ? c.target[q.r] : 0.0; }
@@ -616,7 +632,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
     const int H = s.H, HC = s.HC, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
     const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, ds, O, s.point,
                   s.qQ + (size_t)b * O * ds * ds, s.qa + (size_t)b * O * ds, s.qc + (size_t)b * O,
-                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step};
+                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step, s.R1};
     double *hkey = s.hkey + (size_t)b * NB * H * ds, *hval = s.hval + (size_t)b * NB * H * RM;
     double *ckey = s.ckey + (size_t)b * NB * HC * ds, *cJ = s.cJ + (size_t)b * NB * HC * RM * ds, *cb = s.cb + (size_t)b * NB * HC * RM;
     int *hn = s.hn + (size_t)b * NB, *cn = s.cn + (size_t)b * NB;
@@ -881,7 +897,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   const int H = s.H, NB = s.NB, RM = s.RM, m_nl = s.m_nl;
   const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, ds, O, s.point,
                   s.qQ + (size_t)b * O * ds * ds, s.qa + (size_t)b * O * ds, s.qc + (size_t)b * O,
-                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step};
+                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step, s.R1};
   double *hkey = s.hkey + (size_t)b * NB * H * ds, *hval = s.hval + (size_t)b * NB * H * RM;
   int *hn = s.hn + (size_t)b * NB;
   for (int t = tid; t < NB; t += SCO_BLOCK)
@@ -1042,7 +1058,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *
   const double *obs = s.obstacles + (size_t)b * O * 3;
   const RowCtx rc{len, obs, s.target + (size_t)b * 2, s.point_link, s.point_frac, s.ds, O, s.point,
                   s.qQ + (size_t)b * O * s.ds * s.ds, s.qa + (size_t)b * O * s.ds, s.qc + (size_t)b * O,
-                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step};
+                  s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step, s.R1};
   const RowLay L{T, s.NBt, R, s.Req};
   double v[3] = {traj_obj_partial(x, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr), 0.0, 0.0};
   if (s.cost)
@@ -1440,7 +1456,7 @@ static int load_program_impl(sco_sqp *h, int n_words, const int *words, const in
   if ((h->desc.family & 15) != SCO_FAM_STATE_PROGRAM) { sco_set_error("sco_sqp_load_program: family has no row programs"); return SCO_ERR_ARG; }
   if (!h->loaded) { sco_set_error("sco_sqp_load_program: call sco_sqp_load first"); return SCO_ERR_STATE; }
   // the rows of a block, then (SCO_FAM_FLAG_OBJ_PROGRAM) the objective term of a timestep
-  const int R = h->d.O + (h->d.cost == 2 ? 1 : 0), ds = h->d.ds;
+  const int R = h->d.O - h->d.R1 + (h->d.cost == 2 ? 1 : 0), ds = h->d.ds;       // (r04: R1 leading rows of a block are circle rows)
   if (n_words <= 0 || n_consts < 0 || n_params < 0) { sco_set_error("sco_sqp_load_program: bad program layout"); return SCO_ERR_ARG; }
   // the whole of row_ptr is checked BEFORE any word is read through it: 0 = first entry, strictly increasing, last = n_words
   if (row_ptr[0] != 0) { sco_set_error("sco_sqp_load_program: bad program layout"); return SCO_ERR_ARG; }
@@ -1452,7 +1468,7 @@ static int load_program_impl(sco_sqp *h, int n_words, const int *words, const in
     if (words[2 * (row_ptr[r + 1] - 1)] != SCO_OP_END) {
       sco_set_error("sco_sqp_load_program: a row's program must end with SCO_OP_END"); return SCO_ERR_ARG;
     }
-    const int nx = r < h->d.O ? ds : h->d.d;      // the objective term sees one timestep
+    const int nx = r < h->d.O - h->d.R1 ? ds : h->d.d;      // the objective term sees one timestep
     int sp = 0;
     for (int w = row_ptr[r]; w < row_ptr[r + 1] - 1; w++) {
       const int op = words[2 * w], arg = words[2 * w + 1];
@@ -1505,6 +1521,21 @@ extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, c
 extern "C" int sco_sqp_load_program_steps(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts,
                                           const double *consts, int n_params, const double *params) {
   return load_program_impl(h, n_words, words, row_ptr, n_consts, consts, n_params, params, true);
+}
+
+// r04: two kinds of non-linear rows in one problem.  SCO_FAM_STATE_PROGRAM, span 1, before sco_sqp_load_program: the first n_rows
+// rows of every block are keep-out rows r_o - || x[0:2] - c_o || of the point (x[0], x[1]) against obstacles[b][0 .. n_rows) of
+// sco_sqp_load (SCO_FAM_POINT_CIRCLES' rows); the program supplies the remaining n_obstacles - n_rows rows.  In the reference: two
+// BoundExprs on the same timestep Variable, the circle Expr added first (prob.py:112-144).  0 restores the plain program family.
+extern "C" int sco_sqp_set_circle_rows(sco_sqp *h, int n_rows) {
+  if (!h) { sco_set_error("sco_sqp_set_circle_rows: null pointer"); return SCO_ERR_ARG; }
+  if ((h->desc.family & 15) != SCO_FAM_STATE_PROGRAM || h->d.S != 1 || h->d.d < 2) {
+    sco_set_error("sco_sqp_set_circle_rows: program family on single timesteps with dof >= 2 only"); return SCO_ERR_ARG;
+  }
+  if (n_rows < 0 || n_rows >= h->d.O || n_rows > h->d.O - h->d.Req - 1 + 1) { sco_set_error("sco_sqp_set_circle_rows: 0 <= n_rows < rows per block, equality rows belong to the program"); return SCO_ERR_ARG; }
+  if (n_rows != h->d.R1) { h->prog_loaded = false; h->solved = false; }       // the program's row count changes with it
+  h->d.R1 = n_rows;
+  return SCO_OK;
 }
 
 // r04: coefficients vals[batch][nnz] (CSR order of the pattern given to sco_sqp_create_rows) and right-hand sides

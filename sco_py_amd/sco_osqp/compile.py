@@ -134,6 +134,19 @@ def _compile(prob):
         blocks[t].append(be)
 
     fam = first.kind
+    blocks_all = [list(bl) for bl in blocks]
+    circ = None
+    if fam == "point_circles" and all(len(bl) >= 2 and bl[1].expr.expr.kind == "program" for bl in blocks):
+        # r04: two kinds of non-linear rows on every timestep Variable -- the point's keep-out discs first, then program rows
+        # (sco_sqp_set_circle_rows)
+        circ = [bl[0] for bl in blocks]
+        if any(type(be.expr) is not ex.LEqExpr or be.expr.expr.kind != "point_circles" or
+               not _same(be.expr.expr.obstacles, circ[0].expr.expr.obstacles) for be in circ):
+            _no("the circle rows in front of the program rows are one LEqExpr per timestep with per-problem obstacles")
+        blocks = [bl[1:] for bl in blocks]
+        fam = "program"
+        if blocks[0][0].expr.expr.program.span != 1:
+            _no("circle rows go with program rows on single timesteps")
     pr = dict(d=d, T=T, reach=reach_be is not None, link_len=np.ones(d), point_link=np.zeros(1, dtype=np.int32),
               point_frac=np.ones(1))
     n_eq = 0
@@ -209,7 +222,12 @@ def _compile(prob):
         else:
             par = step_par[0].copy()
         pr.update(K=1, O=prog.n_rows, obstacles=np.zeros((prog.n_rows, 3)), row_program=prog, row_params=par)
-        key_fam = ("program", id(prog), per_step)
+        nc = 0
+        if circ is not None:
+            cobs = np.asarray(circ[0].expr.expr.obstacles, dtype=np.float64)
+            nc = int(cobs.shape[0])
+            pr.update(O=nc + prog.n_rows, obstacles=np.concatenate([cobs, np.zeros((prog.n_rows, 3))]), circle_rows=nc)
+        key_fam = ("program", id(prog), per_step, nc)
     else:
         _no("no device family for %r" % fam)
 
@@ -359,7 +377,7 @@ def _compile(prob):
 
     # ---- groups ---------------------------------------------------------------------------------------------------
     groups = prob._cnt_groups
-    block_bes = [bl for bl in blocks] + ([[reach_be]] if reach_be is not None else [])
+    block_bes = [bl for bl in blocks_all] + ([[reach_be]] if reach_be is not None else [])
     gids = sorted(groups.keys())
     block_groups = []
     for bl in block_bes:
@@ -432,6 +450,8 @@ def _stack(cps):
             a[k] = st(k)
     if p0.get("groups") is not None:
         a["groups"] = p0["groups"]
+    if p0.get("circle_rows"):
+        a["circle_rows"] = p0["circle_rows"]
     if p0.get("lin_gen") is not None:
         from ..batch import rows_pattern
         row_ptr, col_idx, (r, c) = rows_pattern(p0["lin_gen"]["A"] != 0)
@@ -458,7 +478,7 @@ def run_compiled(cps, params, qp_settings, device=0):
                              joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
                              point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None,
                              program=a.get("row_program") if a.get("row_program") is not None else False,
-                             n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows"))
+                             n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows"), circle_rows=a.get("circle_rows", 0))
     _HANDLES[hk] = tb                       # most recently used last
     while len(_HANDLES) > _HANDLE_CAP:
         _HANDLES.pop(next(iter(_HANDLES))).close()

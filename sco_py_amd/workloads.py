@@ -479,7 +479,7 @@ def general_rows(i, d, T, start, goal):
     return dict(A=np.array(rows), rhs=np.array(rhs), is_eq=np.array(eq, dtype=np.int32))
 
 
-def make_problem(i, obj_weights=False, per_step=False, lin_rows=False, **kw):
+def make_problem(i, obj_weights=False, per_step=False, lin_rows=False, circles=0, **kw):
     """Seeded problem i of the batch; see _make_problem for the families.  r04 (wider template):
     obj_weights=True adds per-joint weights w_j in [0.4, 3] of the smoothing objective (``obj_w``; a QuadExpr built from a
     weighted difference matrix, prob.py:88-104, 348-367); per_step=True (program family) gives every timestep its own
@@ -487,6 +487,18 @@ def make_problem(i, obj_weights=False, per_step=False, lin_rows=False, **kw):
     timestep's Expr closes over its own data, expr.py:22-41).  Both draw from their own generators: every other number of
     the problem is what it is without them.  lin_rows=True adds the general affine rows of ``general_rows`` (``lin_gen``)."""
     out = _make_problem(i, **kw)
+    if circles:
+        # r04: a SECOND kind of non-linear rows on every timestep: `circles` keep-out discs for the point (x[0], x[1]) IN FRONT of the
+        # program's rows -- two BoundExprs on one timestep Variable (prob.py:112-144)
+        prog = out.get("row_program")
+        if prog is None or prog.span != 1:
+            raise ValueError("circles: program family with blocks on one timestep")
+        rng = np.random.default_rng(6000 + i)
+        along = np.sort(rng.uniform(0.25, 0.75, size=circles))
+        centre = (1 - along[:, None]) * out["start"][None, :2] + along[:, None] * out["goal"][None, :2] + 0.06 * rng.standard_normal((circles, 2))
+        obs = np.zeros((circles + prog.n_rows, 3))
+        obs[:circles, :2] = centre; obs[:circles, 2] = rng.uniform(0.06, 0.14, size=circles)
+        out["obstacles"] = obs; out["O"] = circles + prog.n_rows; out["circle_rows"] = int(circles)
     if lin_rows:
         out["lin_gen"] = general_rows(i, out["d"], out["T"], out["start"], out["goal"])
     if obj_weights:
@@ -579,6 +591,8 @@ def make_batch(B, first=0, **kw):
         extra["jlo"] = np.stack([p["jlo"] for p in probs]); extra["jhi"] = np.stack([p["jhi"] for p in probs])
     if p0.get("obj_w") is not None:
         extra["obj_w"] = np.stack([p["obj_w"] for p in probs])
+    if p0.get("circle_rows"):
+        extra["circle_rows"] = p0["circle_rows"]
     if p0.get("lin_gen") is not None:
         # shared CSR pattern = the union of the problems' non-zeros (a problem's structural zero is a zero coefficient), values
         # and right-hand sides per problem (sco_sqp_create_rows / sco_sqp_load_linear_rows)

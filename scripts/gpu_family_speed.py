@@ -12,6 +12,7 @@ for name, kw in (("circles", {}), ("reach", dict(reach=True)), ("vel", dict(vel_
                  # r04, the wider template: general affine rows, weighted smoothing objective (any family), program parameters per timestep
                  ("circles+rows", dict(lin_rows=True)), ("circles+weights", dict(obj_weights=True)), ("vel+weights", dict(vel_limit=0.3, obj_weights=True)),
                  ("program d=2 T=20", dict(d=2, T=20, K=1, program=True)), ("program+steps", dict(d=2, T=20, K=1, program=True, per_step=True)),
+                 ("program+circles (two kinds)", dict(d=2, T=20, K=1, program=True, circles=3)),
                  ("sweep+steps (span 2)", dict(d=2, T=20, K=1, program=True, variant="sweep", per_step=True)),
                  ("attract+steps+weights", dict(d=2, T=20, K=1, program=True, variant="attract", per_step=True, obj_weights=True)),
                  # shapes other than 7 x 20 on the patterns the wavefront tier takes (which tier is faster where)

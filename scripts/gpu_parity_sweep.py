@@ -20,6 +20,7 @@ for tok in sys.argv[4:]:                                         # reach, vel, g
         KW.update(program=True, variant=v, d=3 if v in ("dynamics", "curve") else 2, T=10, K=1)
     if tok == "objw": KW["obj_weights"] = True                                     # r04: weighted smoothing objective
     if tok == "steps": KW["per_step"] = True                                       # r04: program parameters per timestep
+    if tok == "circles": KW["circles"] = 2                                         # r04: two kinds of non-linear rows (with prog)
     if tok == "rows": KW["lin_rows"] = True                                        # r04: general affine rows
     if tok == "ajac": AJ = True
 AJ = "ajac" in sys.argv[4:]

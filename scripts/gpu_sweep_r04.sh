@@ -19,4 +19,6 @@ run 6000 256 parity prog:dynamics ajac
 run 6000 256 parity jl vel
 run 6000 256 parity rows
 run 6000 256 parity rows reach objw
+run 6000 256 parity prog circles
+run 6000 256 parity prog:attract circles steps rows
 cat $O

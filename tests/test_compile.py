@@ -28,6 +28,7 @@ FAMILIES = [
     dict(d=2, T=6, K=1, program=True, variant="sweep", per_step=True), dict(d=2, T=6, K=1, program=True, variant="attract", per_step=True, obj_weights=True),
     dict(d=2, T=8, K=1, program=True, variant="accel"), dict(d=2, T=9, K=1, program=True, variant="jerk", per_step=True),      # span 3, span 4
     dict(SMALL, lin_rows=True), dict(SMALL, lin_rows=True, vel_limit=0.6, joint_limit=0.3, obj_weights=True), dict(d=2, T=8, K=1, O=3, point=True, lin_rows=True),
+    dict(d=2, T=8, K=1, program=True, circles=2), dict(d=2, T=8, K=1, program=True, variant="attract", circles=1, per_step=True, groups="split"),   # two kinds of rows
 ]
 
 

@@ -1186,17 +1186,21 @@ def test_program_reload_with_another_size_and_the_n_eq_rows_check(gpu):
     (dict(d=2, T=8, K=1, program=True, variant="accel"), False), (dict(d=3, T=8, K=1, program=True, variant="accel", per_step=True, vel_limit=0.6), True),
     (dict(d=2, T=9, K=1, program=True, variant="jerk"), False), (dict(d=2, T=9, K=1, program=True, variant="jerk", groups="split", obj_weights=True), True),
     (dict(d=3, T=6, K=2, O=2, lin_rows=True), False), (dict(d=3, T=6, K=2, O=2, lin_rows=True, vel_limit=0.6, joint_limit=0.3, obj_weights=True, reach=True), True),
-    (dict(d=2, T=8, K=1, program=True, lin_rows=True, per_step=True), False), (dict(lin_rows=True), False)],
+    (dict(d=2, T=8, K=1, program=True, lin_rows=True, per_step=True), False), (dict(lin_rows=True), False),
+    (dict(d=2, T=8, K=1, program=True, circles=2), False), (dict(d=2, T=8, K=1, program=True, variant="attract", circles=1, per_step=True, groups="split"), False),
+    (dict(d=3, T=6, K=1, program=True, circles=2, lin_rows=True, obj_weights=True), True), (dict(d=2, T=20, K=1, program=True, circles=3), False)],
     ids=["weights", "weights-reach-vel", "weights-objterm", "weights-point-jl-analytic", "steps", "steps-sweep-analytic", "steps-dynamics",
          "steps-attract-weights", "weights-7x20", "span3", "span3-steps-vel-analytic", "span4", "span4-groups-weights-analytic",
-         "rows", "rows-vel-jl-weights-reach-analytic", "rows-program-steps", "rows-7x20"])
+         "rows", "rows-vel-jl-weights-reach-analytic", "rows-program-steps", "rows-7x20",
+         "two-kinds", "two-kinds-attract-steps-groups", "two-kinds-rows-weights-analytic", "two-kinds-2x20"])
 def test_wider_template_matches_the_oracle(gpu, kw, analytic):
     """sco_sqp_load_obj_weights: sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 with per-problem, per-joint weights (objective value, P
     of every QP, the degree-2 model of an objective term on top of it); sco_sqp_load_program_steps: block t and the objective
     term of timestep t evaluated with params[problem][t] (values, finite-difference and forward-mode Jacobians, numeric
     Hessians); span 3 and 4: constraint blocks on three / four consecutive timesteps (acceleration and jerk limits, a keep-out
     on the centroid of four points); sco_sqp_create_rows / sco_sqp_load_linear_rows: general affine rows (a shared CSR pattern,
-    coefficients and right-hand sides per problem; inequalities and an equality) in the projection QP and in every penalty QP.
+    coefficients and right-hand sides per problem; inequalities and an equality) in the projection QP and in every penalty QP;
+    sco_sqp_set_circle_rows: two kinds of non-linear rows per timestep (the point's keep-out discs in front of program rows).
     Every decision, QP status, iteration count, merit and the answer against the oracle, which reproduces the
     reference's own runs of these cases (tests/test_golden.py, trajopt_wide.npz)."""
     n = 4 if kw.get("d", 7) == 7 else 8
@@ -1260,6 +1264,13 @@ def test_wider_template_reloads_and_argument_checks(gpu):
         with pytest.raises(ValueError):                                  # no general rows in this handle
             tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                     row_program=a["row_program"], row_params=a["row_params"], lin_vals=np.ones((4, 3)), lin_rhs=np.ones((4, 2)))
+    with pytest.raises(ValueError):                                      # circle rows: program family on single timesteps
+        sb.TrajOptBatch(2, 3, 6, 2, 2, circle_rows=1)
+    am, _ = af.make_batch(2, d=2, T=8, K=1, program=True, circles=2)
+    with pytest.raises(ValueError):                                      # the program supplies O - circle_rows rows
+        with sb.TrajOptBatch(2, 2, 8, 1, am["O"], program=am["row_program"], circle_rows=1) as tbm:
+            tbm.load(am["x0"], am["start"], am["goal"], am["link_len"], am["point_link"], am["point_frac"], am["obstacles"],
+                     row_program=am["row_program"], row_params=am["row_params"])
     # patterns are checked before anything is built: a column out of range, columns not increasing, an empty row
     for rp, ci in (([0, 2], [0, 99]), ([0, 2], [3, 3]), ([0, 0, 1], [1])):
         with pytest.raises(_lib.ScoHipError):

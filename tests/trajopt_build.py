@@ -114,6 +114,19 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
     for t in range(0 if wide else T):
         sv = mods.Variable(atoms[t * d:(t + 1) * d, :], pr["x0"][t * d:(t + 1) * d].reshape(d, 1).copy())
         step_vars.append(sv)
+        if pr.get("circle_rows"):
+            # r04: a second kind of non-linear rows on the same Variable, added first: the point's keep-out discs
+            nc = pr["circle_rows"]
+
+            def fc_(x, pr=pr, nc=nc):
+                return af.point_dist(x.ravel(), pr["obstacles"][:nc]).reshape(-1, 1)
+
+            def gc_(x, pr=pr, nc=nc):
+                return af.point_dist_jac(x.ravel(), pr["obstacles"][:nc])
+            ec = mods.Expr(fc_, gc_) if analytic_jac else mods.Expr(fc_)
+            if dx is not None:
+                ec = dx.PointCirclesExpr(pr["obstacles"][:nc], analytic=analytic_jac)
+            prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(ec, np.zeros((nc, 1))), sv), pr["groups"][t] if pr.get("groups") is not None else None)
 
         def f(x, pr=pr, t=t):
             if pr.get("row_program") is not None:    # program family: the compiled rows as a NumPy callable
@@ -143,7 +156,7 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
                  dx.PointCirclesExpr(pr["obstacles"], analytic=analytic_jac) if pr.get("point") else
                  dx.ArmCirclesExpr(pr["link_len"], pr["point_link"], pr["point_frac"], pr["obstacles"], analytic=analytic_jac))
         gids = pr["groups"][t] if pr.get("groups") is not None else None
-        prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(e, np.zeros((R, 1))), sv), gids)
+        prob.add_cnt_expr(mods.BoundExpr(mods.LEqExpr(e, np.zeros((R - int(pr.get("circle_rows") or 0), 1))), sv), gids)
     if prog is not None and prog.objective:
         # the program family's objective term: one plain Expr per timestep Variable (prob.py:88-104), degree-2 convexified
         for t in range(T):
