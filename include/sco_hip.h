@@ -257,6 +257,11 @@ void sco_sqp_default_params(sco_sqp_params *p);
                                   every SQP iteration exactly like SCO_FAM_FLAG_EE_COST (numeric Hessian, eigenvalue shift,
                                   numeric gradient, expr.py:102-156; model into P and q, prob.py:348-367) */
 
+#define SCO_FAM_FLAG_ACC_COST 256     /* r04, any family: the quadratic objective carries an ACCELERATION term
+                                  sum_t sum_j a_j (theta[t+2][j] - 2 theta[t+1][j] + theta[t][j])^2 next to the velocity term (a QuadExpr built
+                                  from first and second difference matrices, prob.py:88-104, 348-367): P gets its second
+                                  super-diagonal block; weights via sco_sqp_load_acc_weights (0 until then); horizon >= 3 */
+
 typedef struct sco_trajopt_desc {
   int batch;
   int dof;
@@ -333,6 +338,8 @@ int sco_sqp_load_program_steps(sco_sqp *h, int n_words, const int *words, const 
  * i.e. the QuadExpr a caller of the reference builds from a weighted difference matrix (prob.py:88-104, 348-367; the unweighted
  * form is the default).  After sco_sqp_load; NULL restores all weights 1.  Any family. */
 int sco_sqp_load_obj_weights(sco_sqp *h, const double *w);
+/* SCO_FAM_FLAG_ACC_COST only, after sco_sqp_load: a[batch][dof] finite and >= 0; NULL = all 0. */
+int sco_sqp_load_acc_weights(sco_sqp *h, const double *a);
 /* SCO_FAM_FLAG_VEL_LIMITS only, after sco_sqp_load: vmax[batch] > 0, one limit per problem. */
 int sco_sqp_load_vel_limit(sco_sqp *h, const double *vmax);
 /* SCO_FAM_FLAG_JOINT_LIMITS only, after sco_sqp_load: lo[batch][dof] < hi[batch][dof]. */

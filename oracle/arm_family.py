@@ -7,4 +7,4 @@ module only re-exports them under the name the oracle and the golden generators 
 from sco_py_amd.workloads import (arm_dist, arm_dist_jac, block_groups, default_points, ee_cost, ee_jac, ee_pos,  # noqa: F401
                                   joint_limit_rows, link_points, make_batch, corridor_program, make_point_problem, make_problem,
                                   make_program_problem, make_quadratic_problem,
-                                  point_dist, point_dist_jac, quad_rows, quad_rows_jac, step_params, velocity_rows)
+                                  point_dist, point_dist_jac, quad_rows, quad_rows_jac, smooth_Q, step_params, velocity_rows)

@@ -479,12 +479,9 @@ def trajopt_flat(prob, analytic_jac=False):
     from . import arm_family as af
     d, T = prob["d"], prob["T"]
     n_x = d * T
-    Q = sp.lil_matrix((n_x, n_x))
-    ow = prob["obj_w"] if prob.get("obj_w") is not None else np.ones(d)      # r04: per-joint weights of the smoothing objective
-    for t in range(T - 1):
-        for j in range(d):
-            a, b = t * d + j, (t + 1) * d + j
-            Q[a, a] += 2.0 * ow[j]; Q[b, b] += 2.0 * ow[j]; Q[a, b] -= 2.0 * ow[j]; Q[b, a] -= 2.0 * ow[j]
+    # r04: per-joint weights of the smoothing objective and an acceleration term (workloads.smooth_Q: the matrix the object-API
+    # builder hands to QuadExpr)
+    Q = sp.lil_matrix(af.smooth_Q(d, T, prob.get("obj_w"), prob.get("acc_w")))
     reach = bool(prob.get("reach"))
     lin = sp.lil_matrix((d if reach else 2 * d, n_x))
     for j in range(d):

@@ -84,6 +84,7 @@ ABI = {
     "sco_sqp_load_program": (C.c_int, [C.c_void_p, C.c_int, _IP, _IP, C.c_int, _DP, C.c_int, _DP]),
     "sco_sqp_load_program_steps": (C.c_int, [C.c_void_p, C.c_int, _IP, _IP, C.c_int, _DP, C.c_int, _DP]),
     "sco_sqp_load_obj_weights": (C.c_int, [C.c_void_p, _DP]),
+    "sco_sqp_load_acc_weights": (C.c_int, [C.c_void_p, _DP]),
     "sco_sqp_load_linear_rows": (C.c_int, [C.c_void_p, _DP, _DP]),
     "sco_sqp_set_circle_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "sco_sqp_load_vel_limit": (C.c_int, [C.c_void_p, _DP]),

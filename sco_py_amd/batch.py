@@ -24,6 +24,7 @@ SCO_FAM_FLAG_VEL_LIMITS = 16
 SCO_FAM_FLAG_JOINT_LIMITS = 32
 SCO_FAM_FLAG_EE_COST = 64
 SCO_FAM_FLAG_OBJ_PROGRAM = 128
+SCO_FAM_FLAG_ACC_COST = 256
 TRACE_W = 8
 
 
@@ -58,8 +59,10 @@ class TrajOptBatch(object):
 
     def __init__(self, batch, dof, horizon, n_points, n_obstacles, device=0, analytic_jac=False,
                  prox_count=2, reach=False, vel_limits=False, joint_limits=False, ee_cost=False, point=False,
-                 quadratic=False, program=False, n_eq_rows=0, lin_rows=None, circle_rows=0):
-        """circle_rows (r04, program family, span 1): the first ``circle_rows`` of the ``n_obstacles`` rows of a block are keep-out
+                 quadratic=False, program=False, n_eq_rows=0, lin_rows=None, circle_rows=0, acc_cost=False):
+        """acc_cost (r04): the quadratic objective carries an acceleration term sum_t sum_j a_j (x[t+2][j] - 2 x[t+1][j] + x[t][j])^2
+        (``load(acc_weights=)``, (B, dof)); fixed at creation because P gets a second super-diagonal block.
+        circle_rows (r04, program family, span 1): the first ``circle_rows`` of the ``n_obstacles`` rows of a block are keep-out
         rows of the point (x[0], x[1]) against ``obstacles[b, :circle_rows]`` -- a second kind of non-linear rows next to the
         program's (two BoundExprs on one timestep Variable in the reference).
         lin_rows (r04): pattern of GENERAL affine rows over the trajectory variables, shared by the batch:
@@ -101,8 +104,10 @@ class TrajOptBatch(object):
                                 (SCO_FAM_FLAG_VEL_LIMITS if self.vel_limits else 0) |
                                 (SCO_FAM_FLAG_JOINT_LIMITS if self.joint_limits else 0) |
                                 (SCO_FAM_FLAG_EE_COST if self.ee_cost else 0) |
-                                (SCO_FAM_FLAG_OBJ_PROGRAM if self.obj_program else 0),
+                                (SCO_FAM_FLAG_OBJ_PROGRAM if self.obj_program else 0) |
+                                (SCO_FAM_FLAG_ACC_COST if bool(acc_cost) else 0),
                                 1 if analytic_jac else 0, int(prox_count), self.span, self.n_eq)
+        self.acc_cost = bool(acc_cost)
         self.circle_rows = int(circle_rows)
         if self.circle_rows and not (self.program and self.span == 1):
             raise ValueError("circle rows next to program rows: program family, blocks on one timestep")
@@ -139,7 +144,7 @@ class TrajOptBatch(object):
 
     def load(self, x0, start, goal, link_len, point_link, point_frac, obstacles, target=None, vmax=None,
              jlo=None, jhi=None, cost_weight=None, cost_target=None, quad_Q=None, quad_a=None, quad_c=None,
-             row_program=None, row_params=None, obj_weights=None, lin_vals=None, lin_rhs=None):
+             row_program=None, row_params=None, obj_weights=None, lin_vals=None, lin_rhs=None, acc_weights=None):
         """Upload per-problem data (host arrays, copied).  ``target`` (B, 2): end-effector
         position of the reach variant (``goal`` is then ignored by the device).  r04: ``row_params`` may be (B, T, n_params) --
         one parameter vector per timestep (block t and the objective term of timestep t read row_params[b, t]);
@@ -211,6 +216,11 @@ class TrajOptBatch(object):
             _lib.check(_lib.load().sco_sqp_load_linear_rows(self._h, _lib.dptr(lv), _lib.dptr(lr)))
         elif lin_vals is not None or lin_rhs is not None:
             raise ValueError("the batch was created without general affine rows (lin_rows=)")
+        if self.acc_cost:
+            aw = arr(np.broadcast_to(np.asarray(acc_weights if acc_weights is not None else 0.0, dtype=np.float64), (B, d)), (B, d))
+            _lib.check(_lib.load().sco_sqp_load_acc_weights(self._h, _lib.dptr(aw)))
+        elif acc_weights is not None:
+            raise ValueError("the batch was created without the acceleration term (acc_cost=True)")
         if obj_weights is not None:
             ow = arr(np.broadcast_to(np.asarray(obj_weights, dtype=np.float64), (B, d)), (B, d))
             _lib.check(_lib.load().sco_sqp_load_obj_weights(self._h, _lib.dptr(ow)))
@@ -304,13 +314,14 @@ def solve_batch(batch_arrays, params=None, qp_settings=None, device=0, analytic_
                       joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
                       point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None,
                       program=a.get("row_program") if a.get("row_program") is not None else False,
-                      n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows"), circle_rows=a.get("circle_rows", 0)) as tb:
+                      n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows"), circle_rows=a.get("circle_rows", 0),
+                      acc_cost=a.get("acc_w") is not None) as tb:
         tb.load(a["x0"], a["start"], a["goal"], a["link_len"], a["point_link"], a["point_frac"], a["obstacles"],
                 target=a.get("target"), vmax=a.get("vmax"), jlo=a.get("jlo"), jhi=a.get("jhi"),
                 cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),
                 quad_Q=a.get("quad_Q"), quad_a=a.get("quad_a"), quad_c=a.get("quad_c"),
                 row_program=a.get("row_program"), row_params=a.get("row_params"), obj_weights=a.get("obj_w"),
-                lin_vals=a.get("lin_vals"), lin_rhs=a.get("lin_rhs"))
+                lin_vals=a.get("lin_vals"), lin_rhs=a.get("lin_rhs"), acc_weights=a.get("acc_w"))
         if a.get("groups") is not None:
             tb.set_groups(a["groups"])
         tb.solve(params, qp_settings)

@@ -73,6 +73,8 @@ struct SqpDev {
                      // (sco_sqp_set_circle_rows); programs supply the remaining O - R1 rows
   int par_step;      // r04: 0 = one parameter vector per problem; n_par = one per problem AND timestep (sco_sqp_load_program_steps:
                      // block t and the objective term of timestep t read params[problem][t])
+  int acc;                // r04 (SCO_FAM_FLAG_ACC_COST): P holds the second super-diagonal block too
+  const double *accw;     // r04: [B][d] weights of the acceleration term sum_t sum_j a_j (x[t+2][j] - 2 x[t+1][j] + x[t][j])^2, nullptr = all 0
   const double *objw;     // r04: [B][d] weights of the smoothing objective sum_t sum_j w_j (x[t+1][j] - x[t][j])^2, nullptr = all 1
   // linear rows: m_pin pins (start, and goal unless reach), then m_vel velocity-limit rows, then m_jl joint-limit
   // rows (theta <= hi for every trajectory variable, then -theta <= -lo)
@@ -138,6 +140,7 @@ struct sco_sqp {
   std::vector<hipEvent_t> events;
   void *prog_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // sco_sqp_load_program: words, row starts, constants, parameters
   void *objw_buf = nullptr;                                    // sco_sqp_load_obj_weights
+  void *accw_buf = nullptr;                                    // sco_sqp_load_acc_weights
   std::vector<int> gen_ptr, gen_col, gen_iseq;                 // sco_sqp_create_rows: the general affine rows' pattern
   bool gen_loaded = false;
   size_t prog_bytes[4] = {0, 0, 0, 0};
@@ -456,13 +459,36 @@ __device__ __forceinline__ int memo_find(const double *keys, int count, int d, c
 }
 
 // w: the problem's objective weights (r04, QuadExpr with per-joint weights, prob.py:348-367) or nullptr = all 1
-__device__ __forceinline__ double traj_obj_partial(const double *x, int d, int T, int tid, const double *w) {
+__device__ __forceinline__ double traj_obj_partial(const double *x, int d, int T, int tid, const double *w, const double *aw) {
   double s = 0.0;
   for (int e = tid; e < (T - 1) * d; e += SCO_BLOCK) {
     const double df = x[e + d] - x[e];
     s += w ? w[e % d] * (df * df) : df * df;
   }
+  if (aw)                                  // acceleration term (r04): second differences
+    for (int e = tid; e < (T - 2) * d; e += SCO_BLOCK) {
+      const double dd = (x[e + 2 * d] - 2.0 * x[e + d]) + x[e];
+      s += aw[e % d] * (dd * dd);
+    }
   return s;
+}
+// entries of the objective's P = Q (0.5 x'Qx form) in column (t, j): (t - 2, j), (t - 1, j), (t, j); wv / wa the joint's weights
+__device__ __forceinline__ double obj_p_diag(int t, int T, double wv, double wa) {
+  double v = ((t == 0 || t == T - 1) ? 2.0 : 4.0) * wv;
+  if (wa != 0.0) {
+    if (t <= T - 3) v += 2.0 * wa;                    // first point of window t
+    if (t >= 1 && t <= T - 2) v += 8.0 * wa;          // middle point of window t - 1
+    if (t >= 2) v += 2.0 * wa;                        // last point of window t - 2
+  }
+  return v;
+}
+__device__ __forceinline__ double obj_p_off1(int t, int T, double wv, double wa) {      // entry ((t - 1, j), (t, j)), t >= 1
+  double v = -2.0 * wv;
+  if (wa != 0.0) {
+    if (t <= T - 2) v -= 4.0 * wa;                    // (first, middle) of window t - 1
+    if (t >= 2) v -= 4.0 * wa;                        // (middle, last) of window t - 2
+  }
+  return v;
 }
 
 // upper bound of linear inequality row i (m_pin <= i < m_lin): velocity rows, then theta <= hi, then -theta <= -lo, then the
@@ -556,9 +582,11 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_proj_post_kernel(SqpDev s, QpDe
       if (tid == 0) {
         const int t = col / d;
         const double wj = s.objw ? s.objw[(size_t)b * d + col % d] : 1.0;
-        if (t > 0) Pv[pos++] = -2.0 * wj;
+        const double aj = s.accw ? s.accw[(size_t)b * d + col % d] : 0.0;
+        if (s.acc && t > 1) Pv[pos++] = 2.0 * aj;                            // ((t - 2, j), (t, j)): first x last of window t - 2
+        if (t > 0) Pv[pos++] = obj_p_off1(t, s.T, wj, aj);
         if (s.cost) for (int i = 0; i < col % d; i++) Pv[pos++] = 0.0;
-        Pv[pos++] = ((t == 0 || t == s.T - 1) ? 2.0 : 4.0) * wj;
+        Pv[pos++] = obj_p_diag(t, s.T, wj, aj);
       }
     }
     double *qv = q1.q + (size_t)b * n;
@@ -805,13 +833,13 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_pre_kernel(SqpDev s, QpDev q1, 
         int k = e % npair, i = 0;
         while (k >= d - i) { k -= d - i; i++; }
         const int j = i + k;
-        const double base = (i == j) ? ((t == 0 || t == T - 1) ? 2.0 : 4.0) * (s.objw ? s.objw[(size_t)b * d + i] : 1.0) : 0.0;
+        const double base = (i == j) ? obj_p_diag(t, T, s.objw ? s.objw[(size_t)b * d + i] : 1.0, s.accw ? s.accw[(size_t)b * d + i] : 0.0) : 0.0;
         Pv[s.ppos[t * d + j] + i] = base + oH[(size_t)t * d * d + i * d + j];
       }
       for (int e = tid; e < n_x; e += SCO_BLOCK) qv[e] = oA[e];
     }
     // S7: merit at the convexification point (prob.py:571-579), S4 prerequisite: save
-    double v[2] = {traj_obj_partial(x, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr) + ((s.cost && tid < T) ? of0[tid] : 0.0), 0.0};
+    double v[2] = {traj_obj_partial(x, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr, s.accw ? s.accw + (size_t)b * d : nullptr) + ((s.cost && tid < T) ? of0[tid] : 0.0), 0.0};
     for (int e = tid; e < m_nl; e += SCO_BLOCK) {
       const RowRef q = row_ref(e, L);
       v[1] += row_viol(q, gs[e] - row_rhs(rc, q));
@@ -906,7 +934,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_post_kernel(SqpDev s, QpDev q1,
   // model violation uses the FULL Jacobian (prob.py:627-628), new violation f at the new point (prob.py:575-577)
   // v: quadratic objective, model violation, new violation, objective MODELS at the new point (prob.py:625-626),
   //    objective terms at the new point (prob.py:571-573), max violation at the saved point
-  double v[6] = {traj_obj_partial(xq, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr), 0.0, 0.0, 0.0, 0.0, 0.0};
+  double v[6] = {traj_obj_partial(xq, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr, s.accw ? s.accw + (size_t)b * d : nullptr), 0.0, 0.0, 0.0, 0.0, 0.0};
   if (s.cost) {
     const double *oH = s.oH + (size_t)b * T * d * d, *oA = s.oA + (size_t)b * T * d, *ob = s.ob + (size_t)b * T;
     for (int t = tid; t < T; t += SCO_BLOCK) {
@@ -1060,7 +1088,7 @@ __global__ __launch_bounds__(SCO_BLOCK) void sqp_final_kernel(SqpDev s, double *
                   s.qQ + (size_t)b * O * s.ds * s.ds, s.qa + (size_t)b * O * s.ds, s.qc + (size_t)b * O,
                   s.pw, s.pptr, s.pconst, s.ppar + (size_t)b * s.n_par * (s.par_step ? s.T : 1), s.par_step, s.R1};
   const RowLay L{T, s.NBt, R, s.Req};
-  double v[3] = {traj_obj_partial(x, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr), 0.0, 0.0};
+  double v[3] = {traj_obj_partial(x, d, T, tid, s.objw ? s.objw + (size_t)b * d : nullptr, s.accw ? s.accw + (size_t)b * d : nullptr), 0.0, 0.0};
   if (s.cost)
     for (int t = tid; t < T; t += SCO_BLOCK)
       v[0] += obj_value(ObjCtx{s.cost, len, d, s.ctgt[(size_t)b * 2], s.ctgt[(size_t)b * 2 + 1], s.cw[b]}, rc, t, x + t * d, -1, 0.0, -1, 0.0);
@@ -1121,8 +1149,8 @@ extern "C" int sco_sqp_create_rows(int device, const sco_trajopt_desc *desc, int
   const int fam = desc->family & 15, span = desc->span > 0 ? desc->span : 1;
   const bool statefam = fam == SCO_FAM_STATE_QUADRATIC || fam == SCO_FAM_STATE_PROGRAM;
   if (desc->batch <= 0 || desc->dof <= 0 || desc->horizon < 2 || desc->n_points <= 0 || desc->n_obstacles <= 0 ||
-      desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS | SCO_FAM_FLAG_EE_COST | SCO_FAM_FLAG_OBJ_PROGRAM)) ||
-      ((desc->family & SCO_FAM_FLAG_EE_COST) && desc->dof > OBJ_DMAX) ||
+      desc->horizon > 256 || (desc->family & ~(15 | SCO_FAM_FLAG_VEL_LIMITS | SCO_FAM_FLAG_JOINT_LIMITS | SCO_FAM_FLAG_EE_COST | SCO_FAM_FLAG_OBJ_PROGRAM | SCO_FAM_FLAG_ACC_COST)) ||
+      ((desc->family & SCO_FAM_FLAG_EE_COST) && desc->dof > OBJ_DMAX) || ((desc->family & SCO_FAM_FLAG_ACC_COST) && desc->horizon < 3) ||
       (fam != SCO_FAM_ARM_CIRCLES && fam != SCO_FAM_ARM_REACH && fam != SCO_FAM_POINT_CIRCLES && !statefam) ||
       (fam == SCO_FAM_POINT_CIRCLES && (desc->n_points != 1 || desc->dof < 2 || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
       (statefam && (desc->n_points != 1 || (desc->family & SCO_FAM_FLAG_EE_COST))) ||
@@ -1171,6 +1199,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   const bool reach = (desc->family & 15) == SCO_FAM_ARM_REACH, vel = (desc->family & SCO_FAM_FLAG_VEL_LIMITS) != 0;
   const bool jl = (desc->family & SCO_FAM_FLAG_JOINT_LIMITS) != 0;
   const bool cost = (desc->family & (SCO_FAM_FLAG_EE_COST | SCO_FAM_FLAG_OBJ_PROGRAM)) != 0;
+  const bool acc = (desc->family & SCO_FAM_FLAG_ACC_COST) != 0;
   const int NE = reach ? 2 : 0;                  // equality rows (end-effector x, y) on the last timestep
   const int S = desc->span > 0 ? desc->span : 1, ds = S * d, NBt = T - S + 1, Req = desc->n_eq_rows;
   const int m_pin = reach ? d : 2 * d, dT1 = d * (T - 1), m_vel = vel ? 2 * dT1 : 0;
@@ -1227,6 +1256,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
     for (int col = 0; col < n; col++) {
       Pp[col] = (int)Pi.size();
       if (col < n_x) {
+        if (acc && col / d > 1) Pi.push_back(col - 2 * d);       // acceleration term (r04): second super-diagonal block
         if (col / d > 0) Pi.push_back(col - d);
         ppos[col] = (int)Pi.size();
         // a non-quadratic objective term fills the upper triangle of its timestep's diagonal block
@@ -1282,6 +1312,7 @@ static int sqp_create_impl(sco_sqp *h, int device, const sco_trajopt_desc *desc)
   s.NE = NE; s.NB = NBt + (reach ? 1 : 0); s.RM = std::max(R, NE) + (cost ? 1 : 0);     // + the objective term's value
   s.S = S; s.ds = ds; s.NBt = NBt; s.Req = Req;
   s.m_gen = m_gen; s.nnz_gen = nnz_gen;
+  s.acc = acc ? 1 : 0;
   s.m_pin = m_pin; s.m_vel = m_vel; s.m_jl = m_jl; s.cost = (desc->family & SCO_FAM_FLAG_OBJ_PROGRAM) ? 2 : cost ? 1 : 0;
   int rc = 0;
 #define AL(f, cnt) if ((rc = sq_alloc(h, (cnt), &s.f))) return rc;
@@ -1344,6 +1375,7 @@ extern "C" int sco_sqp_destroy(sco_sqp *h) {
   for (void *p : h->allocs) (void)hipFree(p);
   for (void *p : h->prog_buf) if (p) (void)hipFree(p);
   if (h->objw_buf) (void)hipFree(h->objw_buf);
+  if (h->accw_buf) (void)hipFree(h->accw_buf);
   for (auto e : h->events) (void)hipEventDestroy(e);
   for (auto &ge : h->gevents) for (auto e : ge) (void)hipEventDestroy(e);
   for (auto e : h->done) (void)hipEventDestroy(e);
@@ -1521,6 +1553,27 @@ extern "C" int sco_sqp_load_program(sco_sqp *h, int n_words, const int *words, c
 extern "C" int sco_sqp_load_program_steps(sco_sqp *h, int n_words, const int *words, const int *row_ptr, int n_consts,
                                           const double *consts, int n_params, const double *params) {
   return load_program_impl(h, n_words, words, row_ptr, n_consts, consts, n_params, params, true);
+}
+
+// r04 (SCO_FAM_FLAG_ACC_COST): weights a[batch][dof] >= 0 of the acceleration term of the quadratic objective,
+//     sum_t sum_j a_j (theta[t+2][j] - 2 theta[t+1][j] + theta[t][j])^2,
+// next to the (weighted) velocity term -- the QuadExpr a caller builds from first AND second difference matrices (prob.py:88-104,
+// 348-367).  P gets its second super-diagonal block (pattern fixed at sco_sqp_create by the flag).  After sco_sqp_load; nullptr = 0.
+extern "C" int sco_sqp_load_acc_weights(sco_sqp *h, const double *a) {
+  if (!h) { sco_set_error("sco_sqp_load_acc_weights: null pointer"); return SCO_ERR_ARG; }
+  if (!h->d.acc) { sco_set_error("sco_sqp_load_acc_weights: the handle was created without SCO_FAM_FLAG_ACC_COST"); return SCO_ERR_ARG; }
+  if (!h->loaded) { sco_set_error("sco_sqp_load_acc_weights: call sco_sqp_load first"); return SCO_ERR_STATE; }
+  SqpDev &s = h->d;
+  if (!a) { s.accw = nullptr; h->solved = false; return SCO_OK; }
+  for (size_t i = 0; i < (size_t)s.batch * s.d; i++)
+    if (!(a[i] >= 0.0) || !(a[i] < 1e30)) { sco_set_error("sco_sqp_load_acc_weights: weights must be finite and >= 0"); return SCO_ERR_ARG; }
+  SCO_ON_DEVICE(h->device);
+  s.accw = nullptr;
+  if (!h->accw_buf) SCO_HIP(hipMalloc(&h->accw_buf, (size_t)s.batch * s.d * sizeof(double)));
+  SCO_HIP(hipMemcpy(h->accw_buf, a, (size_t)s.batch * s.d * sizeof(double), hipMemcpyHostToDevice));
+  s.accw = (const double *)h->accw_buf;
+  h->solved = false;
+  return SCO_OK;
 }
 
 // r04: two kinds of non-linear rows in one problem.  SCO_FAM_STATE_PROGRAM, span 1, before sco_sqp_load_program: the first n_rows

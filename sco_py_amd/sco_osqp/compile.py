@@ -28,6 +28,7 @@ What is read and what it must look like (each test names the reference behaviour
 import numpy as np
 
 from .. import devexpr as dx
+from .. import workloads as wl
 from .. import expr as ex
 
 _reason = [""]
@@ -269,12 +270,20 @@ def _compile(prob):
         _no("the quadratic objective is not a QuadExpr on the whole trajectory")
     # sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 with weights w_j >= 0 read off the first super-diagonal (r04; all 1 = the
     # reference examples' smoothing term)
+    # plus (r04) an acceleration term sum_t sum_j a_j (x[t+2][j] - 2 x[t+1][j] + x[t][j])^2: a_j off the second super-diagonal
+    # block, then w_j off the first one (entry ((0, j), (1, j)) is -2 w_j - 4 a_j)
     Qm = np.asarray(qe.Q, dtype=np.float64)
-    ow = -0.5 * Qm[np.arange(d), d + np.arange(d)] if (T > 1 and Qm.shape == (n_x, n_x)) else np.ones(d)
-    if not (Qm.shape == (n_x, n_x) and np.all(ow >= 0) and np.allclose(Qm, _smooth_Q(d, T, ow), rtol=1e-12, atol=1e-14) and not np.any(qe.A) and not np.any(qe.b)):
-        _no("the quadratic objective is not sum_t sum_j w_j (x[t+1][j] - x[t][j])^2")
+    ok_shape = Qm.shape == (n_x, n_x)
+    aw = 0.5 * Qm[np.arange(d), 2 * d + np.arange(d)] if (ok_shape and T > 2) else np.zeros(d)
+    ow = -0.5 * (Qm[np.arange(d), d + np.arange(d)] + 4.0 * aw) if (ok_shape and T > 1) else np.ones(d)
+    has_acc = bool(np.any(aw != 0.0))
+    if not (ok_shape and np.all(ow >= 0) and np.all(aw >= 0) and not np.any(qe.A) and not np.any(qe.b) and
+            np.allclose(Qm, wl.smooth_Q(d, T, ow, aw) if has_acc else _smooth_Q(d, T, ow), rtol=1e-12, atol=1e-14)):
+        _no("the quadratic objective is not sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 (+ a_j (second differences)^2)")
     if not np.all(ow == 1.0):
         pr["obj_w"] = ow
+    if has_acc:
+        pr["acc_w"] = aw
     nq = list(prob._nonquad_obj_exprs)
     if nq:
         if len(nq) != T:
@@ -393,7 +402,7 @@ def _compile(prob):
     gkey = None if trivial else tuple(tuple(g) for g in block_groups)
 
     key = (d, T, span, n_eq, key_fam, analytic, prox_count, reach_be is not None, "vmax" in pr, "jlo" in pr,
-           "cost_weight" in pr, bool(nq), gkey, lin_key)
+           "cost_weight" in pr, bool(nq), gkey, lin_key, "acc_w" in pr)
     return CompiledProb(key, pr, holders, atoms, gids)
 
 
@@ -450,6 +459,8 @@ def _stack(cps):
             a[k] = st(k)
     if p0.get("groups") is not None:
         a["groups"] = p0["groups"]
+    if p0.get("acc_w") is not None:
+        a["acc_w"] = st("acc_w")
     if p0.get("circle_rows"):
         a["circle_rows"] = p0["circle_rows"]
     if p0.get("lin_gen") is not None:
@@ -478,7 +489,8 @@ def run_compiled(cps, params, qp_settings, device=0):
                              joint_limits=a.get("jlo") is not None, ee_cost=a.get("cost_weight") is not None,
                              point=bool(a.get("point")), quadratic=a.get("quad_Q") is not None,
                              program=a.get("row_program") if a.get("row_program") is not None else False,
-                             n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows"), circle_rows=a.get("circle_rows", 0))
+                             n_eq_rows=a.get("quad_n_eq", 0), lin_rows=a.get("lin_rows"), circle_rows=a.get("circle_rows", 0),
+                             acc_cost=a.get("acc_w") is not None)
     _HANDLES[hk] = tb                       # most recently used last
     while len(_HANDLES) > _HANDLE_CAP:
         _HANDLES.pop(next(iter(_HANDLES))).close()
@@ -489,7 +501,7 @@ def run_compiled(cps, params, qp_settings, device=0):
             cost_weight=a.get("cost_weight"), cost_target=a.get("cost_target"),
             quad_Q=a.get("quad_Q"), quad_a=a.get("quad_a"), quad_c=a.get("quad_c"),
             row_program=a.get("row_program"), row_params=a.get("row_params"), obj_weights=a.get("obj_w"),
-            lin_vals=a.get("lin_vals"), lin_rhs=a.get("lin_rhs"))
+            lin_vals=a.get("lin_vals"), lin_rhs=a.get("lin_rhs"), acc_weights=a.get("acc_w"))
     if a.get("groups") is not None:
         tb.set_groups(a["groups"])
     t1 = time.perf_counter()

@@ -479,7 +479,7 @@ def general_rows(i, d, T, start, goal):
     return dict(A=np.array(rows), rhs=np.array(rhs), is_eq=np.array(eq, dtype=np.int32))
 
 
-def make_problem(i, obj_weights=False, per_step=False, lin_rows=False, circles=0, **kw):
+def make_problem(i, obj_weights=False, per_step=False, lin_rows=False, circles=0, acc_weights=False, **kw):
     """Seeded problem i of the batch; see _make_problem for the families.  r04 (wider template):
     obj_weights=True adds per-joint weights w_j in [0.4, 3] of the smoothing objective (``obj_w``; a QuadExpr built from a
     weighted difference matrix, prob.py:88-104, 348-367); per_step=True (program family) gives every timestep its own
@@ -503,6 +503,8 @@ def make_problem(i, obj_weights=False, per_step=False, lin_rows=False, circles=0
         out["lin_gen"] = general_rows(i, out["d"], out["T"], out["start"], out["goal"])
     if obj_weights:
         out["obj_w"] = np.random.default_rng(7000 + i).uniform(0.4, 3.0, size=out["d"])
+    if acc_weights:          # r04: acceleration term sum_t sum_j a_j (x[t+2][j] - 2 x[t+1][j] + x[t][j])^2 in the quadratic objective
+        out["acc_w"] = np.random.default_rng(7500 + i).uniform(0.2, 2.0, size=out["d"])
     if per_step:
         if out.get("row_program") is None:
             raise ValueError("per_step needs the program family")
@@ -510,6 +512,25 @@ def make_problem(i, obj_weights=False, per_step=False, lin_rows=False, circles=0
         t = np.arange(out["T"], dtype=np.float64)[:, None]
         out["row_params"] = par[None, :] + 0.04 * np.abs(par)[None, :] * np.sin(0.9 * t + np.arange(par.shape[0])[None, :])
     return out
+
+
+def smooth_Q(d, T, w=None, a=None):
+    """Q of the quadratic objective in QuadExpr's 0.5 x'Qx form: sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 (w None = 1) plus, with a,
+    sum_t sum_j a_j (x[t+2][j] - 2 x[t+1][j] + x[t][j])^2 -- added entry by entry in (t, j) order, first differences first."""
+    n = d * T
+    Q = np.zeros((n, n))
+    w = np.ones(d) if w is None else np.asarray(w, dtype=np.float64)
+    for t in range(T - 1):
+        for j in range(d):
+            i0, i1 = t * d + j, (t + 1) * d + j
+            Q[i0, i0] += 2.0 * w[j]; Q[i1, i1] += 2.0 * w[j]; Q[i0, i1] -= 2.0 * w[j]; Q[i1, i0] -= 2.0 * w[j]
+    if a is not None:
+        c = np.array([1.0, -2.0, 1.0])
+        for t in range(T - 2):
+            for j in range(d):
+                idx = np.array([t * d + j, (t + 1) * d + j, (t + 2) * d + j])
+                Q[np.ix_(idx, idx)] += 2.0 * a[j] * np.outer(c, c)
+    return Q
 
 
 def step_params(pr, t):
@@ -591,6 +612,8 @@ def make_batch(B, first=0, **kw):
         extra["jlo"] = np.stack([p["jlo"] for p in probs]); extra["jhi"] = np.stack([p["jhi"] for p in probs])
     if p0.get("obj_w") is not None:
         extra["obj_w"] = np.stack([p["obj_w"] for p in probs])
+    if p0.get("acc_w") is not None:
+        extra["acc_w"] = np.stack([p["acc_w"] for p in probs])
     if p0.get("circle_rows"):
         extra["circle_rows"] = p0["circle_rows"]
     if p0.get("lin_gen") is not None:

@@ -10,7 +10,7 @@ ONLY = _os.environ.get("FAMILIES")
 for name, kw in (("circles", {}), ("reach", dict(reach=True)), ("vel", dict(vel_limit=0.3)), ("jl", dict(joint_limit=0.2)),
                  ("vel+jl", dict(vel_limit=0.3, joint_limit=0.2)), ("reach+vel+jl", dict(reach=True, vel_limit=0.3, joint_limit=0.2)),
                  # r04, the wider template: general affine rows, weighted smoothing objective (any family), program parameters per timestep
-                 ("circles+rows", dict(lin_rows=True)), ("circles+weights", dict(obj_weights=True)), ("vel+weights", dict(vel_limit=0.3, obj_weights=True)),
+                 ("circles+rows", dict(lin_rows=True)), ("circles+acceleration term", dict(acc_weights=True)), ("circles+weights", dict(obj_weights=True)), ("vel+weights", dict(vel_limit=0.3, obj_weights=True)),
                  ("program d=2 T=20", dict(d=2, T=20, K=1, program=True)), ("program+steps", dict(d=2, T=20, K=1, program=True, per_step=True)),
                  ("program+circles (two kinds)", dict(d=2, T=20, K=1, program=True, circles=3)),
                  ("sweep+steps (span 2)", dict(d=2, T=20, K=1, program=True, variant="sweep", per_step=True)),

@@ -21,6 +21,7 @@ for tok in sys.argv[4:]:                                         # reach, vel, g
     if tok == "objw": KW["obj_weights"] = True                                     # r04: weighted smoothing objective
     if tok == "steps": KW["per_step"] = True                                       # r04: program parameters per timestep
     if tok == "circles": KW["circles"] = 2                                         # r04: two kinds of non-linear rows (with prog)
+    if tok == "acc": KW["acc_weights"] = True                                      # r04: acceleration term in the quadratic objective
     if tok == "rows": KW["lin_rows"] = True                                        # r04: general affine rows
     if tok == "ajac": AJ = True
 AJ = "ajac" in sys.argv[4:]

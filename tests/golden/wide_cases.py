@@ -3,7 +3,8 @@ w*: per-joint weights of the smoothing objective (a QuadExpr from a weighted dif
 parameters differ from timestep to timestep (every timestep's Expr closes over its own data); ac* / jk*: constraint blocks on
 THREE and FOUR consecutive timesteps (acceleration and jerk limits as non-linear rows on a Variable of 3 / 4 timesteps); lr*:
 GENERAL affine rows (LEqExpr / EqExpr on an AffExpr over the whole trajectory: joint couplings, a two-step limit, one equality);
-mx*: TWO kinds of non-linear rows per timestep (the point's keep-out discs and program rows, two BoundExprs on one Variable)."""
+mx*: TWO kinds of non-linear rows per timestep (the point's keep-out discs and program rows, two BoundExprs on one Variable);
+aa*: an ACCELERATION term in the quadratic objective (QuadExpr from first and second difference matrices, per-joint weights)."""
 ARM = dict(d=3, T=6, K=2, O=2)
 P = dict(K=1, program=True)
 CASES = [("w%d_" % i, dict(ARM, obj_weights=True), i, False) for i in range(2)] + \
@@ -26,4 +27,7 @@ CASES = [("w%d_" % i, dict(ARM, obj_weights=True), i, False) for i in range(2)] 
          ("lrg_", dict(P, d=2, T=8, lin_rows=True, per_step=True), 1, False)] + \
         [("mx%d_" % i, dict(P, d=2, T=8, circles=2), i, False) for i in range(2)] + \
         [("mxa_", dict(P, d=2, T=8, variant="attract", circles=1, per_step=True, groups="split"), 0, False),
-         ("ja_mx_", dict(P, d=3, T=6, circles=2, lin_rows=True), 1, True)]
+         ("ja_mx_", dict(P, d=3, T=6, circles=2, lin_rows=True), 1, True)] + \
+        [("aa%d_" % i, dict(ARM, acc_weights=True), i, False) for i in range(2)] + \
+        [("aaw_", dict(ARM, acc_weights=True, obj_weights=True, vel_limit=0.6), 1, False),
+         ("aap_", dict(P, d=2, T=8, acc_weights=True, per_step=True), 0, True)]

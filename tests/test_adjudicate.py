@@ -76,13 +76,15 @@ def test_margin_at_the_check_where_the_r03_device_stopped(fx, i, margin_lo, marg
 
 
 # ---- r04 sweeps: two more problems where two float64 routes of the ORACLE ITSELF part (profiles/r04_parity_sweep.txt) ----
-WIDE = {6072: dict(program=True, variant="dynamics", d=3, T=10, K=1), 6233: dict(program=True, variant="jerk", d=2, T=10, K=1)}
+WIDE = {6072: dict(program=True, variant="dynamics", d=3, T=10, K=1), 6233: dict(program=True, variant="jerk", d=2, T=10, K=1),
+        6059: dict(lin_rows=True)}
+WIDE_AJ = {6072: True, 6233: True, 6059: False}           # forward-mode Jacobians in the sweep that found the problem
 
 
 def oracle_route(i, **kw):
     from oracle import arm_family as af, sco_ref as sr
     solver = (lambda P, q, A, l, u, w, s: o.solve(P, q, A, l, u, w=w, **dict(s, **kw))) if kw else None
-    return sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i, **WIDE[i]), analytic_jac=True), None, emulate_memo=True, qp_solver=solver)
+    return sr.penalty_sqp(sr.trajopt_flat(af.make_problem(i, **WIDE[i]), analytic_jac=WIDE_AJ[i]), None, emulate_memo=True, qp_solver=solver)
 
 
 def test_a_qp_at_the_edge_of_max_iter_splits_the_oracles_own_float64_routes():
@@ -108,3 +110,14 @@ def test_unconverged_qps_put_the_noise_floor_of_a_run_above_the_parity_bar():
         assert np.array_equal(r.trace[:, 0], kkt.trace[:, 0]) and np.array_equal(r.trace[:, 6:8], kkt.trace[:, 6:8])
     assert sorted(kkt.trace[:, 6].astype(int).tolist()).count(2) == 2
     assert 1e-5 < np.abs(x87.x - kkt.x).max() < 1e-4 and 5e-6 < np.abs(red.x - kkt.x).max() < 1e-4
+
+
+def test_a_dual_residual_within_five_parts_in_ten_million_of_its_tolerance():
+    """7-DOF x 20 with general affine rows, problem 6059: at the check of iteration 49 725 the first penalty QP's dual residual
+    is 1.999999e-6 against a tolerance of 2.0e-6.  The KKT route (float64, x87) and the x87 reduced route pass there; the float64
+    reduced route -- the device's algebra -- computes 2.000001e-6 and passes one check later (49 750).  The sweep counts it as a
+    mismatch (|dx| 1.2e-7); the device reproduces the oracle's reduced route (tests/test_adjudicate_gpu.py)."""
+    kkt, red, x87 = oracle_route(6059), oracle_route(6059, linsys=1), oracle_route(6059, extended=True, linsys=1)
+    assert kkt.trace[:, 7].astype(int).tolist() == [50, 49725, 100000] and x87.trace[:, 7].astype(int).tolist() == [50, 49725, 100000]
+    assert red.trace[:, 7].astype(int).tolist() == [50, 49750, 100000]
+    assert np.array_equal(red.trace[:, 6], kkt.trace[:, 6]) and np.abs(red.x - kkt.x).max() < 1e-6

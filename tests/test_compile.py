@@ -29,6 +29,7 @@ FAMILIES = [
     dict(d=2, T=8, K=1, program=True, variant="accel"), dict(d=2, T=9, K=1, program=True, variant="jerk", per_step=True),      # span 3, span 4
     dict(SMALL, lin_rows=True), dict(SMALL, lin_rows=True, vel_limit=0.6, joint_limit=0.3, obj_weights=True), dict(d=2, T=8, K=1, O=3, point=True, lin_rows=True),
     dict(d=2, T=8, K=1, program=True, circles=2), dict(d=2, T=8, K=1, program=True, variant="attract", circles=1, per_step=True, groups="split"),   # two kinds of rows
+    dict(SMALL, acc_weights=True), dict(SMALL, acc_weights=True, obj_weights=True, reach=True), dict(d=2, T=8, K=1, program=True, acc_weights=True),       # acceleration term
 ]
 
 
@@ -48,6 +49,8 @@ def test_compile_prob_reads_the_problem_record_back_out_of_the_object_api(kw):
             assert cp.pr[k] == v
         elif isinstance(v, bool) or v is None:
             assert bool(cp.pr.get(k)) == bool(v), k
+        elif k == "obj_w" and pr.get("acc_w") is not None:      # read back through -2 w - 4 a: one rounding
+            assert np.allclose(cp.pr[k], v, rtol=4e-16, atol=0)
         elif k == "lin_gen":
             assert all(np.array_equal(cp.pr[k][f], v[f]) for f in ("A", "rhs", "is_eq"))
         elif k == "row_params" and np.ndim(v) == 2:

@@ -597,7 +597,8 @@ def test_flat_oracle_reproduces_reference_for_the_wider_template(case):
     whose parameters change from timestep to timestep (each timestep's Expr closes over its own data, expr.py:22-41:
     drifting, pulsing obstacles; span 2, equality rows and objective programs included); blocks on 3 and 4 timesteps; general
     affine rows (LEqExpr / EqExpr on an AffExpr over the trajectory, prob.py:317-346); two kinds of non-linear rows on one
-    timestep Variable (keep-out discs + program rows: two BoundExprs, prob.py:112-144).  Runs of the reference's own
+    timestep Variable (keep-out discs + program rows: two BoundExprs, prob.py:112-144); an acceleration term in the quadratic
+    objective (pentadiagonal Q).  Runs of the reference's own
     modules (tests/golden/make_golden_wide.py): every QP it assembled, statuses, iteration counts, answer."""
     prefix, kw, i, aj = case
     g = np.load(os.path.join(GOLD, "trajopt_wide.npz"))
@@ -629,7 +630,7 @@ def test_the_wider_template_is_exercised_by_its_goldens():
 def test_mirror_api_reproduces_reference_for_the_wider_template(oracle_qp_backend):
     g = np.load(os.path.join(GOLD, "trajopt_wide.npz"))
     cases = _wide_cases()
-    for prefix, kw, i, aj in [cases[0], cases[3], cases[6], cases[8], cases[11], cases[18], cases[20], cases[22], cases[23], cases[25], cases[26]]:
+    for prefix, kw, i, aj in [cases[0], cases[3], cases[6], cases[8], cases[11], cases[18], cases[20], cases[22], cases[23], cases[25], cases[26], cases[27], cases[29], cases[30]]:
         del oracle_qp_backend[:]
         mods = ct.mirror_mods()
         prob, traj, _, _ = tb.build_prob(mods, af.make_problem(i, **kw), analytic_jac=aj)

@@ -1188,11 +1188,14 @@ def test_program_reload_with_another_size_and_the_n_eq_rows_check(gpu):
     (dict(d=3, T=6, K=2, O=2, lin_rows=True), False), (dict(d=3, T=6, K=2, O=2, lin_rows=True, vel_limit=0.6, joint_limit=0.3, obj_weights=True, reach=True), True),
     (dict(d=2, T=8, K=1, program=True, lin_rows=True, per_step=True), False), (dict(lin_rows=True), False),
     (dict(d=2, T=8, K=1, program=True, circles=2), False), (dict(d=2, T=8, K=1, program=True, variant="attract", circles=1, per_step=True, groups="split"), False),
-    (dict(d=3, T=6, K=1, program=True, circles=2, lin_rows=True, obj_weights=True), True), (dict(d=2, T=20, K=1, program=True, circles=3), False)],
+    (dict(d=3, T=6, K=1, program=True, circles=2, lin_rows=True, obj_weights=True), True), (dict(d=2, T=20, K=1, program=True, circles=3), False),
+    (dict(d=3, T=6, K=2, O=2, acc_weights=True), False), (dict(d=3, T=6, K=2, O=2, acc_weights=True, obj_weights=True, ee_cost_weight=1.0, vel_limit=0.6), False),
+    (dict(d=2, T=8, K=1, program=True, acc_weights=True, per_step=True), True), (dict(acc_weights=True), False)],
     ids=["weights", "weights-reach-vel", "weights-objterm", "weights-point-jl-analytic", "steps", "steps-sweep-analytic", "steps-dynamics",
          "steps-attract-weights", "weights-7x20", "span3", "span3-steps-vel-analytic", "span4", "span4-groups-weights-analytic",
          "rows", "rows-vel-jl-weights-reach-analytic", "rows-program-steps", "rows-7x20",
-         "two-kinds", "two-kinds-attract-steps-groups", "two-kinds-rows-weights-analytic", "two-kinds-2x20"])
+         "two-kinds", "two-kinds-attract-steps-groups", "two-kinds-rows-weights-analytic", "two-kinds-2x20",
+         "acc", "acc-weights-objterm-vel", "acc-program-steps-analytic", "acc-7x20"])
 def test_wider_template_matches_the_oracle(gpu, kw, analytic):
     """sco_sqp_load_obj_weights: sum_t sum_j w_j (x[t+1][j] - x[t][j])^2 with per-problem, per-joint weights (objective value, P
     of every QP, the degree-2 model of an objective term on top of it); sco_sqp_load_program_steps: block t and the objective
@@ -1200,7 +1203,9 @@ def test_wider_template_matches_the_oracle(gpu, kw, analytic):
     Hessians); span 3 and 4: constraint blocks on three / four consecutive timesteps (acceleration and jerk limits, a keep-out
     on the centroid of four points); sco_sqp_create_rows / sco_sqp_load_linear_rows: general affine rows (a shared CSR pattern,
     coefficients and right-hand sides per problem; inequalities and an equality) in the projection QP and in every penalty QP;
-    sco_sqp_set_circle_rows: two kinds of non-linear rows per timestep (the point's keep-out discs in front of program rows).
+    sco_sqp_set_circle_rows: two kinds of non-linear rows per timestep (the point's keep-out discs in front of program rows);
+    SCO_FAM_FLAG_ACC_COST / sco_sqp_load_acc_weights: an acceleration term in the quadratic objective (second super-diagonal block
+    of P; with an objective term on top of it).
     Every decision, QP status, iteration count, merit and the answer against the oracle, which reproduces the
     reference's own runs of these cases (tests/test_golden.py, trajopt_wide.npz)."""
     n = 4 if kw.get("d", 7) == 7 else 8
@@ -1213,8 +1218,8 @@ def test_wider_template_matches_the_oracle(gpu, kw, analytic):
         for b in np.nonzero(res.qp_solves > 1)[0]:                      # (projection feasible) the rows hold at every returned point
             v = probs[b]["lin_gen"]["A"] @ res.x[b] - probs[b]["lin_gen"]["rhs"]
             assert v[g0["is_eq"] == 0].max() < 1e-5 and np.abs(v[g0["is_eq"] != 0]).max() < 1e-5
-    if kw.get("obj_weights") or kw.get("per_step"):
-        plain = {k: v for k, v in arrays.items() if k != "obj_w"}
+    if kw.get("obj_weights") or kw.get("per_step") or kw.get("acc_weights"):
+        plain = {k: v for k, v in arrays.items() if k not in ("obj_w", "acc_w")}
         if kw.get("per_step"):
             plain["row_params"] = arrays["row_params"][:, 0, :].copy()
         res0 = sb.solve_batch(plain, analytic_jac=analytic)

@@ -29,12 +29,7 @@ def build_prob(mods, pr, analytic_jac=False, device_exprs=False):
     traj = mods.Variable(atoms, pr["x0"].reshape(n_x, 1).copy())
     prob.add_var(traj)
 
-    Q = np.zeros((n_x, n_x))
-    ow = pr["obj_w"] if pr.get("obj_w") is not None else np.ones(d)          # r04: weighted smoothing objective
-    for t in range(T - 1):
-        for j in range(d):
-            a, b = t * d + j, (t + 1) * d + j
-            Q[a, a] += 2.0 * ow[j]; Q[b, b] += 2.0 * ow[j]; Q[a, b] -= 2.0 * ow[j]; Q[b, a] -= 2.0 * ow[j]
+    Q = af.smooth_Q(d, T, pr.get("obj_w"), pr.get("acc_w"))     # r04: weighted smoothing objective, acceleration term
     prob.add_obj_expr(mods.BoundExpr(mods.QuadExpr(Q, np.zeros((1, n_x)), np.zeros((1, 1))), traj))
 
     reach = bool(pr.get("reach"))
