@@ -82,7 +82,7 @@ def install_standins():
             a = self.args
             kw = a["kw"]
             st = dict(rho=kw["rho"], sigma=kw["sigma"], eps_abs=kw["eps_abs"], eps_rel=kw["eps_rel"], max_iter=int(kw["max_iter"]))
-            if CANON_NX[0] is not None and np.asarray(a["q"]).shape[0] > CANON_NX[0]:
+            if CANON_NX[0] is not None and np.asarray(a["q"]).shape[0] >= CANON_NX[0]:       # (the projection QP too: its bound rows come in set order)
                 import trajopt_build as tb
                 Pd, Ad = sp.csc_matrix(a["P"]).toarray(), sp.csc_matrix(a["A"]).toarray()
                 P2, q2, A2, l2, u2, perm, rows = tb.canonical_qp(Pd, np.array(a["q"]), Ad, np.array(a["l"]), np.array(a["u"]),
