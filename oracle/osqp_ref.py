@@ -72,7 +72,14 @@ _lib_ld = None
 
 def build_extended(force=False):
     """Compile osqp_ref_ld.c: osqp_ref.c with `double` -> `long double` behind the same double ABI (gcc, host only)."""
+    global _SO_LD
     newest = max(os.path.getmtime(_SRC), os.path.getmtime(_SRC_LD))
+    if os.environ.get("SCO_ORACLE_SANITIZE", "0") == "1":       # scripts/cpu_sanitize.sh: ASan + UBSan variant next to it
+        _SO_LD = os.path.join(_HERE, "_osqp_ref_ld_asan.so")
+        if force or not os.path.exists(_SO_LD) or os.path.getmtime(_SO_LD) < newest:
+            subprocess.check_call(["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                                   "-fno-sanitize-recover=undefined", "-shared", "-fPIC", "-o", _SO_LD, _SRC_LD, "-lm"], cwd=_HERE)
+        return _SO_LD
     if force or not os.path.exists(_SO_LD) or os.path.getmtime(_SO_LD) < newest:
         subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", _SO_LD, _SRC_LD, "-lm"], cwd=_HERE)
     return _SO_LD

@@ -5,6 +5,7 @@
 # AddressSanitizer + UndefinedBehaviorSanitizer and driven by the existing tests:
 #   tests/test_qp_plan.py   (plan tests that need no HIP: the plan entry points come from scripts/sanitize/plan_driver.cpp)
 #   tests/test_oracle_osqp.py, tests/test_golden.py   (the oracle under the reference's golden vectors)
+#   tests/test_adjudicate.py   (r04: the x87 extended-precision build of the same file, oracle/osqp_ref_ld.c)
 # CPU only -- never on the GPU box (GPU sanitizers are not available on this pool).  Usage: bash scripts/cpu_sanitize.sh
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -28,5 +29,5 @@ _lib.load = lambda: lib
 sys.exit(pytest.main(["tests/test_qp_plan.py", "-x", "-q", "-p", "no:cacheprovider",
                       "-k", "plans_reproduce or eliminated_set or malformed"]))
 PY
-LD_PRELOAD="$ASAN $UBSAN" python3 -m pytest tests/test_oracle_osqp.py tests/test_golden.py -x -q -p no:cacheprovider -m "not gpu" 2>&1 | tee $OUT/sanitize_oracle.log
+LD_PRELOAD="$ASAN $UBSAN" python3 -m pytest tests/test_oracle_osqp.py tests/test_golden.py tests/test_adjudicate.py -x -q -p no:cacheprovider -m "not gpu" 2>&1 | tee $OUT/sanitize_oracle.log
 echo "sanitizer job finished: no AddressSanitizer / UndefinedBehaviorSanitizer report"
