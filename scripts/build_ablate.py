@@ -10,7 +10,8 @@ sys.path.insert(0, ROOT)
 from sco_py_amd import _build
 
 # arguments: ablation masks as integers; "vN" = -DRL_VARIANT=N; "name=path.hip" = an alternative kernel source;
-# "wv:NAME=VAL[,NAME=VAL]" = the wavefront tier's source (sco_admm_wv.hip) with those defines (WV_PD, WV_VARIANT)
+# "wv:NAME=VAL[,NAME=VAL]" = the wavefront tier's source (sco_admm_wv.hip) with those defines (WV_PD, WV_VARIANT);
+# "wvfile:TAG=path.hip" = an alternative source file in its place
 masks = sys.argv[1:] or ["0", "1", "2", "4", "8", "12", "16", "31"]
 _build.build()                                   # product objects are current
 out = os.path.join(_build.CSRC, "variants")
@@ -20,7 +21,11 @@ os.makedirs(out, exist_ok=True)
 def one(mask):
     src, defs, tag = os.path.join(_build.CSRC, "sco_admm_rl.hip"), [], mask
     base = "sco_admm_rl.hip"
-    if mask.startswith("wv:"):
+    if mask.startswith("wvfile:"):               # "wvfile:TAG=path.hip": an alternative source of the wavefront tier
+        base = "sco_admm_wv.hip"
+        tag, src = mask[7:].split("=", 1)
+        tag = "wvfile_" + tag
+    elif mask.startswith("wv:"):
         base = "sco_admm_wv.hip"
         src = os.path.join(_build.CSRC, base)
         defs = ["-D" + d for d in mask[3:].split(",")]
