@@ -212,7 +212,8 @@ bool wv_plan_build(const QpPlan &pl, WvHost &wh) {
   // LDS of the ADMM kernel (doubles): G, ef, en, em | r, x~, x, extra | Jacobian rows (unless they live in registers) | partials
   const bool jreg = WV_JREG && wh.NS * wh.BS <= 28;
   wh.g_doubles = (size_t)npos * 64 + 2 * (size_t)npos * 8 + 8;
-  wh.lds_doubles = wh.g_doubles + 4 * (size_t)npos * 8 + (jreg ? 0 : (size_t)wh.NS * 512) + (size_t)npos * lpb * 8;
+  // (+ the constants of the termination test, lane-minor: 3 NS + 5 NV + 1 slots of 64 doubles)
+  wh.lds_doubles = wh.g_doubles + 4 * (size_t)npos * 8 + (jreg ? 0 : (size_t)wh.NS * 512) + (size_t)npos * lpb * 8 + (size_t)(3 * wh.NS + 5 * wh.NV + 1) * 64;
   wh.lds_bytes = wh.lds_doubles * sizeof(double);
   wh.cst_slots = 3 * wh.NS + 13 * wh.NV + 1;
   // the tier pays only with FOUR problems per CU (one wavefront per SIMD): 40 KB each at most
@@ -489,6 +490,25 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     for (int t = lane; t < 4 * NPOS * 8; t += WV_T) lds[oR + t] = 0.0;
     for (int t = lane; t < NPOS * lpb * 8; t += WV_T) lds[oPART + t] = 0.0;
   }
+  // ---- LDS: the constants of the termination test (scalings of the lane's rows and variables, its P entries), lane-minor.
+  // They are constants of the solve; as registers (fetched one iteration ahead of every test) they cost 70 VGPRs for the
+  // whole launch -- beyond 256 every use of a register is a v_accvgpr move.
+  const int oCK = oPART + NPOS * lpb * 8;
+  double *const ckl = lds + oCK + lane;
+  {
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) ckl[(3 * q + k) * 64] = cstg0[(wv_cst_h(q) + k) * 64];
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+      for (int k = 0; k < 5; k++) ckl[(3 * NS + 5 * v + k) * 64] = cstg0[(wv_cst_v(NS, v) + k) * 64];
+    ckl[(3 * NS + 5 * NV) * 64] = cstg0[wv_cst_x(NS, NV) * 64];
+  }
+#define CKH(q, k) ckl[(3 * (q) + (k)) * 64]
+#define CKV(v, k) ckl[(3 * NS + 5 * (v) + (k)) * 64]
+#define CKX ckl[(3 * NS + 5 * NV) * 64]
   // ---- lane roles (row layout): pointers into the vectors of the lane's block
   const int pos_r = tab0[oPOS * 64 + lane];
   double *const xt_p = lds + oXT + pos_r * 2;                                   // x~ of the block, piece 0 (xc: + (oXC - oXT))
@@ -496,12 +516,14 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   double *const part_p = lds + oPART + (pos_r * lpb + (lane & 15) % lpb) * 2;   // the lane's partial column sums, piece 0
   double *const jl_p = lds + oJ + lane * 2;                                     // Jacobian rows, lane-private
   // hinge slots: constants and state
+  bool h_on[NS];
   double h_ae[NS], h_ab[NS], h_u[NS], h_q[NS], h_kinv[NS], h_z[NS], h_y[NS], h_zb[NS], h_yb[NS], h_xe[NS], h_ge[NS];
   double hJ[JREG ? NS : 1][8];
 #pragma unroll
   for (int q = 0; q < NS; q++) {
     const int h = tab0[(oHROW + q) * 64 + lane], br = tab0[(oHBROW + q) * 64 + lane], ev = tab0[(oHEVAR + q) * 64 + lane];
     const bool on = h >= 0;
+    h_on[q] = on;
     h_ae[q] = on ? As[tab0[(oHEPOS + q) * 64 + lane]] : 0.0;
     h_ab[q] = on ? As[tab0[(oHBPOS + q) * 64 + lane]] : 0.0;
     h_u[q] = on ? usg[h] : 0.0;
@@ -521,7 +543,8 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   // core-variable slots
   double *v_p[NV];                       // address of x~ of the variable (r, x, extra: fixed distances)
   const double *v_pp[NV];                // its component in the first partial-sum slot of its block
-  bool v_on[NV];
+  bool v_on[NV], v_r0on[NV];
+  int v_pkm[NV], v_pkp[NV];               // positions of the variable's neighbours in time inside a block vector (P entries)
   double v_x[NV], v_q[NV], v_a[NV], v_l[NV], v_u[NV], v_z[NV], v_y[NV];
 #pragma unroll
   for (int v = 0; v < NV; v++) {
@@ -533,6 +556,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     v_a[v] = r0 >= 0 ? As[tab0[(oVPOS + v) * 64 + lane]] : 0.0;
     v_l[v] = r0 >= 0 ? lsg[r0] : 0.0; v_u[v] = r0 >= 0 ? usg[r0] : 0.0;
     v_z[v] = r0 >= 0 && resume ? szg[r0] : 0.0; v_y[v] = r0 >= 0 && resume ? syg[r0] : 0.0;
+    v_r0on[v] = r0 >= 0; v_pkm[v] = tab0[(oVPKM + v) * 64 + lane]; v_pkp[v] = tab0[(oVPKP + v) * 64 + lane];
   }
   // extra single rows (a second row on a core variable: pins), one per lane
   const int x_row = tab0[oXROW * 64 + lane];
@@ -558,29 +582,9 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
   // Row / variable indices and scaling constants that only a checked iteration needs.  They are fetched from global memory
   // at the START of that iteration, in front of the sweeps, so that the round trip (L2 or HBM: 68 x 512 B per problem) runs
   // under the iteration's own arithmetic; kept for the whole solve they would cost ~170 registers.
-  struct { int h[NS], r0[NV], var[NV], pkm[NV], pkp[NV]; double hc[NS][3], vc[NV][5], xc; } ck;
   const int pdense = (a.ablate & 32) ? 1 : a.pflag[b];         // P has entries off the three diagonals the compact constants hold
   // delta_y (clipped) / delta_x of the checked iteration: kept in registers for the infeasibility certificates
   struct { double h[NS], b[NS], e[NS], r0[NV], var[NV], x; } dsv;
-  auto load_chk = [&]() {
-    const int *tab = wv_opaque(tab0);
-    const double *c = wv_opaque(cstg0);
-#pragma unroll
-    for (int q = 0; q < NS; q++) {
-      ck.h[q] = tab[(oHROW + q) * 64 + lane];
-#pragma unroll
-      for (int k = 0; k < 3; k++) ck.hc[q][k] = c[(wv_cst_h(q) + k) * 64];
-    }
-#pragma unroll
-    for (int v = 0; v < NV; v++) {
-      ck.r0[v] = tab[(oVROW + v) * 64 + lane]; ck.var[v] = tab[(oVVAR + v) * 64 + lane];
-      ck.pkm[v] = tab[(oVPKM + v) * 64 + lane]; ck.pkp[v] = tab[(oVPKP + v) * 64 + lane];
-#pragma unroll
-      for (int k = 0; k < 5; k++) ck.vc[v][k] = c[(wv_cst_v(NS, v) + k) * 64];
-    }
-    ck.xc = c[wv_cst_x(NS, NV) * 64];
-  };
-
   // One pass over the lane's rows and variables.  MODE 0: initialise (right-hand side of the first iteration from the
   // current x, z, y); 1: a plain iteration; 2: a checked iteration (delta_y / delta_x terms of the infeasibility tests).
   auto rows = [&](auto mode_tag) {
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
           h_y[q] += dy; h_z[q] = zn;
           if (MODE == 2) {
             const double dc = fmax(dy, 0.0);              // clipped to the cone of the bounds (u finite, l = -inf)
-            c_ndy = fmax(c_ndy, wv_recip(ck.hc[q][0]) * fabs(dc)); c_lhs += wc * (h_u[q] * dc);
+            c_ndy = fmax(c_ndy, wv_recip(CKH(q, 0)) * fabs(dc)); c_lhs += wc * (h_u[q] * dc);
             dsv.h[q] = dc;
           }
         }
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
           h_yb[q] += dy; h_zb[q] = zn;
           if (MODE == 2) {
             const double dc = fmin(dy, 0.0);
-            c_ndy = fmax(c_ndy, wv_recip(ck.hc[q][1]) * fabs(dc));           // l = 0: nothing for u' dy+ + l' dy-
+            c_ndy = fmax(c_ndy, wv_recip(CKH(q, 1)) * fabs(dc));           // l = 0: nothing for u' dy+ + l' dy-
             dsv.b[q] = dc;
           }
         }
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         h_xe[q] = xn;
         if (MODE == 2) {
           const double dx = xn - xo;
-          c_ndx = fmax(c_ndx, wv_recip(ck.hc[q][2]) * fabs(dx)); c_qdx += h_q[q] * dx;
+          c_ndx = fmax(c_ndx, wv_recip(CKH(q, 2)) * fabs(dx)); c_qdx += h_q[q] * dx;
           dsv.e[q] = dx;
         }
       }
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         x_y += dy; x_z = zn;
         if (MODE == 2) {
           const double d1 = x_u > WV_BIG ? fmin(dy, 0.0) : dy, dc = x_l < -WV_BIG ? fmax(d1, 0.0) : d1;
-          c_ndy = fmax(c_ndy, wv_recip(ck.xc) * fabs(dc)); c_lhs += x_w * (x_u * fmax(dc, 0.0) + x_l * fmin(dc, 0.0));
+          c_ndy = fmax(c_ndy, wv_recip(CKX) * fabs(dc)); c_lhs += x_w * (x_u * fmax(dc, 0.0) + x_l * fmin(dc, 0.0));
           dsv.x = dc;
         }
       }
@@ -692,11 +696,10 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         v_x[v] = xn;
         if (MODE == 2) {
           const double d1 = v_u[v] > WV_BIG ? fmin(dy, 0.0) : dy, dc = v_l[v] < -WV_BIG ? fmax(d1, 0.0) : d1;
-          const int r0 = ck.r0[v], var = ck.var[v];
-          if (r0 >= 0) { c_ndy = fmax(c_ndy, wv_recip(ck.vc[v][1]) * fabs(dc)); c_lhs += v_u[v] * fmax(dc, 0.0) + v_l[v] * fmin(dc, 0.0); }
+          if (v_r0on[v]) { c_ndy = fmax(c_ndy, wv_recip(CKV(v, 1)) * fabs(dc)); c_lhs += v_u[v] * fmax(dc, 0.0) + v_l[v] * fmin(dc, 0.0); }
           dsv.r0[v] = dc;
           const double dx = xn - xo;
-          if (var >= 0) { c_ndx = fmax(c_ndx, wv_recip(ck.vc[v][0]) * fabs(dx)); c_qdx += v_q[v] * dx; }
+          if (v_on[v]) { c_ndx = fmax(c_ndx, wv_recip(CKV(v, 0)) * fabs(dx)); c_qdx += v_q[v] * dx; }
           dsv.var[v] = dx;
         }
       }
@@ -815,9 +818,6 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
     int next = stop;
     if (a.check > 0) { next = (iter / a.check + 1) * a.check; if (next > stop) next = stop; }
     while (iter + 2 < next) { iter++; if (!(a.ablate & 1)) sweep(); if (!(a.ablate & 2)) rows(std::integral_constant<int, 1>{}); }
-    // the checked iteration's constants are asked for one iteration early: their round trip (L2 / HBM, every wavefront of
-    // the chip at the same moment) then runs under two iterations' arithmetic
-    load_chk();
     if (iter + 1 < next) { iter++; if (!(a.ablate & 1)) sweep(); if (!(a.ablate & 2)) rows(std::integral_constant<int, 1>{}); }
     iter++;
     c_ndy = 0.0; c_lhs = 0.0; c_ndx = 0.0; c_qdx = 0.0;
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
 #pragma unroll
           for (int k = 1; k < BS; k++) s = __builtin_fma(J[k], xc[k], s);
           const double ax = s + h_ae[q] * h_xe[q], axb = h_ab[q] * h_xe[q];
-          const double eh = ck.hc[q][0], eb = ck.hc[q][1], de = ck.hc[q][2];
+          const double eh = CKH(q, 0), eb = CKH(q, 1), de = CKH(q, 2);
           w_pri = fmax(w_pri, fmax(eh * fabs(ax - h_z[q]), eb * fabs(axb - h_zb[q])));
           w_pn = fmax(w_pn, fmax(eh * fmax(fabs(h_z[q]), fabs(ax)), eb * fmax(fabs(h_zb[q]), fabs(axb))));
           const double wy = wc * h_y[q];
@@ -865,14 +865,14 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         *(d2 *)part_p = v0; *(d2 *)(part_p + nslot2) = v1; *(d2 *)(part_p + 2 * nslot2) = v2; *(d2 *)(part_p + 3 * nslot2) = v3;
       }
       {
-        const double xcv = x_p[oXC - oXT], ax = x_a * xcv, ex = ck.xc;
+        const double xcv = x_p[oXC - oXT], ax = x_a * xcv, ex = CKX;
         w_pri = fmax(w_pri, ex * fabs(ax - x_z)); w_pn = fmax(w_pn, ex * fmax(fabs(x_z), fabs(ax)));
         if (x_row >= 0) x_p[oEX - oXT] = x_a * (x_w * x_y);
       }
       WV_SYNC();
 #pragma unroll
       for (int v = 0; v < NV; v++) {
-        const double *c = ck.vc[v];
+        const double c[5] = {CKV(v, 0), CKV(v, 1), CKV(v, 2), CKV(v, 3), CKV(v, 4)};
         const int vix = (int)(v_p[v] - (lds + oXT)), p = (vix % (2 * NPOS)) >> 1;
         const double dj = c[0], e0 = c[1];
         const double ax = v_a[v] * v_x[v];
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         } else {
           for (int s2 = 0; s2 < lpb; s2++) aty += pp[s2 * 2];
         }
-        double px = c[2] * lds[oXC + ck.pkm[v]] + c[3] * lds[oXC + ck.pkp[v]];
+        double px = c[2] * lds[oXC + v_pkm[v]] + c[3] * lds[oXC + v_pkp[v]];
         if (pdense) {
           const double *cd = wv_opaque(cstg0) + (size_t)(wv_cst_v(NS, v) + 5) * 64;
 #pragma unroll
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
               J[0] = j0.x; J[1] = j0.y; J[2] = j1.x; J[3] = j1.y; J[4] = j2.x; J[5] = j2.y; J[6] = j3.x; J[7] = j3.y;
             }
             const double wd = wc * dsv.h[q];
-            nat = fmax(nat, ck.hc[q][2] * fabs(h_ae[q] * wd + h_ab[q] * dsv.b[q]));      // the slack's column
+            nat = fmax(nat, CKH(q, 2) * fabs(h_ae[q] * wd + h_ab[q] * dsv.b[q]));      // the slack's column
 #pragma unroll
             for (int k = 0; k < BS; k++) part[k] = __builtin_fma(J[k], wd, part[k]);
           }
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
           } else {
             for (int s2 = 0; s2 < lpb; s2++) aty += pp[s2 * 2];
           }
-          if (v_on[v]) nat = fmax(nat, ck.vc[v][0] * fabs(aty));
+          if (v_on[v]) nat = fmax(nat, CKV(v, 0) * fabs(aty));
         }
         WV_SYNC();
         nat = wv_wmax(nat);
@@ -963,9 +963,9 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
         double npx = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double *c = ck.vc[v];
+          const double c[5] = {CKV(v, 0), CKV(v, 1), CKV(v, 2), CKV(v, 3), CKV(v, 4)};
           const int vix = (int)(v_p[v] - (lds + oXT)), p = (vix % (2 * NPOS)) >> 1;
-          double px = c[2] * lds[oXC + ck.pkm[v]] + c[3] * lds[oXC + ck.pkp[v]];
+          double px = c[2] * lds[oXC + v_pkm[v]] + c[3] * lds[oXC + v_pkp[v]];
           if (pdense) {
             const double *cd = wv_opaque(cstg0) + (size_t)(wv_cst_v(NS, v) + 5) * 64;
 #pragma unroll
@@ -996,16 +996,16 @@ __global__ __launch_bounds__(WV_T) void qp_admm_wv_kernel(WvArgs a) {
             double s2 = J[0] * dxb[0];
 #pragma unroll
             for (int k = 1; k < BS; k++) s2 = __builtin_fma(J[k], dxb[k], s2);
-            const double adh = ck.hc[q][0] * (s2 + h_ae[q] * dsv.e[q]), adb = ck.hc[q][1] * (h_ab[q] * dsv.e[q]);
-            if (ck.h[q] >= 0 && ((h_u[q] < WV_BIG && adh > thr) || adb < -thr)) badv = 1.0;     // hinge: l = -inf; its slack's bound row: [0, inf)
+            const double adh = CKH(q, 0) * (s2 + h_ae[q] * dsv.e[q]), adb = CKH(q, 1) * (h_ab[q] * dsv.e[q]);
+            if (h_on[q] && ((h_u[q] < WV_BIG && adh > thr) || adb < -thr)) badv = 1.0;     // hinge: l = -inf; its slack's bound row: [0, inf)
           }
 #pragma unroll
           for (int v = 0; v < NV; v++) {
-            const double adx = ck.vc[v][1] * (v_a[v] * dsv.var[v]);
-            if (ck.r0[v] >= 0 && ((v_u[v] < WV_BIG && adx > thr) || (v_l[v] > -WV_BIG && adx < -thr))) badv = 1.0;
+            const double adx = CKV(v, 1) * (v_a[v] * dsv.var[v]);
+            if (v_r0on[v] && ((v_u[v] < WV_BIG && adx > thr) || (v_l[v] > -WV_BIG && adx < -thr))) badv = 1.0;
           }
           if (x_row >= 0) {
-            const double adx = ck.xc * (x_a * x_p[oXC - oXT]);
+            const double adx = CKX * (x_a * x_p[oXC - oXT]);
             if ((x_u < WV_BIG && adx > thr) || (x_l > -WV_BIG && adx < -thr)) badv = 1.0;
           }
           badv = wv_wmax(badv);
