@@ -56,6 +56,8 @@ class CompiledProb(object):
 
 
 def _same(a, b):
+    if a is b:                                  # the usual case: one parameter array shared by the expressions of every timestep
+        return True
     a, b = np.asarray(a), np.asarray(b)
     return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
 
